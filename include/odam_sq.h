@@ -1,0 +1,77 @@
+/*
+ * odam_sq.h -- C ABI of the MI355X (gfx950) super-quadric multi-view fit.
+ *
+ * Drop-in boundary for the reference's (likojack/ODAM) SQ path:
+ *   src/scripts/run_multi_view.py:22-76       optim_process       (per-object driver, host Python)
+ *   src/super_quadric/sq_libs.py:432-475      SuperQuadricOptimizer.run   -> odam_sq_fit_batch
+ *   src/super_quadric/sq_libs.py:577-595      compute_ellipsoid_points    -> odam_sq_points_batch
+ *   learnable_primitives/fast_sampler/sampling.hpp:5-15  sample_on_batch  -> odam_sq_sample
+ *
+ * Conventions: plain pointers and sizes, no exceptions across the boundary, int return code
+ * (0 = OK, otherwise an ODAM_E_* value; odam_last_error() returns a static message), caller-owned
+ * buffers, work is enqueued on the caller's hipStream_t (passed as void*), no synchronisation and
+ * no allocation inside the *_batch calls (all scratch lives in the handle).
+ * Pointers marked [dev] are device pointers, [host] host pointers.
+ */
+#ifndef ODAM_SQ_H
+#define ODAM_SQ_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ODAM_OK 0
+#define ODAM_E_INVALID 1   /* bad argument (null pointer, size out of range) */
+#define ODAM_E_HIP 2       /* a HIP runtime call failed */
+#define ODAM_E_LIMIT 3     /* problem exceeds a compiled limit (views per object, iterations) */
+
+#define ODAM_SQ_POINTS 1000      /* surface samples per super-quadric   (sq_libs.py:545) */
+#define ODAM_SQ_MAX_VIEWS 1024   /* views per object handled by one workgroup */
+
+/* representation codes, sq_libs.py:362-386 */
+#define ODAM_SQ_SUPER_QUADRIC 0  /* 9 parameters optimised */
+#define ODAM_SQ_CUBE 1           /* shapes frozen (caller passes -10000), 7 optimised */
+#define ODAM_SQ_QUADRIC 2        /* shapes frozen at -0, 7 optimised */
+
+typedef struct odam_sq_ctx odam_sq_ctx;
+
+const char* odam_last_error(void);
+
+/* Creates the per-device context: uploads the sampler's constant random draws
+ * (std::mt19937(0), _sampler.pyx:438) and the Adam bias-correction tables for up to max_iters
+ * steps (lr 0.01 / 0.1 for the shape logits, sq_libs.py:373-387). */
+int odam_sq_create(int max_iters, odam_sq_ctx** out);
+int odam_sq_destroy(odam_sq_ctx* ctx);
+
+/*
+ * Fits n_obj super-quadrics, one workgroup per object, n_iters Adam steps each, entirely on device.
+ *   init_params  [dev] [n_obj][9]   translate[3], angle, scales[3] (= sqrt(dims/2)), shapes[2]
+ *   class_id     [dev] [n_obj]      0..7 selects the scale prior row; < 0 = no prior (prior=False)
+ *   view_offsets [dev] [n_obj+1]    object o owns views view_offsets[o] .. view_offsets[o+1]-1
+ *   P            [dev] [sumF][12]   row-major 3x4 projection K @ inv(T_wc)[:3,:] as float32
+ *   tgt          [dev] [sumF][4]    bbox edge in pixels per direction x_min,x_max,y_min,y_max
+ *                                   (the reference stores gt = -pixel and compares with -gt)
+ *   mask         [dev] [sumF][4]    1 = edge is a constraint, 0 = dropped (near the image border)
+ *   prior_icov   [dev] [8][9]       row-major 3x3 inverse covariances, CLASS_MAPPER order
+ *   out_params   [dev] [n_obj][9]
+ *   out_points   [dev] [n_obj][1000][3]  surface of the fitted SQ (compute_ellipsoid_points); nullable
+ *   loss_log     [dev] [n_obj][n_iters]  loss_2d per step (sq_libs.py:471); nullable
+ *   traj         [dev] [n_obj][n_iters][9] parameters after every step; nullable (parity tests)
+ *   max_views    largest view count of any object (host-known; sizes the workgroup's LDS)
+ */
+int odam_sq_fit_batch(odam_sq_ctx* ctx, int n_obj, const float* init_params, const int* class_id,
+                      const int* view_offsets, const float* P, const float* tgt, const float* mask,
+                      const float* prior_icov, int n_iters, int representation, int max_views,
+                      float* out_params, float* out_points, float* loss_log, float* traj,
+                      void* stream);
+
+/* Surface points of n super-quadrics: params [dev][n][9] -> out_points [dev][n][1000][3]. */
+int odam_sq_points_batch(odam_sq_ctx* ctx, int n, const float* params, float* out_points, void* stream);
+
+/* Host-side sampler with the reference's C signature semantics for B = M = 1, N = 1000,
+ * buffer_size = 201, seed = 0:  a[3], e[2] -> etas[1000], omegas[1000]  (all [host]). */
+int odam_sq_sample(const float* a, const float* e, float* etas, float* omegas);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

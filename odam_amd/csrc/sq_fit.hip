@@ -1,0 +1,583 @@
+// sq_fit.hip -- persistent per-object super-quadric multi-view fit for gfx950 (MI355X).
+//
+// One 512-thread workgroup (8 wavefronts of 64) owns one object for all Adam steps; parameters,
+// Adam moments, the 1000 surface points, the sampler's theta buffers / CDF and the per-view
+// gradient rows live in LDS for the whole fit, so HBM sees only the view constraints
+// (48 + 32 bytes per view) streamed once per step through L2 and one 36-byte result per object.
+//
+// Replaces (reference, likojack/ODAM): SuperQuadricOptimizer.run  src/super_quadric/sq_libs.py:432-475
+// with everything it calls per step: fast_sampler/sampling.cpp:158-215 (surface sampler),
+// learnable_primitives/sampling.py:558-622 (points), sq_libs.py:395-430 (projected-extent
+// residual), autograd (closed form in sq_core.h::edge_grad), torch.optim.Adam (sq_libs.py:373-387).
+//
+// Phases of one step (barriers between them):
+//   A  shape scalars (cos/sin of yaw, a = s^2, e = squashing(h))            7 lanes
+//   B  equal-arc-length subdivision of the two super-ellipses, breadth first:
+//      every pending arc is independent of its siblings, so one level = one parallel step
+//   C  CDF terms + per-buffer-entry trig/power factors (201 + 201 + 201 lanes), then the
+//      strictly sequential float32 prefix sum on one lane, then normalisation
+//   D  1000 lanes: inverse-CDF lookup, surface point, rotate + translate -> LDS
+//   E  views dealt to wavefronts; per view each lane projects 16 points, keeps the four
+//      running extremes (value, first index), 6-step xor butterfly merges the 64 lanes;
+//      winners of up to 16 views are parked one (view, direction) per lane and the closed-form
+//      gradient runs on all 64 lanes at once; 2 more xor steps add the four directions
+//   F  fixed-shape pairwise tree over the per-view gradient rows, prior, Adam on 9 lanes
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (division and sqrt are the
+// correctly rounded forms, hipcc's default).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../include/odam_sq.h"
+#include "odam_err.h"
+#include "sq_core.h"
+
+namespace {
+using namespace odam_sq;
+
+constexpr int NT = 512;         // threads per workgroup (8 wavefronts, 2 per SIMD -> 256 VGPRs each)
+constexpr int NW = NT / 64;     // wavefronts per workgroup
+constexpr int BUFP = 208;       // padded theta-buffer length
+constexpr int QCAP = 200;       // pending arcs per curve per level (sum of n over a level <= 199)
+constexpr int PTS_PER_LANE = 16;  // ceil(1000 / 64)
+constexpr int NONE = 0x7fffffff;
+
+struct FitArgs {
+    const float* init_params;
+    const int* class_id;
+    const int* view_offsets;
+    const float* P;
+    const float* tgt;
+    const float* mask;
+    const float* prior_icov;
+    const float* draws;               // [1000] uniform draws for eta
+    const unsigned short* omega_idx;  // [1000] buffer index of omega
+    const float* adam_tab;            // [max_iters][4]: -lr/bc1 (main), -lr/bc1 (shapes), sqrt(bc2), pad
+    int n_iters;
+    int representation;
+    int pn_views;                     // power of two >= max views per object (LDS sizing)
+    float* out_params;
+    float* out_points;
+    float* loss_log;
+    float* traj;
+};
+
+struct Lds {
+    float* p;       // [12]
+    float* m;       // [12]
+    float* v;       // [12]
+    float* s0;      // [4]
+    float* icov;    // [12]
+    float* shape;   // [12]  c, s, a0..2, e0..1, sig0..1
+    float* misc;    // [8]   cdf sum, dirsum[4]
+    int* cnt;       // [8]   3 x 2 level counters
+    float* pwx;     // [1024] x3
+    float* pwy;
+    float* pwz;
+    unsigned short* ie;  // [1024]
+    unsigned short* io;  // [1024]
+    float* buf;     // [2][BUFP]
+    float* cdf;     // [BUFP]
+    float* term;    // [BUFP]
+    float* fac;     // [8][BUFP]  ce, se, f1, fz, cw, sw, f2, fs2
+    Arc* q;         // [2 curves][2][QCAP]
+    float* vgrad;   // [pn][9]
+    float* lterm;   // [pn][4]
+};
+
+__host__ __device__ inline size_t lds_words(int pn) {
+    return 12 * 6 + 8 + 8 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 8 +
+           (size_t)pn * 9 + (size_t)pn * 4;
+}
+
+__device__ inline Lds carve(float* base, int pn) {
+    Lds L;
+    float* w = base;
+    L.p = w; w += 12;
+    L.m = w; w += 12;
+    L.v = w; w += 12;
+    L.s0 = w; w += 12;
+    L.icov = w; w += 12;
+    L.shape = w; w += 12;
+    L.misc = w; w += 8;
+    L.cnt = (int*)w; w += 8;
+    L.pwx = w; w += 1024;
+    L.pwy = w; w += 1024;
+    L.pwz = w; w += 1024;
+    L.ie = (unsigned short*)w; w += 512;
+    L.io = (unsigned short*)w; w += 512;
+    L.buf = w; w += 2 * BUFP;
+    L.cdf = w; w += BUFP;
+    L.term = w; w += BUFP;
+    L.fac = w; w += 8 * BUFP;
+    L.q = (Arc*)w; w += 2 * 2 * QCAP * 8;
+    L.vgrad = w; w += (size_t)pn * 9;
+    L.lterm = w;
+    return L;
+}
+
+__device__ inline Shape load_shape(const float* s) {
+    Shape S;
+    S.c = s[0]; S.s = s[1];
+    S.a[0] = s[2]; S.a[1] = s[3]; S.a[2] = s[4];
+    S.e[0] = s[5]; S.e[1] = s[6];
+    S.sig[0] = s[7]; S.sig[1] = s[8];
+    return S;
+}
+
+// lexicographic (value, first index) merge of two candidates
+__device__ inline void merge_min(float& v, int& i, float ov, int oi) {
+    if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+__device__ inline void merge_max(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
+    extern __shared__ __align__(16) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int obj = blockIdx.x;
+    Lds L = carve(smem, A.pn_views);
+
+    int v0 = 0, F = 0;
+    if (A.view_offsets) {
+        v0 = A.view_offsets[obj];
+        F = A.view_offsets[obj + 1] - v0;
+    }
+    const float* Pm = A.P + (size_t)12 * v0;
+    const float* tgt = A.tgt + (size_t)4 * v0;
+    const float* msk = A.mask + (size_t)4 * v0;
+    const int cls = A.class_id ? A.class_id[obj] : -1;
+    const bool use_prior = (cls >= 0) && (A.prior_icov != nullptr);
+    const int n_opt = (A.representation == ODAM_SQ_SUPER_QUADRIC) ? 9 : 7;
+    const bool want_loss = (A.loss_log != nullptr);
+
+    if (tid < 9) {
+        L.p[tid] = A.init_params[(size_t)obj * 9 + tid];
+        L.m[tid] = 0.0f;
+        L.v[tid] = 0.0f;
+        if (use_prior) L.icov[tid] = A.prior_icov[cls * 9 + tid];
+    }
+    if (tid < 3) L.s0[tid] = A.init_params[(size_t)obj * 9 + 4 + tid];
+    __syncthreads();
+
+    int Pn = 1;
+    while (Pn < F) Pn <<= 1;
+    const float invF = 1.0f / (float)F;
+    int chunk = (F + NW - 1) / NW;
+    if (chunk > 16) chunk = 16;
+    if (chunk < 1) chunk = 1;
+    const int nchunks = (F + chunk - 1) / chunk;
+
+    for (int it = 0; it <= A.n_iters; ++it) {
+        // ---------------- A: shape scalars ------------------------------------------------------
+        if (tid == 0) L.shape[0] = cosf_(L.p[3]);
+        else if (tid == 1) L.shape[1] = sinf_(L.p[3]);
+        else if (tid < 5) L.shape[tid] = L.p[2 + tid] * L.p[2 + tid];          // a = scales^2
+        else if (tid < 7) {
+            float sg = 1.0f / (1.0f + expf_(-L.p[2 + tid]));                      // shapes at p[7], p[8]
+            L.shape[2 + tid] = sg;                                                // sig -> [7], [8]
+            L.shape[tid] = sg * 1.4f + 0.2f;                                      // e   -> [5], [6]
+        }
+        __syncthreads();
+        const Shape S = load_shape(L.shape);
+        float p[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) p[k] = L.p[k];
+
+        // ---------------- B: breadth-first arc subdivision -------------------------------------
+        // curve 0: eta  (a1, a3, e1) from +pi/2 to -pi/2;  curve 1: omega (a1, a2, e2) from +pi to -pi
+        {
+            const int j = tid >> 6;  // lanes 0 of waves 0..3 evaluate the four end points
+            if (lane == 0 && j < 4) {
+                const int c = j >> 1, end = j & 1;
+                const float a1 = S.a[0], a2 = c ? S.a[1] : S.a[2], e = S.e[c];
+                const float ta = c ? PI_F : PI_F / 2;
+                const float th = end ? -ta : ta;
+                float cx, cy;
+                xy(th, a1, a2, e, cx, cy);
+                Arc* root = &L.q[(c * 2 + 0) * QCAP];
+                if (end == 0) {
+                    root->ax = cx; root->ay = cy; root->ta = th;
+                    root->n = BUF - 2; root->off = 1;
+                    L.buf[c * BUFP] = th;
+                } else {
+                    root->bx = cx; root->by = cy; root->tb = th;
+                    L.buf[c * BUFP + BUF - 1] = th;
+                }
+            }
+            if (tid < 6) L.cnt[tid] = (tid < 2) ? 1 : 0;
+        }
+        __syncthreads();
+        for (int lvl = 0; lvl < BUF; ++lvl) {
+            const int cur = lvl % 3, nxt = (lvl + 1) % 3, clr = (lvl + 2) % 3;
+            const int n0 = L.cnt[cur * 2 + 0], n1 = L.cnt[cur * 2 + 1];
+            if ((n0 | n1) == 0) break;
+            if (tid < 2) L.cnt[clr * 2 + tid] = 0;
+            for (int w = tid; w < 512; w += NT) {
+                const int c = w >> 8, i = w & 255;
+                if (i >= (c ? n1 : n0)) continue;
+                const Arc nd = L.q[(c * 2 + (lvl & 1)) * QCAP + i];
+                const float a1 = S.a[0], a2 = c ? S.a[1] : S.a[2], e = S.e[c];
+                Arc lf, rt;
+                float th;
+                const int slot = arc_step(nd, a1, a2, e, th, lf, rt);
+                L.buf[c * BUFP + slot] = th;
+                Arc* qn = &L.q[(c * 2 + ((lvl + 1) & 1)) * QCAP];
+                if (lf.n > 0) qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = lf;
+                if (rt.n > 0) qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = rt;
+            }
+            __syncthreads();
+        }
+
+        // ---------------- C: CDF and per-entry factors ----------------------------------------
+        for (int w = tid; w < 768; w += NT) {
+            const int grp = w >> 8, k = w & 255;
+            if (k >= BUF) continue;
+            if (grp == 0) {
+                if (k >= 1) L.term[k] = (S.a[0] + S.a[1]) * fexp(cosf_(L.buf[k]), S.e[0]);
+            } else {
+                const int c = grp - 1;
+                float ct, st, fc, fs;
+                entry_factors(L.buf[c * BUFP + k], S.e[c], ct, st, fc, fs);
+                L.fac[(4 * c + 0) * BUFP + k] = ct; L.fac[(4 * c + 1) * BUFP + k] = st;
+                L.fac[(4 * c + 2) * BUFP + k] = fc; L.fac[(4 * c + 3) * BUFP + k] = fs;
+            }
+        }
+        __syncthreads();
+        if (tid == 0) {  // sampling.cpp:141-146: strictly ordered float32 running sum
+            float c = 0.001f;
+            L.cdf[0] = c;
+            for (int i = 1; i < BUF; i++) {
+                c = c + 0.001f + L.term[i];
+                L.cdf[i] = c;
+            }
+            L.misc[0] = c;
+        }
+        __syncthreads();
+        if (tid < BUF) L.cdf[tid] = L.cdf[tid] / L.misc[0];
+        __syncthreads();
+
+        // ---------------- D: inverse-CDF lookup + surface points --------------------------------
+        for (int i = tid; i < N_PTS; i += NT) {
+            const float r = A.draws[i];
+            int lo = 0, hi = BUF;  // std::lower_bound
+            while (lo < hi) {
+                const int mid = lo + ((hi - lo) >> 1);
+                if (L.cdf[mid] < r) lo = mid + 1; else hi = mid;
+            }
+            const int ke = lo, ko = A.omega_idx[i];
+            float raw[3], po[3], pw[3];
+            surface_point(S, p, L.fac[2 * BUFP + ke], L.fac[3 * BUFP + ke], L.fac[6 * BUFP + ko],
+                          L.fac[7 * BUFP + ko], raw, po, pw);
+            L.pwx[i] = pw[0]; L.pwy[i] = pw[1]; L.pwz[i] = pw[2];
+            L.ie[i] = (unsigned short)ke;
+            L.io[i] = (unsigned short)ko;
+        }
+        __syncthreads();
+
+        if (it == A.n_iters) {
+            if (A.out_points) {
+                for (int i = tid; i < N_PTS; i += NT) {
+                    float* o = A.out_points + ((size_t)obj * N_PTS + i) * 3;
+                    o[0] = L.pwx[i]; o[1] = L.pwy[i]; o[2] = L.pwz[i];
+                }
+            }
+            break;
+        }
+
+        // ---------------- E: projected extents + per-view gradient rows -----------------------
+        float px[PTS_PER_LANE], py[PTS_PER_LANE], pz[PTS_PER_LANE];
+#pragma unroll
+        for (int j = 0; j < PTS_PER_LANE; j++) {
+            const int i = lane + 64 * j;
+            const bool ok = i < N_PTS;
+            px[j] = ok ? L.pwx[i] : 0.0f;
+            py[j] = ok ? L.pwy[i] : 0.0f;
+            pz[j] = ok ? L.pwz[i] : 0.0f;
+        }
+        for (int ch = wid; ch < nchunks; ch += NW) {
+            const int base = ch * chunk;
+            float my_ext = 0.0f;
+            int my_win = NONE;
+            for (int vi = 0; vi < chunk; ++vi) {
+                const int f = base + vi;
+                if (f >= F) break;
+                const float* M = Pm + (size_t)12 * f;
+                const float m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
+                const float m4 = M[4], m5 = M[5], m6 = M[6], m7 = M[7];
+                const float m8 = M[8], m9 = M[9], m10 = M[10], m11 = M[11];
+                float bv0 = 1000000.0f, bv1 = -1000000.0f, bv2 = 1000000.0f, bv3 = -1000000.0f;
+                int bi0 = NONE, bi1 = NONE, bi2 = NONE, bi3 = NONE;
+#pragma unroll
+                for (int j = 0; j < PTS_PER_LANE; j++) {
+                    const int i = lane + 64 * j;
+                    const float qz = proj_row(px[j], py[j], pz[j], m8, m9, m10, m11);
+                    if (i < N_PTS && qz > 0.5f) {
+                        const float qx = proj_row(px[j], py[j], pz[j], m0, m1, m2, m3);
+                        const float qy = proj_row(px[j], py[j], pz[j], m4, m5, m6, m7);
+                        const float den = absf(qz) + 1e-6f;
+                        const float u = qx / den, v = qy / den;
+                        if (u < bv0) { bv0 = u; bi0 = i; }
+                        if (u > bv1) { bv1 = u; bi1 = i; }
+                        if (v < bv2) { bv2 = v; bi2 = i; }
+                        if (v > bv3) { bv3 = v; bi3 = i; }
+                    }
+                }
+#pragma unroll
+                for (int sft = 32; sft >= 1; sft >>= 1) {
+                    merge_min(bv0, bi0, __shfl_xor(bv0, sft), __shfl_xor(bi0, sft));
+                    merge_max(bv1, bi1, __shfl_xor(bv1, sft), __shfl_xor(bi1, sft));
+                    merge_min(bv2, bi2, __shfl_xor(bv2, sft), __shfl_xor(bi2, sft));
+                    merge_max(bv3, bi3, __shfl_xor(bv3, sft), __shfl_xor(bi3, sft));
+                }
+                if ((lane >> 2) == vi) {
+                    const int d = lane & 3;
+                    my_ext = (d == 0) ? bv0 : (d == 1) ? bv1 : (d == 2) ? bv2 : bv3;
+                    my_win = (d == 0) ? bi0 : (d == 1) ? bi1 : (d == 2) ? bi2 : bi3;
+                }
+            }
+            // closed-form gradient: lane = (view in chunk) * 4 + direction
+            const int f = base + (lane >> 2);
+            const int d = lane & 3;
+            const bool active = ((lane >> 2) < chunk) && (f < F);
+            float g9[9];
+            float lm = 0.0f;
+            if (active) {
+                const bool has = (my_win != NONE);
+                Winner W;
+                if (has) {
+                    const int ke = L.ie[my_win], ko = L.io[my_win];
+                    W.ce = L.fac[0 * BUFP + ke]; W.se = L.fac[1 * BUFP + ke];
+                    W.f1 = L.fac[2 * BUFP + ke]; W.fz = L.fac[3 * BUFP + ke];
+                    W.cw = L.fac[4 * BUFP + ko]; W.sw = L.fac[5 * BUFP + ko];
+                    W.f2 = L.fac[6 * BUFP + ko]; W.fs2 = L.fac[7 * BUFP + ko];
+                    surface_point(S, p, W.f1, W.fz, W.f2, W.fs2, W.raw, W.po, W.pw);
+                } else {
+                    W = Winner{};
+                }
+                float Mv[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) Mv[k] = Pm[(size_t)12 * f + k];
+                lm = edge_grad(d, my_ext, has, tgt[4 * f + d], msk[4 * f + d], invF, Mv, S, p, W,
+                               n_opt == 9, g9);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 9; k++) g9[k] = 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                g9[k] = g9[k] + __shfl_xor(g9[k], 1);   // (d0+d1), (d2+d3)
+                g9[k] = g9[k] + __shfl_xor(g9[k], 2);   // (d0+d1)+(d2+d3)
+            }
+            if (active) {
+                if (d == 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) L.vgrad[f * 9 + k] = g9[k];
+                }
+                if (want_loss) L.lterm[f * 4 + d] = lm;
+            }
+        }
+        for (int idx = tid; idx < (Pn - F) * 9; idx += NT) L.vgrad[F * 9 + idx] = 0.0f;
+        __syncthreads();
+
+        // ---------------- F: tree over views, prior, Adam ---------------------------------------
+        if (want_loss) {
+            if (tid >= 64 && tid < 68) {
+                const int dd = tid - 64;
+                float s = 0.0f;
+                for (int f = 0; f < F; f++) s += L.lterm[f * 4 + dd];
+                L.misc[1 + dd] = s;
+            }
+        }
+        for (int stride = Pn >> 1; stride >= 1; stride >>= 1) {
+            for (int idx = tid; idx < stride * 9; idx += NT) L.vgrad[idx] += L.vgrad[idx + stride * 9];
+            __syncthreads();
+        }
+        if (tid < 9) {
+            float g = (F > 0) ? L.vgrad[tid] : 0.0f;
+            if (use_prior && tid >= 4 && tid < 7) {
+                float gs[3];
+                prior_term(L.icov, L.s0, p, gs);
+                g += gs[tid - 4];
+            }
+            if (tid < n_opt) {
+                const float* tab = A.adam_tab + 4 * it;
+                float pp = L.p[tid], mm = L.m[tid], vv = L.v[tid];
+                adam_scalar(pp, mm, vv, g, (tid < 7) ? tab[0] : tab[1], tab[2]);
+                L.p[tid] = pp; L.m[tid] = mm; L.v[tid] = vv;
+            }
+            if (A.traj) A.traj[((size_t)obj * A.n_iters + it) * 9 + tid] = L.p[tid];
+        }
+        if (want_loss && tid == 0) {
+            float l2d = 0.0f;
+            for (int dd = 0; dd < 4; dd++) l2d += L.misc[1 + dd] * invF;
+            A.loss_log[(size_t)obj * A.n_iters + it] = l2d;
+        }
+        __syncthreads();
+    }
+    if (A.out_params && tid < 9) A.out_params[(size_t)obj * 9 + tid] = L.p[tid];
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct odam_sq_ctx {
+    int max_iters;
+    float* d_draws;
+    unsigned short* d_omega_idx;
+    float* d_adam;
+    float* d_dummy_params;
+};
+
+static std::vector<float> sampler_draws() {
+    // sampling.cpp:18-28 with seed 0 (_sampler.pyx:438): identical generator, identical draws
+    std::mt19937 gen(0);
+    std::uniform_real_distribution<float> dis(0, 1);
+    std::vector<float> d(2 * N_PTS);
+    for (auto& x : d) x = dis(gen);
+    return d;
+}
+
+extern "C" int odam_sq_create(int max_iters, odam_sq_ctx** out) {
+    if (!out || max_iters < 0) return odam_fail(ODAM_E_INVALID, "odam_sq_create: bad arguments");
+    std::vector<float> draws = sampler_draws();
+    std::vector<unsigned short> oidx(N_PTS);
+    for (int i = 0; i < N_PTS; i++) {
+        int k = (int)(draws[N_PTS + i] * (float)BUF);  // sampling.cpp:211
+        if (k < 0 || k >= BUF) return odam_fail(ODAM_E_INVALID, "sampler draw table out of range");
+        oidx[i] = (unsigned short)k;
+    }
+    std::vector<float> tab((size_t)4 * (max_iters + 1), 0.0f);
+    for (int t = 1; t <= max_iters; t++) {  // torch/optim/adam.py _single_tensor_adam, float64 scalars
+        double bc1 = 1.0 - std::pow(0.9, (double)t);
+        double bc2 = 1.0 - std::pow(0.999, (double)t);
+        tab[4 * (t - 1) + 0] = (float)(-(0.01 / bc1));
+        tab[4 * (t - 1) + 1] = (float)(-(0.1 / bc1));
+        tab[4 * (t - 1) + 2] = (float)std::pow(bc2, 0.5);
+    }
+    odam_sq_ctx* c = new odam_sq_ctx();
+    c->max_iters = max_iters;
+    ODAM_HIP(hipMalloc(&c->d_draws, sizeof(float) * N_PTS));
+    ODAM_HIP(hipMalloc(&c->d_omega_idx, sizeof(unsigned short) * N_PTS));
+    ODAM_HIP(hipMalloc(&c->d_adam, sizeof(float) * tab.size()));
+    ODAM_HIP(hipMemcpy(c->d_draws, draws.data(), sizeof(float) * N_PTS, hipMemcpyHostToDevice));
+    ODAM_HIP(hipMemcpy(c->d_omega_idx, oidx.data(), sizeof(unsigned short) * N_PTS, hipMemcpyHostToDevice));
+    ODAM_HIP(hipMemcpy(c->d_adam, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+    ODAM_HIP(hipFuncSetAttribute((const void*)sq_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 160 * 1024));
+    *out = c;
+    return ODAM_OK;
+}
+
+extern "C" int odam_sq_destroy(odam_sq_ctx* c) {
+    if (!c) return ODAM_OK;
+    (void)hipFree(c->d_draws);
+    (void)hipFree(c->d_omega_idx);
+    (void)hipFree(c->d_adam);
+    delete c;
+    return ODAM_OK;
+}
+
+static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hipStream_t stream) {
+    int pn = 1;
+    while (pn < max_views) pn <<= 1;
+    A.pn_views = pn;
+    A.draws = ctx->d_draws;
+    A.omega_idx = ctx->d_omega_idx;
+    A.adam_tab = ctx->d_adam;
+    size_t bytes = lds_words(pn) * sizeof(float);
+    if (bytes > 160 * 1024) return odam_fail(ODAM_E_LIMIT, "odam_sq: LDS budget exceeded");
+    hipLaunchKernelGGL(sq_fit_kernel, dim3(n_obj), dim3(NT), bytes, stream, A);
+    ODAM_HIP(hipGetLastError());
+    return ODAM_OK;
+}
+
+extern "C" int odam_sq_fit_batch(odam_sq_ctx* ctx, int n_obj, const float* init_params, const int* class_id,
+                                 const int* view_offsets, const float* P, const float* tgt,
+                                 const float* mask, const float* prior_icov, int n_iters,
+                                 int representation, int max_views, float* out_params, float* out_points,
+                                 float* loss_log, float* traj, void* stream) {
+    if (!ctx || !init_params || !view_offsets || !P || !tgt || !mask || !out_params)
+        return odam_fail(ODAM_E_INVALID, "odam_sq_fit_batch: null pointer");
+    if (n_obj < 0 || n_iters < 0 || representation < 0 || representation > 2)
+        return odam_fail(ODAM_E_INVALID, "odam_sq_fit_batch: bad size / representation");
+    if (n_iters > ctx->max_iters) return odam_fail(ODAM_E_LIMIT, "odam_sq_fit_batch: n_iters > max_iters of the context");
+    if (max_views < 1 || max_views > ODAM_SQ_MAX_VIEWS)
+        return odam_fail(ODAM_E_LIMIT, "odam_sq_fit_batch: max_views outside 1..ODAM_SQ_MAX_VIEWS");
+    if (n_obj == 0) return ODAM_OK;
+    FitArgs A{};
+    A.init_params = init_params; A.class_id = class_id; A.view_offsets = view_offsets;
+    A.P = P; A.tgt = tgt; A.mask = mask; A.prior_icov = prior_icov;
+    A.n_iters = n_iters; A.representation = representation;
+    A.out_params = out_params; A.out_points = out_points; A.loss_log = loss_log; A.traj = traj;
+    return launch_fit(ctx, n_obj, A, max_views, (hipStream_t)stream);
+}
+
+extern "C" int odam_sq_points_batch(odam_sq_ctx* ctx, int n, const float* params, float* out_points,
+                                    void* stream) {
+    if (!ctx || !params || !out_points || n < 0) return odam_fail(ODAM_E_INVALID, "odam_sq_points_batch: bad arguments");
+    if (n == 0) return ODAM_OK;
+    FitArgs A{};
+    A.init_params = params;
+    A.n_iters = 0;
+    A.representation = ODAM_SQ_SUPER_QUADRIC;
+    A.out_params = nullptr;
+    A.out_points = out_points;
+    return launch_fit(ctx, n, A, 1, (hipStream_t)stream);
+}
+
+// host sampler: same leaf arithmetic as the device path, serial walk (sampling.cpp:158-215)
+static void host_subdivide(const Arc& nd, float a1, float a2, float e, float* buf) {
+    if (nd.n <= 0) return;
+    Arc lf, rt;
+    float th;
+    int slot = arc_step(nd, a1, a2, e, th, lf, rt);
+    buf[slot] = th;
+    host_subdivide(lf, a1, a2, e, buf);
+    host_subdivide(rt, a1, a2, e, buf);
+}
+
+static void host_buffer(float a1, float a2, float e, float ta, float tb, float* buf) {
+    Arc root;
+    xy(ta, a1, a2, e, root.ax, root.ay);
+    xy(tb, a1, a2, e, root.bx, root.by);
+    root.ta = ta; root.tb = tb; root.n = BUF - 2; root.off = 1;
+    buf[0] = ta;
+    host_subdivide(root, a1, a2, e, buf);
+    buf[BUF - 1] = tb;
+}
+
+extern "C" int odam_sq_sample(const float* a, const float* e, float* etas, float* omegas) {
+    if (!a || !e || !etas || !omegas) return odam_fail(ODAM_E_INVALID, "odam_sq_sample: null pointer");
+    static const std::vector<float> draws = sampler_draws();
+    float buf[BUF], cdf[BUF];
+    host_buffer(a[0], a[2], e[0], PI_F / 2, -(PI_F / 2), buf);
+    float c = 0.001f;
+    cdf[0] = c;
+    for (int i = 1; i < BUF; i++) {
+        c = c + 0.001f + (a[0] + a[1]) * fexp(cosf_(buf[i]), e[0]);
+        cdf[i] = c;
+    }
+    for (int i = 0; i < BUF; i++) cdf[i] = cdf[i] / c;
+    for (int i = 0; i < N_PTS; i++) {
+        int lo = 0, hi = BUF;
+        while (lo < hi) {
+            int mid = lo + ((hi - lo) >> 1);
+            if (cdf[mid] < draws[i]) lo = mid + 1; else hi = mid;
+        }
+        etas[i] = buf[lo];
+    }
+    host_buffer(a[0], a[1], e[1], PI_F, -PI_F, buf);
+    for (int i = 0; i < N_PTS; i++) omegas[i] = buf[(int)(draws[N_PTS + i] * (float)BUF)];
+    return ODAM_OK;
+}

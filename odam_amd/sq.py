@@ -1,0 +1,162 @@
+"""Host side of the super-quadric multi-view fit: thin Python over the C ABI (include/odam_sq.h).
+
+Mirrors the pieces of the reference (likojack/ODAM) that sit around SuperQuadricOptimizer.run:
+  src/super_quadric/sq_libs.py:353-393  (init: scales -> sqrt(dims/2), shapes = -0 / -10000, prior table)
+  src/super_quadric/sq_libs.py:438-451  (gt / mask arrays per direction)
+  src/super_quadric/sq_libs.py:13-22    (CLASS_MAPPER order of the prior rows)
+"""
+import ctypes
+import os
+import pickle
+
+import numpy as np
+import torch
+
+from . import _lib
+
+N_POINTS = 1000
+MAX_VIEWS = 1024
+NAMES = ("x_min", "x_max", "y_min", "y_max")  # sq_libs.py:438
+REPRESENTATIONS = {"super_quadric": 0, "cube": 1, "quadric": 2}
+# sq_libs.py:13-22
+CLASS_MAPPER = {0: "03211117", 1: "04379243", 2: "02808440", 3: "02747177",
+                4: "04256520", 5: "03001627", 6: "02933112", 7: "02871439"}
+
+_PRIOR_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "scale_prior.npz")
+
+
+def load_scale_prior(path=None):
+    """[8, 9] float32 inverse covariances in CLASS_MAPPER order.
+
+    `path` may be the reference's pickle (src/super_quadric/scale_prior, a dict synset -> 3x3
+    float64) or None for the copy of those 72 numbers shipped in odam_amd/data/scale_prior.npz.
+    """
+    if path is None:
+        z = np.load(_PRIOR_PATH)
+        return z["icov"].astype(np.float32).reshape(8, 9)
+    with open(path, "rb") as f:
+        d = pickle.load(f)
+    return np.stack([np.asarray(d[CLASS_MAPPER[k]], np.float64).astype(np.float32).reshape(9)
+                     for k in range(8)])
+
+
+def lines_to_targets(bbox_lines):
+    """list (per valid frame) of {name: [a, b, -pixel]} -> tgt[F,4], mask[F,4] float32 (sq_libs.py:438-451)."""
+    F = len(bbox_lines)
+    tgt = np.zeros((F, 4), np.float32)
+    mask = np.zeros((F, 4), np.float32)
+    for f, d in enumerate(bbox_lines):
+        for k, name in enumerate(NAMES):
+            if name in d:
+                mask[f, k] = 1.0
+                # gt = float32(line[-1]) = -pixel; the residual compares with -gt
+                tgt[f, k] = -np.float32(d[name][-1])
+    return tgt, mask
+
+
+def init_params(translate, angle, dims, representation="super_quadric"):
+    """SuperQuadricOptimizer.__init__ (sq_libs.py:353-371): 9 float32 parameters."""
+    scales = np.sqrt(np.asarray(dims, np.float64) / 2)
+    shapes = np.array([-10000.0, -10000.0]) if representation == "cube" else np.array([-0.0, -0.0])
+    return np.concatenate([np.asarray(translate, np.float64).reshape(3), [float(angle)], scales,
+                           shapes]).astype(np.float32)
+
+
+class SqFitter:
+    """Owns the device context (constant sampler draws + Adam tables)."""
+
+    def __init__(self, device="cuda:0", max_iters=200):
+        self.device = torch.device(device)
+        self.max_iters = int(max_iters)
+        L = _lib.lib()
+        with torch.cuda.device(self.device):
+            h = ctypes.c_void_p()
+            _lib.check(L.odam_sq_create(ctypes.c_int(self.max_iters), ctypes.byref(h)), "odam_sq_create")
+        self._h = h
+        self._prior = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().odam_sq_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _prior_dev(self):
+        if self._prior is None:
+            self._prior = torch.from_numpy(load_scale_prior()).to(self.device).contiguous()
+        return self._prior
+
+    def fit(self, params0, class_ids, view_counts, P, tgt, mask, n_iters=200, representation="super_quadric",
+            prior=True, want_points=True, want_loss=False, want_traj=False):
+        """Batched SuperQuadricOptimizer.run.
+
+        params0 [n,9] f32; class_ids [n] int; view_counts [n] int; P [sumF,3,4]/[sumF,12] f32;
+        tgt, mask [sumF,4] f32 (numpy or torch, host or device).  Returns dict of device tensors.
+        """
+        dev = self.device
+        n = len(view_counts)
+        as_dev = lambda x, dt: torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(
+            device=dev, dtype=dt).contiguous()
+        vc = np.asarray(view_counts, np.int64)
+        if n == 0:
+            return {"params": torch.zeros(0, 9, device=dev), "points": torch.zeros(0, N_POINTS, 3, device=dev)}
+        if vc.min() < 1 or vc.max() > MAX_VIEWS:
+            raise _lib.OdamError(f"views per object must be in 1..{MAX_VIEWS}, got {vc.min()}..{vc.max()}")
+        offs = np.zeros(n + 1, np.int32)
+        offs[1:] = np.cumsum(vc)
+        d_p0 = as_dev(params0, torch.float32).reshape(n, 9)
+        cls = np.asarray(class_ids, np.int32).copy()
+        if prior:
+            if cls.min() < 0 or cls.max() > 7:
+                raise KeyError(int(cls.max()))  # CLASS_MAPPER covers 0..7 only (sq_libs.py:464)
+        else:
+            cls[:] = -1
+        d_cls = as_dev(cls, torch.int32)
+        d_off = as_dev(offs, torch.int32)
+        d_P = as_dev(P, torch.float32).reshape(-1, 12)
+        d_t = as_dev(tgt, torch.float32).reshape(-1, 4)
+        d_m = as_dev(mask, torch.float32).reshape(-1, 4)
+        assert d_P.shape[0] == offs[-1] and d_t.shape[0] == offs[-1] and d_m.shape[0] == offs[-1]
+        out_p = torch.empty(n, 9, device=dev, dtype=torch.float32)
+        out_pts = torch.empty(n, N_POINTS, 3, device=dev, dtype=torch.float32) if want_points else None
+        loss = torch.empty(n, n_iters, device=dev, dtype=torch.float32) if want_loss else None
+        traj = torch.empty(n, n_iters, 9, device=dev, dtype=torch.float32) if want_traj else None
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().odam_sq_fit_batch(
+                self._h, ctypes.c_int(n), _lib.ptr(d_p0), _lib.ptr(d_cls), _lib.ptr(d_off), _lib.ptr(d_P),
+                _lib.ptr(d_t), _lib.ptr(d_m), _lib.ptr(self._prior_dev()), ctypes.c_int(int(n_iters)),
+                ctypes.c_int(REPRESENTATIONS[representation]), ctypes.c_int(int(vc.max())),
+                _lib.ptr(out_p), _lib.ptr(out_pts), _lib.ptr(loss), _lib.ptr(traj),
+                ctypes.c_void_p(stream)), "odam_sq_fit_batch")
+        return {"params": out_p, "points": out_pts, "loss": loss, "traj": traj}
+
+    def points(self, params):
+        """compute_ellipsoid_points for [n,9] parameter rows -> [n,1000,3] device tensor."""
+        dev = self.device
+        d_p = torch.as_tensor(np.asarray(params) if not torch.is_tensor(params) else params).to(
+            device=dev, dtype=torch.float32).reshape(-1, 9).contiguous()
+        n = d_p.shape[0]
+        out = torch.empty(n, N_POINTS, 3, device=dev, dtype=torch.float32)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().odam_sq_points_batch(self._h, ctypes.c_int(n), _lib.ptr(d_p), _lib.ptr(out),
+                                                       ctypes.c_void_p(stream)), "odam_sq_points_batch")
+        return out
+
+
+def host_sample(a, e):
+    """odam_sq_sample: (a[3], e[2]) -> etas[1000], omegas[1000] float32 (host)."""
+    a = np.ascontiguousarray(a, np.float32)
+    e = np.ascontiguousarray(e, np.float32)
+    et = np.zeros(N_POINTS, np.float32)
+    om = np.zeros(N_POINTS, np.float32)
+    fp = _lib.c_float_p
+    _lib.check(_lib.lib().odam_sq_sample(a.ctypes.data_as(fp), e.ctypes.data_as(fp), et.ctypes.data_as(fp),
+                                         om.ctypes.data_as(fp)), "odam_sq_sample")
+    return et, om
