@@ -102,3 +102,55 @@ def make_frames(n, h=IMG_H, w=IMG_W, seed=0):
                          127 + 90 * np.cos(xx / 71.0 + yy / 43.0 + ph)], -1)
         img = base + rs.randint(-24, 25, size=(h, w, 3))
         yield np.clip(img, 0, 255).astype(np.uint8)
+
+
+def make_scene(n_frames, n_objects, seed=0, K=K_SCANNET, img_w=IMG_W, img_h=IMG_H, min_views=3,
+               max_views=None, noise_px=2.0):
+    """A posed synthetic scene with object tracks in the reference's 82-column layout
+    (src/processor.py:98-108): 0 frame_id | 1 class | 2-5 bbox px | 6-8 dims | 9-11 t_wo |
+    12 az_wo | 13 score | 14-77 code (-1) | 78-81 projected bbox px.
+
+    Returns dict(img_names, T_wcs [n,4,4], P_cws [n,3,4], tracks: list of [n_obs,82] float64, K).
+    """
+    rs = np.random.RandomState(seed)
+    T_wcs = camera_loop(n_frames, seed=seed)
+    P_cws = np.stack([K @ np.linalg.inv(T)[:3, :] for T in T_wcs])
+    img_names = [10 * i for i in range(n_frames)]  # frame ids need not be contiguous
+    tracks = []
+    for o in range(n_objects):
+        dims = rs.uniform(0.3, 1.5, 3)
+        yaw = rs.uniform(-np.pi, np.pi)
+        eps = rs.uniform(0.3, 1.5, 2)
+        centre = np.array([rs.uniform(-1.0, 1.0), rs.uniform(-1.0, 1.0), dims[2] / 2])
+        cls = int(rs.randint(0, 8))
+        surf = sq_surface(centre, yaw, dims, eps, 40, 80)
+        hi = max_views or n_frames
+        want = int(rs.randint(min_views, max(min_views + 1, min(hi, n_frames) + 1)))
+        start = int(rs.randint(0, n_frames))
+        step = max(1, n_frames // max(want, 1)) if want < n_frames else 1
+        rows = []
+        for j in range(want):
+            i = (start + j * step) % n_frames
+            uvw = np.c_[surf, np.ones(len(surf))] @ P_cws[i].T
+            if uvw[:, 2].min() < 0.3:
+                continue
+            uv = uvw[:, :2] / uvw[:, 2:]
+            bb = np.array([uv[:, 0].min(), uv[:, 1].min(), uv[:, 0].max(), uv[:, 1].max()])
+            if bb[2] < 0 or bb[0] > img_w or bb[3] < 0 or bb[1] > img_h:
+                continue
+            bb = np.clip(bb + rs.normal(0, noise_px, 4), [0, 0, 0, 0], [img_w, img_h, img_w, img_h])
+            row = -np.ones(82)
+            row[0] = img_names[i]
+            row[1] = cls
+            row[2:6] = bb
+            row[6:9] = dims * rs.uniform(0.9, 1.1, 3)
+            row[9:12] = centre + rs.normal(0, 0.05, 3)
+            row[12] = yaw + rs.normal(0, 0.08)
+            row[13] = rs.uniform(0.8, 1.0)
+            row[78:82] = bb
+            rows.append(row)
+        if rows:
+            rows.sort(key=lambda r: r[0])
+            tracks.append(np.asarray(rows))
+    return {"img_names": img_names, "T_wcs": T_wcs, "P_cws": P_cws, "tracks": tracks, "K": K,
+            "img_h": img_h, "img_w": img_w}

@@ -1,0 +1,171 @@
+"""Generates the golden vectors under tests/golden/ by IMPORTING the upstream reference
+(/root/reference, likojack/ODAM) in the build container.  Run:  python tests/golden/make_golden.py
+
+The reference has no tests or fixtures of its own, so its observable behaviour
+on seeded synthetic inputs is the pin for the CPU oracle (oracle/sq_oracle.c, oracle/detr_oracle.py).
+Only data (inputs + expected outputs) is written; nothing of the reference's source travels.
+
+Files written:
+  sq_sampler.npz   (a, e) -> etas, omegas from the reference's Cython binding fast_sample_on_batch
+  sq_steps.npz     per-step records of SuperQuadricOptimizer.run re-driven step by step:
+                   parameters before the step, autograd gradient, loss, parameters after Adam
+  sq_optim.npz     full optim_process() on a synthetic scene (tracks in the 82-column layout)
+  *_avx2 entries   the same reference run with ATEN_CPU_CAPABILITY=avx2 (another vector-math
+                   dispatch of the same torch build): shows which trajectories are stable under a
+                   last-bit change of the reference's own arithmetic
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+
+import numpy as np  # noqa: E402
+
+
+def params_of(Q):
+    return np.concatenate([Q.translate.detach().numpy(), [Q.angle.item()], Q.scales.detach().numpy(),
+                           Q.shapes.detach().numpy()]).astype(np.float32)
+
+
+def gen_sampler(out):
+    from learnable_primitives.fast_sampler import fast_sample_on_batch
+    rs = np.random.RandomState(7)
+    A, E = [], []
+    for a1, a2, a3, e1, e2 in [(0.05, 0.05, 0.05, 0.2, 0.2), (1.5, 0.3, 0.77, 1.6, 0.2), (0.3, 1.5, 0.05, 0.5, 0.9),
+                               (0.77, 0.77, 0.77, 1.0, 1.0), (0.25, 0.25, 0.25, 0.25, 0.25), (1.5, 1.5, 1.5, 1.6, 1.6),
+                               (0.36, 0.36, 0.16, 0.9, 0.9), (0.05, 1.5, 0.3, 0.2, 1.6)]:
+        A.append([a1, a2, a3]); E.append([e1, e2])
+    for _ in range(16):
+        A.append(rs.uniform(0.02, 1.6, 3)); E.append(rs.uniform(0.2, 1.6, 2))
+    A = np.asarray(A, np.float32); E = np.asarray(E, np.float32)
+    et, om = [], []
+    for a, e in zip(A, E):
+        x, y = fast_sample_on_batch(a[None, None].copy(), e[None, None].copy(), 1000)
+        et.append(x[0, 0]); om.append(y[0, 0])
+    np.savez_compressed(out, a=A, e=E, etas=np.asarray(et), omegas=np.asarray(om))
+
+
+def step_records(prob, cls, n_iters=200):
+    import torch
+    import src.super_quadric.sq_libs as L
+    opt = L.SuperQuadricOptimizer(prob["translate"], prob["angle"], prob["dims"], cls, "super_quadric", True)
+    lines = prob["bbox_lines"]
+    Ms = torch.tensor(prob["P"]).float()
+    names = ['x_min', 'x_max', 'y_min', 'y_max']
+    gm, gl = {}, {}
+    for name in names:  # sq_libs.py:438-451
+        m = torch.ones(len(lines)).float(); g = torch.zeros(len(lines)).float()
+        for i, l in enumerate(lines):
+            if name not in l:
+                m[i] = 0
+            else:
+                g[i] = l[name][-1]
+        gm[name] = m; gl[name] = g
+    Q = opt.Q_init
+    s0 = Q.scales.detach().clone()
+    icov = opt.scale_prior[L.CLASS_MAPPER[cls]]
+    rec = {k: [] for k in ("p", "g", "l2d", "loss", "p_after")}
+    pts_keep = {}
+    for it in range(n_iters):
+        opt.optimizer.zero_grad()
+        rec["p"].append(params_of(Q))
+        pts, _ = Q.compute_ellipsoid_points(False)
+        l2d = opt.constraint_2d(pts, Ms, gl, gm, names)
+        d = (s0 - Q.scales)[None, :]
+        loss = l2d + (d @ icov @ d.T)[0, 0] * 20
+        loss.backward()
+        rec["g"].append(np.concatenate([Q.translate.grad.numpy(), [Q.angle.grad.item()], Q.scales.grad.numpy(),
+                                        Q.shapes.grad.numpy()]).astype(np.float32))
+        rec["l2d"].append(np.float32(l2d.item())); rec["loss"].append(np.float32(loss.item()))
+        opt.optimizer.step()
+        rec["p_after"].append(params_of(Q))
+        if it in (0, 100, 199):
+            pts_keep[it] = pts.detach().numpy().copy()
+    return {k: np.asarray(v) for k, v in rec.items()}, pts_keep
+
+
+def run_plain(prob, cls, n_iters=200):
+    import src.super_quadric.sq_libs as L
+    opt = L.SuperQuadricOptimizer(prob["translate"], prob["angle"], prob["dims"], cls, "super_quadric", True)
+    Q = opt.run(prob["bbox_lines"], None, prob["P"], n_iters)
+    return params_of(Q)
+
+
+STEP_CASES = [(12, 0), (12, 2), (40, 3), (16, 11), (64, 12)]
+
+
+def gen_steps(out, avx2_final=None):
+    from odam_amd import synth, sq
+    data = {}
+    for ci, (F, seed) in enumerate(STEP_CASES):
+        prob = synth.make_sq_problem(F, seed)
+        cls = prob["class_id"]
+        rec, pts = step_records(prob, cls)
+        tgt, mask = sq.lines_to_targets(prob["bbox_lines"])
+        pre = f"c{ci}_"
+        data[pre + "p0"] = sq.init_params(prob["translate"], prob["angle"], prob["dims"])
+        data[pre + "cls"] = np.int32(cls)
+        data[pre + "P"] = prob["P"].astype(np.float32).reshape(-1, 12)
+        data[pre + "tgt"] = tgt; data[pre + "mask"] = mask
+        for k, v in rec.items():
+            data[pre + k] = v
+        for it, v in pts.items():
+            data[pre + f"pts{it}"] = v
+        data[pre + "final_plain"] = run_plain(prob, cls)
+        if avx2_final is not None:
+            data[pre + "final_avx2"] = avx2_final[ci]
+    data["n_cases"] = np.int32(len(STEP_CASES))
+    np.savez_compressed(out, **data)
+
+
+def ref_optim(scene):
+    from src.scripts.run_multi_view import optim_process
+    out = optim_process(scene["tracks"], scene["img_names"], scene["T_wcs"], scene["P_cws"], scene["img_h"],
+                        scene["img_w"], scene["K"], "super_quadric", True, 200, 10)
+    params = np.stack([params_of(q) for q in out["quadrics"]])
+    return params, np.asarray(out["bboxes_qc"]), np.asarray(out["bboxes_dl"])
+
+
+SCENE = dict(n_frames=120, n_objects=7, seed=3, min_views=4, max_views=60)
+
+
+def gen_optim(out, avx2_params=None):
+    from odam_amd import synth
+    scene = synth.make_scene(**SCENE)
+    params, qc, dl = ref_optim(scene)
+    data = dict(params=params, bboxes_qc=qc, bboxes_dl=dl, n_tracks=np.int32(len(scene["tracks"])),
+                img_names=np.asarray(scene["img_names"]), T_wcs=scene["T_wcs"], P_cws=scene["P_cws"], K=scene["K"])
+    for i, t in enumerate(scene["tracks"]):
+        data[f"track{i}"] = t
+    if avx2_params is not None:
+        data["params_avx2"] = avx2_params
+    np.savez_compressed(out, **data)
+
+
+def main():
+    import refenv
+    mode = sys.argv[1] if len(sys.argv) > 1 else "all"
+    refenv.setup()
+    if mode == "avx2-child":  # second dispatch of the same reference; results handed back through a file
+        from odam_amd import synth
+        finals = np.stack([run_plain(synth.make_sq_problem(F, s), synth.make_sq_problem(F, s)["class_id"])
+                           for F, s in STEP_CASES])
+        params, _, _ = ref_optim(synth.make_scene(**SCENE))
+        np.savez(sys.argv[2], finals=finals, params=params)
+        return
+    tmp = os.path.join(refenv.SCRATCH, "avx2.npz")
+    env = dict(os.environ, ATEN_CPU_CAPABILITY="avx2")
+    subprocess.check_call([sys.executable, os.path.abspath(__file__), "avx2-child", tmp], env=env, cwd=REPO)
+    z = np.load(tmp)
+    gen_sampler(os.path.join(HERE, "sq_sampler.npz"))
+    gen_steps(os.path.join(HERE, "sq_steps.npz"), z["finals"])
+    gen_optim(os.path.join(HERE, "sq_optim.npz"), z["params"])
+    print("golden vectors written to", HERE)
+
+
+if __name__ == "__main__":
+    main()
