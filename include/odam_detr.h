@@ -1,0 +1,95 @@
+/*
+ * odam_detr.h -- C ABI of the MI355X (gfx950) DETR-style monocular 3D detector forward pass.
+ *
+ * Drop-in boundary for the reference's (likojack/ODAM) detector as OdamProcess.run_detector uses it
+ * (src/processor.py:259-289):
+ *   src/models/detr.py:49-94      DETR.forward        -> odam_detr_forward
+ *   src/models/detr.py:96-140     DETR.postprocess    -> odam_detr_postprocess (arithmetic per query;
+ *                                 thresholding + greedy nms_3d :161-205 stay on the host)
+ *   src/models/backbone.py:21-94  FrozenBatchNorm2d + torchvision ResNet-50/101 body
+ *   src/models/transformer.py     6+6 post-norm encoder/decoder, nn.MultiheadAttention(256, 8)
+ *   run_processor.py:32-33        load_state_dict      -> odam_detr_set_weight per state_dict entry,
+ *                                 with the reference's key names
+ *
+ * Conventions as in odam_sq.h: int return codes (0 = OK), odam_last_error(), [dev]/[host] pointers,
+ * caller's hipStream_t passed as void*, no allocation or synchronisation inside forward/postprocess
+ * (the workspace is allocated by odam_detr_create for max_batch frames of img_h x img_w).
+ */
+#ifndef ODAM_DETR_H
+#define ODAM_DETR_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct odam_detr odam_detr;
+
+typedef struct {
+    int resnet_blocks[4];  /* {3,4,6,3} = resnet50, {3,4,23,3} = resnet101 (backbone.py:90) */
+    int hidden_dim;        /* 256  (configs/detr_scan_net.yaml) */
+    int nheads;            /* 8    head dim must be 32 */
+    int dim_feedforward;   /* 2048 */
+    int enc_layers;        /* 6 */
+    int dec_layers;        /* 6 */
+    int num_queries;       /* 100 */
+    int num_classes1;      /* 18 + 1 "no object" (detr.py:531-532) */
+    int angle_bins;        /* 30 */
+    int max_batch;         /* frames per forward call */
+    int img_h, img_w;      /* network input size, e.g. 800 x 1066 for a 640x480 frame (transforms.py:78-96) */
+} odam_detr_cfg;
+
+int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out);
+int odam_detr_destroy(odam_detr* m);
+
+/* One call per state_dict entry, `name` = the reference's key (e.g.
+ * "backbone.0.body.layer1.0.conv1.weight", "transformer.encoder.layers.0.self_attn.in_proj_weight",
+ * "class_embed.bias"); data [host] float32, contiguous, PyTorch layout.  Unknown names are ignored
+ * (e.g. "...num_batches_tracked", as FrozenBatchNorm2d._load_from_state_dict does, backbone.py:36-44).
+ * The sine position embedding of the token grid is passed under the name "pos_embed"
+ * ([h*w, hidden_dim], position_encoding.py:26-46 -- a constant of the input size). */
+int odam_detr_set_weight(odam_detr* m, const char* name, const float* data, const long long* shape, int ndim);
+
+/* Packs weights for the kernels (NHWC k-major filters, FrozenBN folded to scale/bias exactly as
+ * backbone.py:46-56 computes them, fused attention projections); fails if any tensor is missing. */
+int odam_detr_finalize(odam_detr* m);
+
+/* token grid of the configured input: h = ceil(img_h/32), w = ceil(img_w/32) */
+int odam_detr_feature_hw(const odam_detr* m, int* h, int* w);
+
+/*
+ * img [dev] [B,3,img_h,img_w] float32 (normalised, as get_transforms() produces).
+ * Outputs [dev], the last decoder layer's predictions (detr.py:80-88):
+ *   logits [B,Q,num_classes1], boxes [B,Q,4] (sigmoid applied), angle [B,Q,angle_bins], offset [B,Q,2],
+ *   size [B,Q,3], depth [B,Q,1], obj_features [B,Q,hidden] (nullable).
+ */
+int odam_detr_forward(odam_detr* m, const float* img, int B, float* logits, float* boxes, float* angle,
+                      float* offset, float* size, float* depth, float* obj_features, void* stream);
+
+/* optional taps for parity tests: layer4 feature map as NCHW [B,2048,h,w] and encoder memory [B,h*w,hidden]
+ * of the most recent forward (either may be null) */
+int odam_detr_debug_read(odam_detr* m, int B, float* layer4_nchw, float* memory, void* stream);
+
+/*
+ * Per-query post-processing arithmetic (detr.py:111-140) on device:
+ * rows [dev] [B,Q,16] = score, class, x0,y0,x1,y1 (pixels of img_w x img_h), cx3d, cy3d, depth,
+ *                       angle_bin, d0,d1,d2, 0,0,0.   K9 [host] row-major 3x3 intrinsics.
+ */
+int odam_detr_postprocess(odam_detr* m, const float* logits, const float* boxes, const float* angle,
+                          const float* offset, const float* size, const float* depth, int B, const float* K9,
+                          float img_w, float img_h, float* rows, void* stream);
+
+/* ---- single-operator entry points (the same kernels the forward uses; for parity tests and reuse) ---- */
+/* NHWC convolution / linear:  x [dev][B,H,W,Cin] (Cin power of two >= 4), w_packed [dev][Cout][Kpad]
+ * (k = (ky*KW+kx)*Cin+ci, zero padded to a multiple of 32), scale/bias/residual nullable, y [dev][B,Ho,Wo,Cout] */
+int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const float* scale, const float* bias,
+                        const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                        int stride, int pad, int Kpad, int relu, void* stream);
+int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                      int B, int H, int Lq, int Lk, void* stream);
+int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y, int M,
+                          void* stream);
+int odam_op_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,182 @@
+// conv_gemm.hip -- see conv_gemm.h
+#include "conv_gemm.h"
+
+#include "odam_err.h"
+
+namespace odam_cg {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;  // 144-byte rows: 16-byte aligned, conflict-free for ds_read_b128
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
+    constexpr int TM = BM / WM / 32;   // 32x32 MFMA tiles per wave along M
+    constexpr int TN = BN / WN / 32;
+    constexpr int A_LD = BM / 32;      // float4 loads per thread for the A tile
+    constexpr int B_LD = BN / 32;
+    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+
+    extern __shared__ __align__(16) float smem[];
+    float* As = smem;                         // [2][BM][LDS_STRIDE]
+    float* Bs = smem + 2 * BM * LDS_STRIDE;   // [2][BN][LDS_STRIDE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    const int tile_m = blockIdx.x / tiles_n;
+    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-thread gather bookkeeping (rows are fixed over the K loop) ---------------------
+    const int c4 = tid & 7;    // which float4 of the 32-wide k slice
+    const int r0 = tid >> 3;   // 0..31
+    int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
+    bool a_ok[A_LD];
+    const int hw = a.Ho * a.Wo;
+#pragma unroll
+    for (int i = 0; i < A_LD; i++) {
+        const int m = m0 + r0 + 32 * i;
+        a_ok[i] = m < a.M;
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / a.Wo;
+        const int ox = rem - oy * a.Wo;
+        a_iy0[i] = oy * a.stride - a.pad;
+        a_ix0[i] = ox * a.stride - a.pad;
+        a_base[i] = ((b * a.H + a_iy0[i]) * a.W + a_ix0[i]) * a.Cin;
+    }
+    const float* w_ptr[B_LD];
+    bool b_ok[B_LD];
+#pragma unroll
+    for (int i = 0; i < B_LD; i++) {
+        const int n = n0 + r0 + 32 * i;
+        b_ok[i] = n < a.Cout;
+        w_ptr[i] = a.Wt + (size_t)(b_ok[i] ? n : 0) * a.Kpad + c4 * 4;
+    }
+    const int ntaps = a.KH * a.KW;
+    const int kw_inv = (65536 + a.KW - 1) / a.KW;  // tap / KW for tap < 64, KW <= 7
+
+    float4 ra[A_LD], rb[B_LD];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK + c4 * 4;
+        const int tap = k0 >> a.log2Cin;
+        const int ci = k0 & (a.Cin - 1);
+        const int ky = (tap * kw_inv) >> 16;
+        const int kx = tap - ky * a.KW;
+        const bool tap_ok = tap < ntaps;
+        const int koff = (ky * a.W + kx) * a.Cin + ci;
+#pragma unroll
+        for (int i = 0; i < A_LD; i++) {
+            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            const bool ok = a_ok[i] && tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            ra[i] = ok ? *reinterpret_cast<const float4*>(a.A + (size_t)(a_base[i] + koff)) : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; i++)
+            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(w_ptr[i] + kt * BK) : float4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; i++)
+            *reinterpret_cast<float4*>(&As[(buf * BM + r0 + 32 * i) * LDS_STRIDE + c4 * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_LD; i++)
+            *reinterpret_cast<float4*>(&Bs[(buf * BN + r0 + 32 * i) * LDS_STRIDE + c4 * 4]) = rb[i];
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    const int nk = a.Kpad / BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frag_row = lane & 31;
+    const int frag_k = (lane >> 5) * 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+        const float* Ab = &As[(cur * BM + wm * (BM / WM) + frag_row) * LDS_STRIDE + frag_k];
+        const float* Bb = &Bs[(cur * BN + wn * (BN / WN) + frag_row) * LDS_STRIDE + frag_k];
+#pragma unroll
+        for (int q = 0; q < BK / 8; q++) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + q * 8);
+#pragma unroll
+            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE + q * 8);
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kt + 1 < nk) store_tile(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
+    const int half = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        const bool n_ok = n < a.Cout;
+        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
+        const float bi = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (n_ok && m < a.M) {
+                    float v = acc[i][j][r] * sc + bi;
+                    if (a.res) v += a.res[(size_t)m * a.ldc + n];
+                    if (a.relu) v = v > 0.0f ? v : 0.0f;
+                    a.C[(size_t)m * a.ldc + n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+    if (!attr_set) {
+        ODAM_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN>,
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), lds, stream, a);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
+    if (a.Kpad % BK != 0 || a.Cin < 4 || (a.Cin & (a.Cin - 1)) != 0 || a.KW > 7 || a.KH * a.KW > 64)
+        return odam_fail(1, "conv_gemm: unsupported shape (Kpad % 32, Cin power of two >= 4, KW <= 7)");
+    if (a.M <= 0 || a.Cout <= 0) return 0;
+    if (a.Cout <= 64) return launch_cfg<128, 64, 4, 1>(a, stream);
+    const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
+    if (tiles128 < 128) return launch_cfg<64, 64, 2, 2>(a, stream);
+    return launch_cfg<128, 128, 2, 2>(a, stream);
+}
+
+}  // namespace odam_cg

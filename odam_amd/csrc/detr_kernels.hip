@@ -1,0 +1,368 @@
+// detr_kernels.hip -- see detr_kernels.h
+#include "detr_kernels.h"
+
+#include "odam_err.h"
+
+namespace odam_dk {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// =================================================================================================
+// Fused attention, d_head = 32, fp32 on v_mfma_f32_32x32x2_f32.
+//
+// Workgroup = 4 wavefronts, each owns 32 query rows of one (batch, head); the workgroup walks the
+// keys in tiles of 32 staged once in LDS for all four wavefronts (double buffered).
+//   S^T tile (keys x queries) = K_tile . Q^T        16 MFMA (K-dim = 32 head channels, 2 per MFMA)
+//   online softmax over keys: the key index lives in the accumulator REGISTER (plus the lane
+//     half), the query on the lane -> row max / row sum are 15 in-register ops + one lane^32 swap
+//   O^T (channels x queries) += V_tile^T . P^T       16 MFMA; the S^T accumulator registers ARE the
+//     B operand of this product (same lane <-> query, same register <-> key), so P never leaves
+//     the register file and stays fp32.
+// Reference semantics: torch.nn.functional.multi_head_attention_forward as called from
+// src/models/transformer.py:154-167, 217-238 (q scaled by sqrt(1/32) before the product, softmax
+// over keys, no dropout at inference, padding mask all-false for same-size frames).
+// =================================================================================================
+constexpr int ATT_D = 32;
+constexpr int ATT_KT = 32;          // keys per tile
+constexpr int ATT_LD = ATT_D + 4;   // LDS row stride (floats)
+
+__device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ Q, int ldq,
+                                                        const float* __restrict__ K, int ldk,
+                                                        const float* __restrict__ V, int ldv,
+                                                        float* __restrict__ O, int ldo, int Lq, int Lk) {
+    __shared__ __align__(16) float Ks[2][ATT_KT][ATT_LD];
+    __shared__ __align__(16) float Vs[2][ATT_KT][ATT_LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float* Qb = Q + (size_t)b * Lq * ldq + h * ATT_D;
+    const float* Kb = K + (size_t)b * Lk * ldk + h * ATT_D;
+    const float* Vb = V + (size_t)b * Lk * ldv + h * ATT_D;
+
+    // this lane's 16 query channels d = 16*half + s, pre-scaled by sqrt(1/32)
+    float qreg[16];
+    {
+        const int q = q0 + col;
+        const float scale = (float)0.1767766952966369;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float4 v = (q < Lq) ? *reinterpret_cast<const float4*>(Qb + (size_t)q * ldq + 16 * half + 4 * g)
+                                : float4{0.f, 0.f, 0.f, 0.f};
+            qreg[4 * g + 0] = v.x * scale; qreg[4 * g + 1] = v.y * scale;
+            qreg[4 * g + 2] = v.z * scale; qreg[4 * g + 3] = v.w * scale;
+        }
+    }
+
+    const int lr = tid >> 3, lc = (tid & 7) * 4;  // tile loader: row 0..31, float4 column
+    auto load_kv = [&](int kt, float4& kv, float4& vv) {
+        const int key = kt * ATT_KT + lr;
+        if (key < Lk) {
+            kv = *reinterpret_cast<const float4*>(Kb + (size_t)key * ldk + lc);
+            vv = *reinterpret_cast<const float4*>(Vb + (size_t)key * ldv + lc);
+        } else {
+            kv = float4{0.f, 0.f, 0.f, 0.f};
+            vv = float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+
+    floatx16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[r] = 0.0f;
+    float m_run = -1e30f, l_run = 0.0f;
+
+    const int ntiles = (Lk + ATT_KT - 1) / ATT_KT;
+    float4 kv, vv;
+    load_kv(0, kv, vv);
+    *reinterpret_cast<float4*>(&Ks[0][lr][lc]) = kv;
+    *reinterpret_cast<float4*>(&Vs[0][lr][lc]) = vv;
+    __syncthreads();
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) load_kv(kt + 1, kv, vv);
+
+        // S^T = K . Q^T   (rows = keys, cols = queries)
+        floatx16 s;
+#pragma unroll
+        for (int r = 0; r < 16; r++) s[r] = 0.0f;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const float4 kf = *reinterpret_cast<const float4*>(&Ks[cur][col][16 * half + 4 * g]);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qreg[4 * g + 0], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qreg[4 * g + 1], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[4 * g + 2], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qreg[4 * g + 3], s, 0, 0, 0);
+        }
+        // mask keys beyond Lk (last tile only)
+        const int kbase = kt * ATT_KT;
+        if (kbase + ATT_KT > Lk) {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                if (kbase + acc_row(r, half) >= Lk) s[r] = -1e30f;
+        }
+        // online softmax over the key axis (registers + the other lane half)
+        float mx = s[0];
+#pragma unroll
+        for (int r = 1; r < 16; r++) mx = fmaxf(mx, s[r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            s[r] = __expf(s[r] - m_new);
+            psum += s[r];
+        }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[r] *= alpha;
+        // O^T += V^T . P^T : k-slot (step r, lane half) <-> key acc_row(r, half) on both operands
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const float vf = Vs[cur][acc_row(r, half)][col];
+            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], oacc, 0, 0, 0);
+        }
+        if (kt + 1 < ntiles) {
+            *reinterpret_cast<float4*>(&Ks[cur ^ 1][lr][lc]) = kv;
+            *reinterpret_cast<float4*>(&Vs[cur ^ 1][lr][lc]) = vv;
+        }
+        __syncthreads();
+    }
+
+    const int q = q0 + col;
+    if (q < Lq) {
+        const float inv = 1.0f / l_run;
+        float* Ob = O + ((size_t)b * Lq + q) * ldo + h * ATT_D;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            float4 v = {oacc[4 * g + 0] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
+            *reinterpret_cast<float4*>(Ob + 8 * g + 4 * half) = v;  // channels acc_row(4g..4g+3, half)
+        }
+    }
+}
+
+int launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                     int B, int H, int Lq, int Lk, hipStream_t stream) {
+    if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
+    dim3 grid((Lq + 127) / 128, H, B);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// residual add + LayerNorm over 256 channels: one wavefront per row, 4 channels per lane
+// (nn.LayerNorm(256), eps 1e-5, biased variance; transformer.py:147-148, 160-166)
+// =================================================================================================
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            const float* __restrict__ pos, int L,
+                                                            float* __restrict__ y_pos, int M) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
+    if (r) {
+        const float4 t = *reinterpret_cast<const float4*>(r + (size_t)row * 256 + lane * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
+    const float dx = v.x - mean, dy = v.y - mean, dz = v.z - mean, dw = v.w - mean;
+    const float var = wave_sum((dx * dx + dy * dy) + (dz * dz + dw * dw)) * (1.0f / 256.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
+    const float4 be = *reinterpret_cast<const float4*>(beta + lane * 4);
+    float4 o = {dx * rstd * g.x + be.x, dy * rstd * g.y + be.y, dz * rstd * g.z + be.z, dw * rstd * g.w + be.w};
+    *reinterpret_cast<float4*>(y + (size_t)row * 256 + lane * 4) = o;
+    if (y_pos) {
+        const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)(row % L) * 256 + lane * 4);
+        float4 o2 = {o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w};
+        *reinterpret_cast<float4*>(y_pos + (size_t)row * 256 + lane * 4) = o2;
+    }
+}
+
+int launch_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y,
+                         const float* pos, int L, float* y_pos, int M, hipStream_t stream) {
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, r, gamma, beta, y, pos, L,
+                       y_pos, M);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ x, const float* __restrict__ pos,
+                                                      int L, float* __restrict__ out, int M) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // float4 index
+    if (i >= (size_t)M * 64) return;
+    const int row = (int)(i >> 6), c4 = (int)(i & 63);
+    float4 p = *reinterpret_cast<const float4*>(pos + (size_t)(row % L) * 256 + c4 * 4);
+    if (x) {
+        const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+        p.x += v.x; p.y += v.y; p.z += v.z; p.w += v.w;
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = p;
+}
+
+int launch_add_pos(const float* x, const float* pos, int L, float* out, int M, hipStream_t stream) {
+    if (M <= 0) return 0;
+    const size_t n4 = (size_t)M * 64;
+    hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos, L, out, M);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// layout / pooling
+// =================================================================================================
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int HW, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // pixel index over B*H*W
+    if (i >= total) return;
+    const size_t b = i / HW, p = i - b * HW;
+    const float* s = in + b * 3 * (size_t)HW + p;
+    float4 v = {s[0], s[HW], s[2 * (size_t)HW], 0.0f};
+    *reinterpret_cast<float4*>(out + i * 4) = v;
+}
+
+int launch_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t stream) {
+    const size_t total = (size_t)B * H * W;
+    if (!total) return 0;
+    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out,
+                       H * W, total);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
+                                                      int W, int C4, int Ho, int Wo, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // over B*Ho*Wo*C4
+    if (i >= total) return;
+    const int c4 = (int)(i % C4);
+    size_t p = i / C4;
+    const int ox = (int)(p % Wo); p /= Wo;
+    const int oy = (int)(p % Ho);
+    const size_t b = p / Ho;
+    float4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int dy = 0; dy < 3; dy++) {
+        const int iy = oy * 2 - 1 + dy;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int dx = 0; dx < 3; dx++) {
+            const int ix = ox * 2 - 1 + dx;
+            if ((unsigned)ix >= (unsigned)W) continue;
+            const float4 v = *reinterpret_cast<const float4*>(in + (((b * H + iy) * W + ix) * (size_t)C4 + c4) * 4);
+            m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+        }
+    }
+    *reinterpret_cast<float4*>(out + i * 4) = m;
+}
+
+int launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t stream) {
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    if (!total) return 0;
+    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, H, W,
+                       C / 4, Ho, Wo, total);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                           int HW, int C, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // output index over B*C*HW
+    if (i >= total) return;
+    const size_t p = i % HW;
+    const size_t c = (i / HW) % C;
+    const size_t b = i / ((size_t)HW * C);
+    out[i] = in[(b * HW + p) * C + c];
+}
+
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream) {
+    const size_t total = (size_t)B * H * W * C;
+    if (!total) return 0;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out,
+                       H * W, C, total);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+__global__ void sigmoid_kernel(float* x, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) x[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+
+int launch_sigmoid(float* x, int n, hipStream_t stream) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, n);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+// =================================================================================================
+// DETR.postprocess arithmetic per query (detr.py:111-140); thresholding + greedy NMS stay on the host
+// =================================================================================================
+__global__ void postprocess_kernel(const float* __restrict__ logits, const float* __restrict__ boxes,
+                                   const float* __restrict__ angle, const float* __restrict__ offset,
+                                   const float* __restrict__ size, const float* __restrict__ depth, int n, int n_cls1,
+                                   int n_bins, float img_w, float img_h, float fx, float fy, float cx, float cy,
+                                   float* __restrict__ rows) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    const float* lg = logits + (size_t)i * n_cls1;
+    float mx = lg[0];
+    for (int c = 1; c < n_cls1; c++) mx = fmaxf(mx, lg[c]);
+    float den = 0.0f;
+    for (int c = 0; c < n_cls1; c++) den += expf(lg[c] - mx);
+    float best = -1.0f;
+    int cls = 0;
+    for (int c = 0; c < n_cls1 - 1; c++) {  // softmax(-1)[..., :-1].max(-1): first maximum wins
+        const float p = expf(lg[c] - mx) / den;
+        if (p > best) { best = p; cls = c; }
+    }
+    const float* bx = boxes + (size_t)i * 4;
+    const float x0 = (bx[0] - 0.5f * bx[2]) * img_w, y0 = (bx[1] - 0.5f * bx[3]) * img_h;
+    const float x1 = (bx[0] + 0.5f * bx[2]) * img_w, y1 = (bx[1] + 0.5f * bx[3]) * img_h;
+    const float d = depth[i];
+    const float scx = offset[(size_t)i * 2 + 0] * img_w + (x0 + x1) / 2.0f;
+    const float scy = offset[(size_t)i * 2 + 1] * img_h + (y0 + y1) / 2.0f;
+    const float c3x = ((scx - cx) / fx) * d;
+    const float c3y = ((scy - cy) / fy) * d;
+    const float* an = angle + (size_t)i * n_bins;
+    int ab = 0;
+    float am = an[0];
+    for (int k = 1; k < n_bins; k++)
+        if (an[k] > am) { am = an[k]; ab = k; }
+    float* o = rows + (size_t)i * 16;
+    o[0] = best; o[1] = (float)cls;
+    o[2] = x0; o[3] = y0; o[4] = x1; o[5] = y1;
+    o[6] = c3x; o[7] = c3y; o[8] = d;
+    o[9] = (float)ab;
+    o[10] = size[(size_t)i * 3 + 0]; o[11] = size[(size_t)i * 3 + 1]; o[12] = size[(size_t)i * 3 + 2];
+    o[13] = 0.0f; o[14] = 0.0f; o[15] = 0.0f;
+}
+
+int launch_postprocess(const float* logits, const float* boxes, const float* angle, const float* offset,
+                       const float* size, const float* depth, int B, int Q, int n_cls1, int n_bins, float img_w,
+                       float img_h, float fx, float fy, float cx, float cy, float* rows, hipStream_t stream) {
+    const int n = B * Q;
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(postprocess_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, logits, boxes, angle, offset,
+                       size, depth, n, n_cls1, n_bins, img_w, img_h, fx, fy, cx, cy, rows);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+}  // namespace odam_dk

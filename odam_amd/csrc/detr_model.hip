@@ -1,0 +1,478 @@
+// detr_model.hip -- host side of the detector: weight intake under the reference's state_dict names,
+// packing, workspace, and the forward schedule over the gfx950 kernels (conv_gemm / detr_kernels).
+//
+// Reference (likojack/ODAM): src/models/detr.py:18-94 (DETR), src/models/backbone.py:21-110 (FrozenBN,
+// ResNet body = torchvision ResNet v1.5 bottlenecks, stride on the 3x3), src/models/transformer.py
+// (post-norm encoder/decoder), src/models/position_encoding.py (sine embedding, passed in precomputed).
+// Layout: activations NHWC / [B*L, C] batch-major rows; every contraction runs on conv_gemm.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/odam_detr.h"
+#include "conv_gemm.h"
+#include "detr_kernels.h"
+#include "odam_err.h"
+
+using odam_cg::ConvGemmArgs;
+
+namespace {
+
+struct HostTensor {
+    std::vector<long long> shape;
+    std::vector<float> data;
+};
+
+struct Conv {          // packed convolution / linear layer on device
+    float* w = nullptr;      // [Cout][Kpad]
+    float* scale = nullptr;  // [Cout] or null
+    float* bias = nullptr;   // [Cout] or null
+    int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
+};
+
+struct Bottleneck {
+    Conv c1, c2, c3, ds;
+    bool has_ds = false;
+};
+
+struct LN { float* g = nullptr; float* b = nullptr; };
+
+struct EncLayer { Conv qk, v, out, l1, l2; LN n1, n2; };
+struct DecLayer { Conv qk, v, out, cq, cout, l1, l2; LN n1, n2, n3; };
+
+int ilog2(int x) { int l = 0; while ((1 << l) < x) l++; return l; }
+int conv_out(int n, int k, int s, int p) { return (n + 2 * p - k) / s + 1; }
+
+}  // namespace
+
+struct odam_detr {
+    odam_detr_cfg cfg;
+    std::map<std::string, HostTensor> host;
+    bool finalized = false;
+    std::vector<void*> allocs;
+
+    Conv stem;
+    std::vector<Bottleneck> blocks;
+    std::vector<int> block_stride;
+    Conv input_proj;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    Conv cross_k_all, cross_v_all;
+    LN dec_norm;
+    Conv class_embed;
+    Conv mlp[5][3];  // bbox, offset, angle, size, depth
+    float* pos = nullptr;        // [L, 256]
+    float* query_pos = nullptr;  // [Q, 256]
+
+    // geometry
+    int H1, W1, H2, W2, fh, fw, L;
+
+    // workspace
+    float *x4 = nullptr, *stem_out = nullptr, *bufA = nullptr, *bufB = nullptr, *t1 = nullptr, *t2 = nullptr,
+          *dsb = nullptr;
+    float *src = nullptr, *srcpos = nullptr, *qk = nullptr, *v = nullptr, *att = nullptr, *tmp = nullptr, *ffn = nullptr;
+    float *kc = nullptr, *vc = nullptr;
+    float *tgt = nullptr, *tgtpos = nullptr, *dqk = nullptr, *dv = nullptr, *datt = nullptr, *dq = nullptr,
+          *dtmp = nullptr, *dffn = nullptr, *hs = nullptr, *h1 = nullptr, *h2 = nullptr;
+    const float* layer4 = nullptr;  // where the last forward left the layer4 map (NHWC)
+
+    template <typename T>
+    int dev_alloc(T** p, size_t n) {
+        ODAM_HIP(hipMalloc((void**)p, n * sizeof(T)));
+        allocs.push_back((void*)*p);
+        return 0;
+    }
+    int upload(float** p, const std::vector<float>& v) {
+        if (int rc = dev_alloc(p, v.size())) return rc;
+        ODAM_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+namespace {
+
+const HostTensor* find(odam_detr* m, const std::string& name) {
+    auto it = m->host.find(name);
+    return it == m->host.end() ? nullptr : &it->second;
+}
+
+#define NEED(var, name)                                                                    \
+    const HostTensor* var = find(m, name);                                                 \
+    if (!var) {                                                                            \
+        std::snprintf(g_odam_err, sizeof(g_odam_err), "odam_detr_finalize: missing weight %s", std::string(name).c_str()); \
+        return 1;                                                                          \
+    }
+
+// [Cout, Cin, KH, KW] (PyTorch) -> [Cout][Kpad], k = (ky*KW + kx)*CinP + ci, CinP = Cin rounded up to 4
+int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad) {
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
+    const int KH = w.shape.size() > 2 ? (int)w.shape[2] : 1, KW = w.shape.size() > 3 ? (int)w.shape[3] : 1;
+    const int CinP = (Cin + 3) / 4 * 4;
+    const int K = KH * KW * CinP;
+    const int Kpad = (K + 31) / 32 * 32;
+    std::vector<float> p((size_t)Cout * Kpad, 0.0f);
+    for (int o = 0; o < Cout; o++)
+        for (int ci = 0; ci < Cin; ci++)
+            for (int ky = 0; ky < KH; ky++)
+                for (int kx = 0; kx < KW; kx++)
+                    p[(size_t)o * Kpad + (ky * KW + kx) * CinP + ci] = w.data[(((size_t)o * Cin + ci) * KH + ky) * KW + kx];
+    c.Cin = CinP; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
+    return m->upload(&c.w, p);
+}
+
+// rows [r0, r1) of a [N, K] Linear weight (+ bias) as a 1x1 layer
+int pack_linear(odam_detr* m, Conv& c, const HostTensor& w, const HostTensor* b, int r0, int r1) {
+    const int K = (int)w.shape[1];
+    std::vector<float> p(w.data.begin() + (size_t)r0 * K, w.data.begin() + (size_t)r1 * K);
+    c.Cin = K; c.Cout = r1 - r0; c.KH = c.KW = 1; c.stride = 1; c.pad = 0; c.Kpad = K;
+    if (int rc = m->upload(&c.w, p)) return rc;
+    if (b) {
+        std::vector<float> bb(b->data.begin() + r0, b->data.begin() + r1);
+        if (int rc = m->upload(&c.bias, bb)) return rc;
+    }
+    return 0;
+}
+
+// FrozenBatchNorm2d.forward (backbone.py:46-56): scale = w * rsqrt(rv + 1e-5); bias = b - rm * scale, in float32
+int fold_bn(odam_detr* m, Conv& c, const std::string& prefix) {
+    NEED(w, prefix + ".weight"); NEED(b, prefix + ".bias");
+    NEED(rm, prefix + ".running_mean"); NEED(rv, prefix + ".running_var");
+    const size_t n = w->data.size();
+    std::vector<float> sc(n), bi(n);
+    for (size_t i = 0; i < n; i++) {
+        const float s = w->data[i] * (1.0f / std::sqrt(rv->data[i] + 1e-5f));
+        sc[i] = s;
+        bi[i] = b->data[i] - rm->data[i] * s;
+    }
+    if (int rc = m->upload(&c.scale, sc)) return rc;
+    return m->upload(&c.bias, bi);
+}
+
+int pack_ln(odam_detr* m, LN& ln, const std::string& prefix) {
+    NEED(w, prefix + ".weight"); NEED(b, prefix + ".bias");
+    if (int rc = m->upload(&ln.g, w->data)) return rc;
+    return m->upload(&ln.b, b->data);
+}
+
+int run_conv(const Conv& c, const float* x, int B, int H, int W, const float* res, bool relu, float* y, int ldc,
+             hipStream_t st) {
+    ConvGemmArgs a{};
+    a.A = x; a.Wt = c.w; a.scale = c.scale; a.bias = c.bias; a.res = res; a.C = y;
+    a.B = B; a.H = H; a.W = W; a.Cin = c.Cin; a.log2Cin = ilog2(c.Cin);
+    a.Ho = conv_out(H, c.KH, c.stride, c.pad); a.Wo = conv_out(W, c.KW, c.stride, c.pad);
+    a.Cout = c.Cout; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad; a.Kpad = c.Kpad;
+    a.relu = relu ? 1 : 0; a.M = B * a.Ho * a.Wo; a.ldc = ldc > 0 ? ldc : c.Cout;
+    return odam_cg::launch_conv_gemm(a, st);
+}
+
+// y[M, Cout] = x[M, K] W^T + b (+ res) (relu)
+int run_linear(const Conv& c, const float* x, int M, const float* res, bool relu, float* y, int ldc, hipStream_t st) {
+    return run_conv(c, x, 1, 1, M, res, relu, y, ldc, st);
+}
+
+#define RC(call)                 \
+    do {                         \
+        int rc_ = (call);        \
+        if (rc_) return rc_;     \
+    } while (0)
+
+}  // namespace
+
+extern "C" int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out) {
+    if (!cfg || !out) return odam_fail(1, "odam_detr_create: null argument");
+    if (cfg->hidden_dim != 256 || cfg->nheads != 8)
+        return odam_fail(3, "odam_detr_create: kernels are built for hidden_dim 256, 8 heads (head dim 32)");
+    if (cfg->max_batch < 1 || cfg->img_h < 32 || cfg->img_w < 32) return odam_fail(1, "odam_detr_create: bad sizes");
+    odam_detr* m = new odam_detr();
+    m->cfg = *cfg;
+    m->H1 = conv_out(cfg->img_h, 7, 2, 3); m->W1 = conv_out(cfg->img_w, 7, 2, 3);
+    m->H2 = conv_out(m->H1, 3, 2, 1); m->W2 = conv_out(m->W1, 3, 2, 1);
+    int h = m->H2, w = m->W2;
+    for (int l = 1; l < 4; l++) { h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1); }
+    m->fh = h; m->fw = w; m->L = h * w;
+    *out = m;
+    return 0;
+}
+
+extern "C" int odam_detr_destroy(odam_detr* m) {
+    if (!m) return 0;
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+    return 0;
+}
+
+extern "C" int odam_detr_feature_hw(const odam_detr* m, int* h, int* w) {
+    if (!m || !h || !w) return odam_fail(1, "odam_detr_feature_hw: null argument");
+    *h = m->fh; *w = m->fw;
+    return 0;
+}
+
+extern "C" int odam_detr_set_weight(odam_detr* m, const char* name, const float* data, const long long* shape,
+                                    int ndim) {
+    if (!m || !name || !data || (!shape && ndim > 0) || ndim < 0 || ndim > 4)
+        return odam_fail(1, "odam_detr_set_weight: bad argument");
+    if (m->finalized) return odam_fail(1, "odam_detr_set_weight: model already finalized");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; i++) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    m->host[name] = std::move(t);
+    return 0;
+}
+
+extern "C" int odam_detr_finalize(odam_detr* m) {
+    if (!m) return odam_fail(1, "odam_detr_finalize: null model");
+    if (m->finalized) return 0;
+    const odam_detr_cfg& c = m->cfg;
+    const std::string bb = "backbone.0.body.";
+    {   // stem
+        NEED(w, bb + "conv1.weight");
+        RC(pack_conv(m, m->stem, *w, 2, 3));
+        RC(fold_bn(m, m->stem, bb + "bn1"));
+    }
+    for (int l = 0; l < 4; l++) {
+        for (int i = 0; i < c.resnet_blocks[l]; i++) {
+            const std::string p = bb + "layer" + std::to_string(l + 1) + "." + std::to_string(i) + ".";
+            const int stride = (i == 0 && l > 0) ? 2 : 1;
+            Bottleneck b;
+            NEED(w1, p + "conv1.weight"); NEED(w2, p + "conv2.weight"); NEED(w3, p + "conv3.weight");
+            RC(pack_conv(m, b.c1, *w1, 1, 0)); RC(fold_bn(m, b.c1, p + "bn1"));
+            RC(pack_conv(m, b.c2, *w2, stride, 1)); RC(fold_bn(m, b.c2, p + "bn2"));   // v1.5: stride on the 3x3
+            RC(pack_conv(m, b.c3, *w3, 1, 0)); RC(fold_bn(m, b.c3, p + "bn3"));
+            if (i == 0) {
+                NEED(wd, p + "downsample.0.weight");
+                RC(pack_conv(m, b.ds, *wd, stride, 0)); RC(fold_bn(m, b.ds, p + "downsample.1"));
+                b.has_ds = true;
+            }
+            m->blocks.push_back(b);
+            m->block_stride.push_back(stride);
+        }
+    }
+    {
+        NEED(w, "input_proj.weight"); NEED(b, "input_proj.bias");
+        RC(pack_conv(m, m->input_proj, *w, 1, 0));
+        RC(m->upload(&m->input_proj.bias, b->data));
+    }
+    const int E = c.hidden_dim;
+    for (int i = 0; i < c.enc_layers; i++) {
+        const std::string p = "transformer.encoder.layers." + std::to_string(i) + ".";
+        EncLayer e;
+        NEED(ipw, p + "self_attn.in_proj_weight"); NEED(ipb, p + "self_attn.in_proj_bias");
+        RC(pack_linear(m, e.qk, *ipw, ipb, 0, 2 * E));
+        RC(pack_linear(m, e.v, *ipw, ipb, 2 * E, 3 * E));
+        NEED(ow, p + "self_attn.out_proj.weight"); NEED(ob, p + "self_attn.out_proj.bias");
+        RC(pack_linear(m, e.out, *ow, ob, 0, E));
+        NEED(w1, p + "linear1.weight"); NEED(b1, p + "linear1.bias");
+        NEED(w2, p + "linear2.weight"); NEED(b2, p + "linear2.bias");
+        RC(pack_linear(m, e.l1, *w1, b1, 0, c.dim_feedforward));
+        RC(pack_linear(m, e.l2, *w2, b2, 0, E));
+        RC(pack_ln(m, e.n1, p + "norm1")); RC(pack_ln(m, e.n2, p + "norm2"));
+        m->enc.push_back(e);
+    }
+    // decoder; the cross-attention key/value projections of all layers read the same (memory + pos) / memory,
+    // so their weights are stacked into two [dec_layers*E, E] layers evaluated once per forward
+    HostTensor kall, vall, kball, vball;
+    kall.shape = {(long long)c.dec_layers * E, E}; vall.shape = kall.shape;
+    for (int i = 0; i < c.dec_layers; i++) {
+        const std::string p = "transformer.decoder.layers." + std::to_string(i) + ".";
+        DecLayer d;
+        NEED(ipw, p + "self_attn.in_proj_weight"); NEED(ipb, p + "self_attn.in_proj_bias");
+        RC(pack_linear(m, d.qk, *ipw, ipb, 0, 2 * E));
+        RC(pack_linear(m, d.v, *ipw, ipb, 2 * E, 3 * E));
+        NEED(ow, p + "self_attn.out_proj.weight"); NEED(ob, p + "self_attn.out_proj.bias");
+        RC(pack_linear(m, d.out, *ow, ob, 0, E));
+        NEED(cw, p + "multihead_attn.in_proj_weight"); NEED(cb, p + "multihead_attn.in_proj_bias");
+        RC(pack_linear(m, d.cq, *cw, cb, 0, E));
+        kall.data.insert(kall.data.end(), cw->data.begin() + (size_t)E * E, cw->data.begin() + (size_t)2 * E * E);
+        vall.data.insert(vall.data.end(), cw->data.begin() + (size_t)2 * E * E, cw->data.begin() + (size_t)3 * E * E);
+        kball.data.insert(kball.data.end(), cb->data.begin() + E, cb->data.begin() + 2 * E);
+        vball.data.insert(vball.data.end(), cb->data.begin() + 2 * E, cb->data.begin() + 3 * E);
+        NEED(cow, p + "multihead_attn.out_proj.weight"); NEED(cob, p + "multihead_attn.out_proj.bias");
+        RC(pack_linear(m, d.cout, *cow, cob, 0, E));
+        NEED(w1, p + "linear1.weight"); NEED(b1, p + "linear1.bias");
+        NEED(w2, p + "linear2.weight"); NEED(b2, p + "linear2.bias");
+        RC(pack_linear(m, d.l1, *w1, b1, 0, c.dim_feedforward));
+        RC(pack_linear(m, d.l2, *w2, b2, 0, E));
+        RC(pack_ln(m, d.n1, p + "norm1")); RC(pack_ln(m, d.n2, p + "norm2")); RC(pack_ln(m, d.n3, p + "norm3"));
+        m->dec.push_back(d);
+    }
+    kball.shape = {(long long)c.dec_layers * E}; vball.shape = kball.shape;
+    RC(pack_linear(m, m->cross_k_all, kall, &kball, 0, c.dec_layers * E));
+    RC(pack_linear(m, m->cross_v_all, vall, &vball, 0, c.dec_layers * E));
+    RC(pack_ln(m, m->dec_norm, "transformer.decoder.norm"));
+    {
+        NEED(w, "class_embed.weight"); NEED(b, "class_embed.bias");
+        RC(pack_linear(m, m->class_embed, *w, b, 0, (int)w->shape[0]));
+        const char* names[5] = {"bbox_embed", "offset_embed", "angle_embed", "size_embed", "depth_embed"};
+        for (int k = 0; k < 5; k++)
+            for (int j = 0; j < 3; j++) {
+                const std::string p = std::string(names[k]) + ".layers." + std::to_string(j);
+                NEED(lw, p + ".weight"); NEED(lb, p + ".bias");
+                RC(pack_linear(m, m->mlp[k][j], *lw, lb, 0, (int)lw->shape[0]));
+            }
+        NEED(q, "query_embed.weight");
+        RC(m->upload(&m->query_pos, q->data));
+        NEED(pe, "pos_embed");
+        if ((int)pe->shape[0] != m->L || (int)pe->shape[1] != E) return odam_fail(1, "pos_embed must be [h*w, hidden_dim]");
+        RC(m->upload(&m->pos, pe->data));
+    }
+    // workspace
+    const size_t B = c.max_batch;
+    const size_t big = B * m->H2 * m->W2 * 256;
+    RC(m->dev_alloc(&m->x4, B * c.img_h * c.img_w * 4));
+    RC(m->dev_alloc(&m->stem_out, B * m->H1 * m->W1 * 64));
+    RC(m->dev_alloc(&m->bufA, big)); RC(m->dev_alloc(&m->bufB, big)); RC(m->dev_alloc(&m->dsb, big));
+    RC(m->dev_alloc(&m->t1, big / 2)); RC(m->dev_alloc(&m->t2, big / 2));
+    const size_t M = B * m->L, Mq = B * c.num_queries, F = c.dim_feedforward;
+    RC(m->dev_alloc(&m->src, M * E)); RC(m->dev_alloc(&m->srcpos, M * E)); RC(m->dev_alloc(&m->qk, M * 2 * E));
+    RC(m->dev_alloc(&m->v, M * E)); RC(m->dev_alloc(&m->att, M * E)); RC(m->dev_alloc(&m->tmp, M * E));
+    RC(m->dev_alloc(&m->ffn, M * F));
+    RC(m->dev_alloc(&m->kc, M * c.dec_layers * E)); RC(m->dev_alloc(&m->vc, M * c.dec_layers * E));
+    RC(m->dev_alloc(&m->tgt, Mq * E)); RC(m->dev_alloc(&m->tgtpos, Mq * E)); RC(m->dev_alloc(&m->dqk, Mq * 2 * E));
+    RC(m->dev_alloc(&m->dv, Mq * E)); RC(m->dev_alloc(&m->datt, Mq * E)); RC(m->dev_alloc(&m->dq, Mq * E));
+    RC(m->dev_alloc(&m->dtmp, Mq * E)); RC(m->dev_alloc(&m->dffn, Mq * F)); RC(m->dev_alloc(&m->hs, Mq * E));
+    RC(m->dev_alloc(&m->h1, Mq * E)); RC(m->dev_alloc(&m->h2, Mq * E));
+    m->host.clear();
+    m->finalized = true;
+    return 0;
+}
+
+extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* logits, float* boxes, float* angle,
+                                 float* offset, float* size, float* depth, float* obj_features, void* stream) {
+    if (!m || !img || !logits || !boxes || !angle || !offset || !size || !depth)
+        return odam_fail(1, "odam_detr_forward: null pointer");
+    if (!m->finalized) return odam_fail(1, "odam_detr_forward: call odam_detr_finalize first");
+    if (B < 1 || B > m->cfg.max_batch) return odam_fail(3, "odam_detr_forward: batch outside 1..max_batch");
+    hipStream_t st = (hipStream_t)stream;
+    const odam_detr_cfg& c = m->cfg;
+    const int E = c.hidden_dim, Hh = c.nheads, Q = c.num_queries;
+
+    // ---- backbone (backbone.py:59-94) ----------------------------------------------------------
+    RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, st));
+    RC(run_conv(m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, 0, st));
+    RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, st));
+    float* cur = m->bufA;
+    float* nxt = m->bufB;
+    int H = m->H2, W = m->W2;
+    for (size_t i = 0; i < m->blocks.size(); i++) {
+        const Bottleneck& b = m->blocks[i];
+        const int s = m->block_stride[i];
+        const int Ho = conv_out(H, 3, s, 1), Wo = conv_out(W, 3, s, 1);
+        RC(run_conv(b.c1, cur, B, H, W, nullptr, true, m->t1, 0, st));
+        RC(run_conv(b.c2, m->t1, B, H, W, nullptr, true, m->t2, 0, st));
+        const float* res = cur;
+        if (b.has_ds) {
+            RC(run_conv(b.ds, cur, B, H, W, nullptr, false, m->dsb, 0, st));
+            res = m->dsb;
+        }
+        RC(run_conv(b.c3, m->t2, B, Ho, Wo, res, true, nxt, 0, st));
+        float* t = cur; cur = nxt; nxt = t;
+        H = Ho; W = Wo;
+    }
+    m->layer4 = cur;
+    const int L = m->L, M = B * L, Mq = B * Q;
+
+    // ---- input_proj + encoder (detr.py:70, transformer.py:154-167) -----------------------------
+    RC(run_conv(m->input_proj, cur, B, H, W, nullptr, false, m->src, 0, st));
+    RC(odam_dk::launch_add_pos(m->src, m->pos, L, m->srcpos, M, st));
+    for (size_t i = 0; i < m->enc.size(); i++) {
+        const EncLayer& e = m->enc[i];
+        RC(run_linear(e.qk, m->srcpos, M, nullptr, false, m->qk, 0, st));
+        RC(run_linear(e.v, m->src, M, nullptr, false, m->v, 0, st));
+        RC(odam_dk::launch_attention(m->qk, 2 * E, m->qk + E, 2 * E, m->v, E, m->att, E, B, Hh, L, L, st));
+        RC(run_linear(e.out, m->att, M, m->src, false, m->tmp, 0, st));
+        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n1.g, e.n1.b, m->src, nullptr, L, nullptr, M, st));
+        RC(run_linear(e.l1, m->src, M, nullptr, true, m->ffn, 0, st));
+        RC(run_linear(e.l2, m->ffn, M, m->src, false, m->tmp, 0, st));
+        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n2.g, e.n2.b, m->src, m->pos, L, m->srcpos, M, st));
+    }
+    // memory = src, memory + pos = srcpos
+    RC(run_linear(m->cross_k_all, m->srcpos, M, nullptr, false, m->kc, 0, st));
+    RC(run_linear(m->cross_v_all, m->src, M, nullptr, false, m->vc, 0, st));
+
+    // ---- decoder (transformer.py:217-238) --------------------------------------------------------
+    ODAM_HIP(hipMemsetAsync(m->tgt, 0, sizeof(float) * (size_t)Mq * E, st));
+    RC(odam_dk::launch_add_pos(nullptr, m->query_pos, Q, m->tgtpos, Mq, st));
+    const int ldkv = c.dec_layers * E;
+    for (size_t i = 0; i < m->dec.size(); i++) {
+        const DecLayer& d = m->dec[i];
+        RC(run_linear(d.qk, m->tgtpos, Mq, nullptr, false, m->dqk, 0, st));
+        RC(run_linear(d.v, m->tgt, Mq, nullptr, false, m->dv, 0, st));
+        RC(odam_dk::launch_attention(m->dqk, 2 * E, m->dqk + E, 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
+        RC(run_linear(d.out, m->datt, Mq, m->tgt, false, m->dtmp, 0, st));
+        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n1.g, d.n1.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, st));
+        RC(run_linear(d.cq, m->tgtpos, Mq, nullptr, false, m->dq, 0, st));
+        RC(odam_dk::launch_attention(m->dq, E, m->kc + i * E, ldkv, m->vc + i * E, ldkv, m->datt, E, B, Hh, Q, L, st));
+        RC(run_linear(d.cout, m->datt, Mq, m->tgt, false, m->dtmp, 0, st));
+        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n2.g, d.n2.b, m->tgt, nullptr, Q, nullptr, Mq, st));
+        RC(run_linear(d.l1, m->tgt, Mq, nullptr, true, m->dffn, 0, st));
+        RC(run_linear(d.l2, m->dffn, Mq, m->tgt, false, m->dtmp, 0, st));
+        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n3.g, d.n3.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, st));
+    }
+    float* hs = obj_features ? obj_features : m->hs;
+    RC(odam_dk::launch_add_layernorm(m->tgt, nullptr, m->dec_norm.g, m->dec_norm.b, hs, nullptr, Q, nullptr, Mq, st));
+
+    // ---- heads on the last decoder layer (detr.py:73-88) ----------------------------------------
+    RC(run_linear(m->class_embed, hs, Mq, nullptr, false, logits, 0, st));
+    float* outs[5] = {boxes, offset, angle, size, depth};
+    for (int k = 0; k < 5; k++) {
+        RC(run_linear(m->mlp[k][0], hs, Mq, nullptr, true, m->h1, 0, st));
+        RC(run_linear(m->mlp[k][1], m->h1, Mq, nullptr, true, m->h2, 0, st));
+        RC(run_linear(m->mlp[k][2], m->h2, Mq, nullptr, false, outs[k], 0, st));
+    }
+    RC(odam_dk::launch_sigmoid(boxes, Mq * 4, st));
+    return 0;
+}
+
+extern "C" int odam_detr_debug_read(odam_detr* m, int B, float* layer4_nchw, float* memory, void* stream) {
+    if (!m || !m->finalized || !m->layer4) return odam_fail(1, "odam_detr_debug_read: no forward has run");
+    hipStream_t st = (hipStream_t)stream;
+    if (layer4_nchw) RC(odam_dk::launch_nhwc_to_nchw(m->layer4, layer4_nchw, B, m->fh, m->fw, 2048, st));
+    if (memory)
+        ODAM_HIP(hipMemcpyAsync(memory, m->src, sizeof(float) * (size_t)B * m->L * m->cfg.hidden_dim,
+                                hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+extern "C" int odam_detr_postprocess(odam_detr* m, const float* logits, const float* boxes, const float* angle,
+                                     const float* offset, const float* size, const float* depth, int B,
+                                     const float* K9, float img_w, float img_h, float* rows, void* stream) {
+    if (!m || !logits || !boxes || !angle || !offset || !size || !depth || !K9 || !rows)
+        return odam_fail(1, "odam_detr_postprocess: null pointer");
+    return odam_dk::launch_postprocess(logits, boxes, angle, offset, size, depth, B, m->cfg.num_queries,
+                                       m->cfg.num_classes1, m->cfg.angle_bins, img_w, img_h, K9[0], K9[4], K9[2],
+                                       K9[5], rows, (hipStream_t)stream);
+}
+
+// ---- single-operator entry points -------------------------------------------------------------------
+extern "C" int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const float* scale, const float* bias,
+                                   const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH,
+                                   int KW, int stride, int pad, int Kpad, int relu, void* stream) {
+    if (!x || !w_packed || !y) return odam_fail(1, "odam_op_conv2d_nhwc: null pointer");
+    Conv c;
+    c.w = const_cast<float*>(w_packed); c.scale = const_cast<float*>(scale); c.bias = const_cast<float*>(bias);
+    c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
+    return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream);
+}
+
+extern "C" int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
+                                 int ldo, int B, int H, int Lq, int Lk, void* stream) {
+    if (!Q || !K || !V || !O) return odam_fail(1, "odam_op_attention: null pointer");
+    return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, (hipStream_t)stream);
+}
+
+extern "C" int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y,
+                                     int M, void* stream) {
+    if (!x || !gamma || !beta || !y) return odam_fail(1, "odam_op_add_layernorm: null pointer");
+    return odam_dk::launch_add_layernorm(x, r, gamma, beta, y, nullptr, 1, nullptr, M, (hipStream_t)stream);
+}
+
+extern "C" int odam_op_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (!x || !y || C % 4) return odam_fail(1, "odam_op_maxpool3x3s2_nhwc: bad argument");
+    return odam_dk::launch_maxpool3x3s2(x, y, B, H, W, C, conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1),
+                                        (hipStream_t)stream);
+}

@@ -1,0 +1,252 @@
+"""Host side of the detector: a drop-in for what OdamProcess needs from the reference's DETR object
+(likojack/ODAM src/models/detr.py): `detector(img_tensor) -> dict`, `detector.postprocess(...)`,
+`load_state_dict` with the reference's key names, `.to(device)`, `.eval()`, and `build(cfg)`.
+
+The arithmetic runs in the gfx950 library behind include/odam_detr.h; this file keeps only what the
+reference keeps on the host (thresholding, greedy nms_3d, list-of-numpy packaging, detr.py:124-159,
+161-205) plus the constant sine position embedding (position_encoding.py:26-46)."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .weights import RESNET_BLOCKS
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [("resnet_blocks", ctypes.c_int * 4), ("hidden_dim", ctypes.c_int), ("nheads", ctypes.c_int),
+                ("dim_feedforward", ctypes.c_int), ("enc_layers", ctypes.c_int), ("dec_layers", ctypes.c_int),
+                ("num_queries", ctypes.c_int), ("num_classes1", ctypes.c_int), ("angle_bins", ctypes.c_int),
+                ("max_batch", ctypes.c_int), ("img_h", ctypes.c_int), ("img_w", ctypes.c_int)]
+
+
+def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000):
+    """PositionEmbeddingSine(128, normalize=True) for an unpadded h x w grid -> [h*w, 256] float32
+    (position_encoding.py:26-46; torch CPU ops, so the table equals the reference's bit for bit)."""
+    not_mask = torch.ones(1, h, w, dtype=torch.bool)
+    y_embed = not_mask.cumsum(1, dtype=torch.float32)
+    x_embed = not_mask.cumsum(2, dtype=torch.float32)
+    eps, scale = 1e-6, 2 * math.pi
+    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
+    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
+    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
+    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
+    pos_x = x_embed[:, :, :, None] / dim_t
+    pos_y = y_embed[:, :, :, None] / dim_t
+    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+    pos = torch.cat((pos_y, pos_x), dim=3)  # [1, h, w, 256]
+    return pos.reshape(h * w, 2 * num_pos_feats).contiguous()
+
+
+def iou_2d(a, b):  # box_utils.py:123-144
+    x_min = max(a[0, 0], b[0, 0]); y_min = max(a[0, 1], b[0, 1])
+    x_max = min(a[1, 0], b[1, 0]); y_max = min(a[1, 1], b[1, 1])
+    inter = max(0, (x_max - x_min)) * max(0, (y_max - y_min))
+    iou = inter / (np.prod(a[1] - a[0]) + np.prod(b[1] - b[0]) - inter)
+    assert iou <= 1 and iou >= 0, "invalid IoU value"
+    return iou
+
+
+def iou_3d(a, b):  # box_utils.py:424-447
+    x_min = max(a[0, 0], b[0, 0]); y_min = max(a[0, 1], b[0, 1]); z_min = max(a[0, 2], b[0, 2])
+    x_max = min(a[1, 0], b[1, 0]); y_max = min(a[1, 1], b[1, 1]); z_max = min(a[1, 2], b[1, 2])
+    inter = max(0, (x_max - x_min)) * max(0, (y_max - y_min)) * max(0, (z_max - z_min))
+    iou = inter / (np.prod(a[1] - a[0]) + np.prod(b[1] - b[0]) - inter)
+    assert iou <= 1 and iou >= 0, "invalid IoU value"
+    return iou
+
+
+def nms_3d(class_, scores, t_cos, dimensions, bbox_2d, nms_2d=True):
+    """Greedy score-ordered suppression: same class and 3D-AABB IoU > 0.25, or 2D IoU > 0.5 (detr.py:161-205)."""
+    orders = np.argsort(scores)[::-1]
+    keep, suppressed = [], set()
+    boxes = [np.array([[-d[0], -d[1], -d[2]], [d[0], d[1], d[2]]]) / 2. + t[None, :] for d, t in zip(dimensions, t_cos)]
+    for i, s in enumerate(orders):
+        if s in suppressed:
+            continue
+        keep.append(s)
+        for t in orders[i + 1:]:
+            if t in suppressed:
+                continue
+            if class_[t] == class_[s] and iou_3d(boxes[s], boxes[t]) > 0.25:
+                suppressed.add(t)
+                continue
+            if nms_2d and iou_2d(bbox_2d[s], bbox_2d[t]) > 0.5:
+                suppressed.add(t)
+    return keep
+
+
+class Detector:
+    """DETR forward on the GPU library.  One native handle per input size (the workspace and the
+    position table depend on it), created lazily at the first call with that size."""
+
+    def __init__(self, backbone="resnet50", hidden_dim=256, nheads=8, dim_feedforward=2048, enc_layers=6,
+                 dec_layers=6, num_queries=100, num_classes=18, angle_bins=30, max_batch=8, device="cuda:0"):
+        self.arch = dict(backbone=backbone, hidden_dim=hidden_dim, nheads=nheads, dim_feedforward=dim_feedforward,
+                         enc_layers=enc_layers, dec_layers=dec_layers, num_queries=num_queries,
+                         num_classes1=num_classes + 1, angle_bins=angle_bins)
+        self.num_queries = num_queries
+        self.max_batch = max_batch
+        self.device = torch.device(device)
+        self._sd = None
+        self._handles = {}
+
+    # ---- nn.Module-like surface used by run_processor.py:30-34 -------------------------------------
+    def to(self, device):
+        self.device = torch.device("cuda:0" if str(device) == "cuda" else device)
+        return self
+
+    def cuda(self):
+        return self.to("cuda:0")
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        self._sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in state_dict.items()
+                    if torch.is_tensor(v) and not k.endswith("num_batches_tracked")}
+        self.close()
+        return self
+
+    def close(self):
+        for h in self._handles.values():
+            _lib.lib().odam_detr_destroy(h)
+        self._handles = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self, H, W):
+        key = (H, W)
+        if key in self._handles:
+            return self._handles[key]
+        if self._sd is None:
+            raise _lib.OdamError("Detector: load_state_dict() must be called before the first forward")
+        L = _lib.lib()
+        a = self.arch
+        cfg = _Cfg()
+        for i, n in enumerate(RESNET_BLOCKS[a["backbone"]]):
+            cfg.resnet_blocks[i] = n
+        for k in ("hidden_dim", "nheads", "dim_feedforward", "enc_layers", "dec_layers", "num_queries", "num_classes1",
+                  "angle_bins"):
+            setattr(cfg, k, a[k])
+        cfg.max_batch, cfg.img_h, cfg.img_w = self.max_batch, H, W
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(L.odam_detr_create(ctypes.byref(cfg), ctypes.byref(h)), "odam_detr_create")
+            fh, fw = ctypes.c_int(), ctypes.c_int()
+            _lib.check(L.odam_detr_feature_hw(h, ctypes.byref(fh), ctypes.byref(fw)), "odam_detr_feature_hw")
+            tensors = dict(self._sd)
+            tensors["pos_embed"] = sine_position_embedding(fh.value, fw.value, a["hidden_dim"] // 2)
+            for name, t in tensors.items():
+                shape = (ctypes.c_longlong * max(t.dim(), 1))(*t.shape)
+                _lib.check(L.odam_detr_set_weight(h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
+                           f"odam_detr_set_weight({name})")
+            _lib.check(L.odam_detr_finalize(h), "odam_detr_finalize")
+        self._handles[key] = h
+        return h
+
+    # ---- DETR.forward (detr.py:49-94) ---------------------------------------------------------------
+    def __call__(self, samples):
+        if isinstance(samples, (list, tuple)):
+            samples = torch.stack(list(samples))
+        x = samples.to(self.device, torch.float32).contiguous()
+        B, C, H, W = x.shape
+        assert C == 3
+        h = self._handle(H, W)
+        a = self.arch
+        Q = a["num_queries"]
+        dev = self.device
+        mk = lambda n: torch.empty(B, Q, n, device=dev, dtype=torch.float32)
+        out = {"pred_logits": mk(a["num_classes1"]), "pred_boxes": mk(4), "pred_angle": mk(a["angle_bins"]),
+               "pred_offset": mk(2), "pred_size": mk(3), "pred_depth": mk(1), "pred_obj_features": mk(a["hidden_dim"])}
+        L = _lib.lib()
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        with torch.cuda.device(dev):
+            for b0 in range(0, B, self.max_batch):
+                b1 = min(B, b0 + self.max_batch)
+                sl = lambda t: _lib.ptr(t[b0:b1])
+                _lib.check(L.odam_detr_forward(h, _lib.ptr(x[b0:b1]), ctypes.c_int(b1 - b0), sl(out["pred_logits"]),
+                                               sl(out["pred_boxes"]), sl(out["pred_angle"]), sl(out["pred_offset"]),
+                                               sl(out["pred_size"]), sl(out["pred_depth"]),
+                                               sl(out["pred_obj_features"]), ctypes.c_void_p(stream)),
+                           "odam_detr_forward")
+        out["_hw"] = (H, W)
+        return out
+
+    forward = __call__
+
+    def debug_taps(self, B, H, W):
+        """layer4 feature map [B,2048,h,w] and encoder memory [B,h*w,256] of the last forward (tests)."""
+        hd = self._handle(H, W)
+        L = _lib.lib()
+        fh, fw = ctypes.c_int(), ctypes.c_int()
+        L.odam_detr_feature_hw(hd, ctypes.byref(fh), ctypes.byref(fw))
+        l4 = torch.empty(B, 2048, fh.value, fw.value, device=self.device)
+        mem = torch.empty(B, fh.value * fw.value, self.arch["hidden_dim"], device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.odam_detr_debug_read(hd, B, _lib.ptr(l4), _lib.ptr(mem),
+                                              ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)),
+                       "odam_detr_debug_read")
+        return l4, mem
+
+    # ---- DETR.postprocess (detr.py:96-159) ----------------------------------------------------------
+    def postprocess_rows(self, out, img_size, intr_mat):
+        """device part: [B,Q,16] rows (score, class, box, 3D centre, angle bin, dims) -> numpy"""
+        H, W = out["_hw"]
+        h = self._handle(H, W)
+        B = out["pred_logits"].shape[0]
+        rows = torch.empty(B, self.num_queries, 16, device=self.device, dtype=torch.float32)
+        K9 = np.ascontiguousarray(np.asarray(intr_mat, np.float64)[:3, :3], np.float32)
+        img_w, img_h = img_size
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().odam_detr_postprocess(
+                h, _lib.ptr(out["pred_logits"]), _lib.ptr(out["pred_boxes"]), _lib.ptr(out["pred_angle"]),
+                _lib.ptr(out["pred_offset"]), _lib.ptr(out["pred_size"]), _lib.ptr(out["pred_depth"]), ctypes.c_int(B),
+                K9.ctypes.data_as(_lib.c_float_p), ctypes.c_float(img_w), ctypes.c_float(img_h), _lib.ptr(rows),
+                ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)), "odam_detr_postprocess")
+        return rows.cpu().numpy()
+
+    @staticmethod
+    def select(rows, threshold, nms_2d=True, n_bins=30):
+        """host part: threshold, greedy NMS, packaging -- one frame's [Q,16] rows"""
+        keep = rows[:, 0] > np.float32(threshold)
+        r = rows[keep]
+        score = r[:, 0]
+        cls = r[:, 1].astype(np.int64)
+        boxes = r[:, 2:6].reshape(-1, 2, 2)
+        t_co = r[:, 6:9]
+        angle = (r[:, 9] * np.float32(180 / n_bins)).astype(np.float32)
+        dims = r[:, 10:13]
+        k = nms_3d(cls, score, t_co, dims, boxes, nms_2d)
+        return dict(bboxes=boxes[k], dimensions=dims[k], angles=angle[k], translates=t_co[k], classes=cls[k],
+                    scores=score[k])
+
+    def postprocess(self, out, img_size, threshold, intr_mat, nms_2d=True):
+        rows = self.postprocess_rows(out, img_size, intr_mat)
+        res = {k: [] for k in ("bboxes", "dimensions", "angles", "translates", "classes", "scores")}
+        for b in range(rows.shape[0]):
+            s = self.select(rows[b], threshold, nms_2d, self.arch["angle_bins"])
+            for k in res:
+                res[k].append(s[k])
+        return res
+
+
+def build(args):
+    """src/models/detr.py:530-573 `build(cfg)` -> (model, criterion, postprocessors); inference only, so the
+    training-time criterion / postprocessors are None.  Reads the same config keys."""
+    g = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
+    ds = g("dataset_file", "scan_net")
+    num_classes = 18 if ds == "scan_net" else (91 if ds == "coco" else 20)
+    if g("pre_norm", False) or g("dilation", False) or g("masks", False):
+        raise _lib.OdamError("pre_norm / dilation / masks configurations are not built")
+    det = Detector(backbone=g("backbone", "resnet50"), hidden_dim=g("hidden_dim", 256), nheads=g("nheads", 8),
+                   dim_feedforward=g("dim_feedforward", 2048), enc_layers=g("enc_layers", 6),
+                   dec_layers=g("dec_layers", 6), num_queries=g("num_queries", 100), num_classes=num_classes)
+    return det, None, None

@@ -1,0 +1,280 @@
+"""OdamProcess -- the plugin surface of the reference (likojack/ODAM src/processor.py:15-368) over the
+MI355X detector and super-quadric fitter.
+
+Same constructor, attributes (`tracks`, `T_wcs`, `P_cws`, `usable_frames`, `sequence_meta`) and methods
+(`init_sequence`, `process_frame`, `run_detector`, `optim_process`, `merge_process`) so that
+src/scripts/run_processor.py:61-83 runs unchanged with `from odam_amd.processor import OdamProcess`.
+
+What is different underneath:
+  * `detector` is an odam_amd.detector.Detector (gfx950 kernels); `run_detector` can also be fed
+    detections computed ahead of time in batches / on other ranks (`detect_frames`, `process_frame(...,
+    detections=...)`): detection is stateless per frame (processor.py:259-289), association is not.
+  * `_prepare_tracks` evaluates the surface of ALL live tracks in one odam_sq_points_batch launch
+    instead of one CPU sampler call per track (processor.py:181-207).
+  * `optim_process` batches every object's 200-step fit into one kernel launch (odam_amd.multi_view).
+The associator (src/models/associator.py) and the track merge (src/scripts/run_merge.py) are the
+reference's own and stay caller-supplied / imported: they are outside this build's hot path.
+"""
+import logging
+from copy import deepcopy
+
+import numpy as np
+import torch
+
+from . import multi_view
+from .sq import init_params
+
+
+class _Meta(dict):
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def get_homogeneous(pts):  # geometry_utils.py:7-49 (numpy, [N,3] -> [N,4])
+    return np.concatenate([pts, np.ones_like(pts[:, 2:])], axis=1)
+
+
+def projection(pts, intr_mat):  # geometry_utils.py:276-316, unbatched, keep_z=False
+    pts = pts @ intr_mat.T
+    z = np.ones_like(pts[:, -1])
+    pts = pts / pts[:, -1:]
+    pts[:, -1] *= z
+    return pts
+
+
+def get_cam_azi(T_wc):  # scannet_utils.py:213-222
+    o = np.array([[0, 0, 1], [0, 0, 0]])
+    o = (get_homogeneous(o) @ T_wc.T)[:, :3]
+    o = o[0] - o[1]
+    o[2] = 0
+    o = o / np.linalg.norm(o)
+    return np.arctan2(o[1], o[0])
+
+
+def detection_rows(out_objects, b, frame_id, seq_w, seq_h):
+    """processor.py:269-288: one frame's post-processed detections -> list of 79-float rows."""
+    n = len(out_objects["bboxes"][b])
+    angles = np.asarray(out_objects["angles"][b]) / 180. * np.pi
+    rows = []
+    for i in range(n):
+        sin_azi, cos_azi = np.sin(angles[i]), np.cos(angles[i])
+        bb = out_objects["bboxes"][b][i]
+        bb[:, 0] /= seq_w
+        bb[:, 1] /= seq_h
+        d, t = out_objects["dimensions"][b][i], out_objects["translates"][b][i]
+        obj = [frame_id, out_objects["classes"][b][i], bb[0, 0], bb[0, 1], bb[1, 0], bb[1, 1], d[0], d[1], d[2],
+               t[0], t[1], t[2], sin_azi, cos_azi, out_objects["scores"][b][i]]
+        rows.append([float(f) for f in obj] + (np.zeros(64) - 1).tolist())
+    return rows
+
+
+class OdamProcess:
+    def __init__(self, detector, associator, transforms, scale_prior, detect_threshold=0.6, match_threshold=0.1,
+                 score_threshold=0.8, representation="super_quadric", no_code=True, fitter=None):
+        self.detector = detector
+        self.associator = associator
+        self.transforms = transforms
+        self.scale_prior = scale_prior
+        self.detect_threshold = detect_threshold
+        self.match_threshold = match_threshold
+        self.score_threshold = score_threshold
+        self.representation = representation
+        self.no_code = no_code
+        self.run_associator = False
+        self.tracks = None
+        self.sequence_meta = None
+        self.fitter = fitter
+        self.logger = logging.getLogger('OdamProcess')
+
+    def _fitter(self):
+        if self.fitter is None:
+            self.fitter = multi_view.default_fitter(str(getattr(self.detector, "device", "cuda:0")))
+        return self.fitter
+
+    # ---- sequence state (processor.py:291-304) ---------------------------------------------------
+    def init_sequence(self, intrinsics, img_h, img_w):
+        self.run_associator = False
+        self.sequence_meta = _Meta(K=intrinsics, img_h=img_h, img_w=img_w)
+        self.tracks = []
+        self.T_wcs = []
+        self.P_cws = []
+        self.usable_frames = []
+
+    # ---- detection (processor.py:259-289) ----------------------------------------------------------
+    def detect_frames(self, rgbs, frame_ids):
+        """Batched, stateless run_detector over several frames: list (per frame) of lists of 79-float rows."""
+        tensors = [self.transforms(rgb, None)[0] for rgb in rgbs]
+        sizes = {tuple(rgb.size) for rgb in rgbs}
+        assert len(sizes) == 1, "frames of one batch must have one size"
+        img_size = sizes.pop()
+        out = []
+        mb = getattr(self.detector, "max_batch", 1)
+        for b0 in range(0, len(tensors), mb):
+            x = torch.stack(tensors[b0:b0 + mb])
+            pred = self.detector(x)
+            objs = self.detector.postprocess(pred, img_size, float(self.detect_threshold), self.sequence_meta.K)
+            for b in range(x.shape[0]):
+                out.append(detection_rows(objs, b, frame_ids[b0 + b], self.sequence_meta.img_w,
+                                          self.sequence_meta.img_h))
+        return out
+
+    def run_detector(self, rgb, frame_id, T_wc):
+        return self.detect_frames([rgb], [frame_id])[0]
+
+    # ---- tracks (processor.py:95-257) --------------------------------------------------------------
+    def _img_size_row(self):
+        m = self.sequence_meta
+        return np.array([[m.img_w, m.img_h, m.img_w, m.img_h]])
+
+    def _init_tracks(self, detections, T_wc):
+        img_size = self._img_size_row()
+        detect_bboxes = detections[:, 2:6] * img_size
+        cam_azi = get_cam_azi(T_wc)
+        tracks = np.zeros((len(detections), 1, 82)) - 1
+        tracks[:, 0, :9] = detections[:, :9]
+        tracks[:, 0, 2:6] *= img_size
+        tracks[:, 0, -4:] = detect_bboxes
+        azi_wo = np.arctan2(detections[:, 12], detections[:, 13]) + cam_azi
+        t_wo = (get_homogeneous(detections[:, 9:12]) @ T_wc.T)[:, :3]
+        tracks[:, 0, 9:12] = t_wo
+        tracks[:, 0, 12] = azi_wo
+        tracks[:, 0, 13] = detections[:, 14]
+        return [t for t in tracks]
+
+    def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100):
+        T_cw = np.linalg.inv(T_wc)
+        in_ = torch.ones((len(tracks), n_times, 79)) * -1
+        for idx, track in enumerate(tracks):
+            n_steps = len(track)
+            tmp = np.zeros((n_steps, 79)) - 1
+            projected_bbox = track[-1, -4:]
+            assert not (projected_bbox == -1).all(), "wrong projected bbox"
+            projected_bbox /= self._img_size_row()[0]
+            projected_bbox = np.clip(projected_bbox, a_min=-1, a_max=2)
+            track[:, 2:6] = projected_bbox
+            tmp[:, 0] = track[:, 0]
+            tmp[:, 1] = track[:, 1]
+            tmp[:, 2:6] = track[:, 2:6]
+            tmp[:, 6:9] = track[:, 6:9]
+            tmp[:, 9:12] = (get_homogeneous(track[:, 9:12]) @ T_cw.T)[:, :3]
+            angle = track[:, 12] - cam_azi
+            tmp[:, 12] = np.sin(angle)
+            tmp[:, 13] = np.cos(angle)
+            tmp[:, 14] = track[:, 13]
+            tmp[:, 15:79] = track[:, 14:78]
+            tmp = torch.tensor(tmp, dtype=torch.float32)
+            if n_steps > n_times:
+                in_[idx, :, :] = tmp[-100:, :]
+            else:
+                in_[idx, :n_steps, :] = tmp
+        return in_
+
+    def _prepare_tracks(self, T_wc, n_times=100):
+        cam_azi = get_cam_azi(T_wc)
+        tracks = deepcopy(self.tracks)
+        # one batched surface evaluation for all tracks (reference: one SuperQuadric + sampler call each)
+        params = []
+        for track in tracks:
+            azi_wo = np.mean(track[:, 12], axis=0)
+            t_wo = np.mean(track[:, 9:12], axis=0)
+            dims = np.clip(np.mean(track[:, 6:9], axis=0), a_min=0.05, a_max=np.inf)
+            params.append(init_params(t_wo, azi_wo, dims))  # scales = sqrt(dims/2), shapes = -0
+        pts_all = self._fitter().points(np.stack(params)).cpu().numpy() if params else np.zeros((0, 1000, 3))
+        T_cw = np.linalg.inv(T_wc)
+        for idx, track in enumerate(tracks):
+            box_3d_c = (get_homogeneous(pts_all[idx]) @ T_cw.T)[:, :3]
+            pixels = projection(box_3d_c, self.sequence_meta.K)
+            x_min, y_min, _ = np.min(pixels, axis=0)
+            x_max, y_max, _ = np.max(pixels, axis=0)
+            track[:, -4:] = np.array([[x_min, y_min, x_max, y_max]])
+            tracks[idx] = track
+        tracks = self._preprocess_tracks(tracks, T_wc, cam_azi, n_times)
+        return tracks.permute(0, 2, 1)
+
+    def _collater(self, data_list):
+        max_dets = 30
+        n_features = data_list[0]['detections'].shape[0]
+        detections = torch.ones((len(data_list), n_features, max_dets), dtype=torch.float) * -1
+        tracks, poses, tsplit, dsplit, valid = [], [], [], [], []
+        for b_id, data in enumerate(data_list):
+            tracks.append(data['tracks'])
+            poses.append(data['pose'])
+            nt, nd = data['tracks'].shape[0], data['detections'].shape[1]
+            tsplit.append(nt); dsplit.append(nd); valid.append((nt, nd))
+            detections[b_id, :, :nd] = data['detections']
+        gt_masks = torch.zeros((sum(tsplit), sum(dsplit)), dtype=torch.float)
+        t0 = d0 = 0
+        for nt, nd in zip(tsplit, dsplit):
+            gt_masks[t0:t0 + nt, d0:d0 + nd] = 1
+            t0 += nt; d0 += nd
+        return {"tracks": torch.cat(tracks, dim=0), "detections": detections, "gt_masks": gt_masks,
+                "track_batch_split": tsplit, "detection_batch_split": dsplit, "poses": poses, "valid_list": valid}
+
+    def _attach_to_tracks(self, pred_match, detections, T_wc, score_mat):
+        cam_azi = get_cam_azi(T_wc)
+        t_wo = (get_homogeneous(detections[:, 9:12]) @ T_wc.T)[:, :3]
+        detections[:, 9:12] = t_wo
+        azi_wo = np.arctan2(detections[:, 12], detections[:, 13]) + cam_azi
+        img_size = self._img_size_row()[0]
+        for match_track_id, det_id, detection in zip(pred_match, np.arange(len(detections)), detections):
+            if score_mat[match_track_id, det_id] < self.score_threshold:
+                continue
+            attach_ = np.zeros((1, 82))
+            attach_[0, :9] = detection[:9]
+            attach_[0, 2:6] *= img_size
+            attach_[0, 9:12] = t_wo[det_id]
+            attach_[0, 12] = azi_wo[det_id]
+            attach_[0, 13] = detection[14]
+            attach_[0, 14:78] = -1 if self.no_code else detection[15:79]
+            attach_[0, 78:82] = detection[2:6] * img_size
+            if match_track_id == -1:
+                self.tracks.append(attach_)
+            else:
+                self.tracks[match_track_id] = np.concatenate([self.tracks[match_track_id], attach_], axis=0)
+
+    # ---- per-frame driver (processor.py:306-345) ---------------------------------------------------
+    def process_frame(self, rgb, frame_id, T_wc, detections=None):
+        """`detections`: optional rows for this frame computed earlier by `detect_frames` (here or on another
+        rank); None -> run the detector now, as the reference does."""
+        self.usable_frames.append(frame_id)
+        self.T_wcs.append(T_wc)
+        self.P_cws.append(self.sequence_meta.K @ np.linalg.inv(T_wc)[:3, :])
+        if detections is None:
+            detections = self.run_detector(rgb, frame_id, T_wc)
+        if len(detections) == 0:
+            return None
+        detections = np.asarray(detections)
+        if len(detections) > 30:
+            detections = detections[:30, :]
+        if not self.run_associator:
+            self.run_associator = True
+            self.tracks = self._init_tracks(detections, T_wc)
+            return None
+        dev = getattr(self.detector, "device", "cuda")
+        track_tensors = self._prepare_tracks(T_wc)
+        data = self._collater([{"detections": torch.from_numpy(detections).float().to(dev).T,
+                                "tracks": track_tensors, "pose": T_wc}])
+        n_tracks, n_detections = data['valid_list'][0]
+        with torch.no_grad():
+            predictions = self.associator(data, self.match_threshold, eval_only=True)
+        pred_matches = predictions['matches'][0].astype(np.int32)
+        score_mat = predictions['pred'][0][0].cpu().exp().numpy()
+        dets = data['detections'][0, :, :n_detections].numpy().T
+        self._attach_to_tracks(pred_matches, dets, T_wc, score_mat)
+
+    # ---- back end (processor.py:347-368) -----------------------------------------------------------
+    def merge_process(self, data):
+        try:
+            from src.scripts.run_merge import merge_process  # the reference's own, when on PYTHONPATH
+        except Exception as e:  # pragma: no cover
+            raise NotImplementedError(
+                "track merging (src/scripts/run_merge.py) is outside this build's hot path; put the reference "
+                "tree on PYTHONPATH or merge the tracks yourself") from e
+        self.logger.info("merging tracks")
+        return merge_process(data, self.usable_frames)
+
+    def optim_process(self, tracks):
+        m = self.sequence_meta
+        return multi_view.optim_process(tracks, self.usable_frames, self.T_wcs, self.P_cws, m.img_h, m.img_w, m.K,
+                                        self.representation, prior=True, n_iters=200, n_views=10,
+                                        fitter=self._fitter())

@@ -1,0 +1,84 @@
+"""Deterministic synthetic detector weights under the reference's state_dict key names
+(the trained checkpoints of the reference are a Google-Drive download, README.md:13 -- not available
+offline).  Same generator on every box: torch's CPU Philox/MT streams are version-stable.
+
+Scaling keeps activations O(1) through the 16/33 bottlenecks (He-uniform filters, residual branch
+damped through bn3.weight) and spreads the class logits so that some queries clear the 0.6 detection
+threshold, which exercises post-processing, NMS and everything downstream."""
+import math
+
+import torch
+
+RESNET_BLOCKS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3)}
+
+
+def _u(gen, shape, bound):
+    return (torch.rand(shape, generator=gen, dtype=torch.float32) * 2 - 1) * bound
+
+
+def _conv(gen, cout, cin, k):
+    return _u(gen, (cout, cin, k, k), math.sqrt(6.0 / (cin * k * k)))
+
+
+def _bn(sd, p, gen, n, gain=1.0):
+    sd[p + ".weight"] = gain * (1.0 + 0.1 * _u(gen, (n,), 1.0))
+    sd[p + ".bias"] = 0.05 * _u(gen, (n,), 1.0)
+    sd[p + ".running_mean"] = 0.05 * _u(gen, (n,), 1.0)
+    sd[p + ".running_var"] = 1.0 + 0.2 * _u(gen, (n,), 1.0)
+
+
+def _linear(sd, p, gen, nout, nin, wscale=1.0, bias=0.0):
+    sd[p + ".weight"] = _u(gen, (nout, nin), wscale * math.sqrt(3.0 / nin))
+    sd[p + ".bias"] = bias + 0.02 * _u(gen, (nout,), 1.0)
+
+
+def make_state_dict(backbone="resnet50", hidden=256, ffn=2048, enc_layers=6, dec_layers=6, num_queries=100,
+                    num_classes=18, angle_bins=30, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    bb = "backbone.0.body."
+    sd[bb + "conv1.weight"] = _conv(g, 64, 3, 7)
+    _bn(sd, bb + "bn1", g, 64)
+    inplanes = 64
+    for l, nb in enumerate(RESNET_BLOCKS[backbone]):
+        planes = 64 * 2 ** l
+        for i in range(nb):
+            p = f"{bb}layer{l + 1}.{i}."
+            sd[p + "conv1.weight"] = _conv(g, planes, inplanes, 1); _bn(sd, p + "bn1", g, planes)
+            sd[p + "conv2.weight"] = _conv(g, planes, planes, 3); _bn(sd, p + "bn2", g, planes)
+            sd[p + "conv3.weight"] = _conv(g, planes * 4, planes, 1); _bn(sd, p + "bn3", g, planes * 4, gain=0.4)
+            if i == 0:
+                sd[p + "downsample.0.weight"] = _conv(g, planes * 4, inplanes, 1)
+                _bn(sd, p + "downsample.1", g, planes * 4, gain=0.7)
+            inplanes = planes * 4
+    sd["input_proj.weight"] = _u(g, (hidden, inplanes, 1, 1), math.sqrt(3.0 / inplanes))
+    sd["input_proj.bias"] = 0.02 * _u(g, (hidden,), 1.0)
+
+    def attn(p):
+        sd[p + "in_proj_weight"] = _u(g, (3 * hidden, hidden), 1.5 * math.sqrt(3.0 / hidden))
+        sd[p + "in_proj_bias"] = 0.02 * _u(g, (3 * hidden,), 1.0)
+        _linear(sd, p + "out_proj", g, hidden, hidden)
+
+    def ln(p):
+        sd[p + ".weight"] = 1.0 + 0.1 * _u(g, (hidden,), 1.0)
+        sd[p + ".bias"] = 0.05 * _u(g, (hidden,), 1.0)
+
+    for i in range(enc_layers):
+        p = f"transformer.encoder.layers.{i}."
+        attn(p + "self_attn.")
+        _linear(sd, p + "linear1", g, ffn, hidden); _linear(sd, p + "linear2", g, hidden, ffn)
+        ln(p + "norm1"); ln(p + "norm2")
+    for i in range(dec_layers):
+        p = f"transformer.decoder.layers.{i}."
+        attn(p + "self_attn."); attn(p + "multihead_attn.")
+        _linear(sd, p + "linear1", g, ffn, hidden); _linear(sd, p + "linear2", g, hidden, ffn)
+        ln(p + "norm1"); ln(p + "norm2"); ln(p + "norm3")
+    ln("transformer.decoder.norm")
+    sd["query_embed.weight"] = torch.randn((num_queries, hidden), generator=g, dtype=torch.float32)
+    _linear(sd, "class_embed", g, num_classes + 1, hidden, wscale=4.0)
+    for name, nout, bias in (("bbox_embed", 4, 0.0), ("offset_embed", 2, 0.0), ("angle_embed", angle_bins, 0.0),
+                             ("size_embed", 3, 0.8), ("depth_embed", 1, 2.5)):
+        _linear(sd, name + ".layers.0", g, hidden, hidden)
+        _linear(sd, name + ".layers.1", g, hidden, hidden)
+        _linear(sd, name + ".layers.2", g, nout, hidden, wscale=0.5, bias=bias)
+    return sd
