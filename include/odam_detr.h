@@ -77,6 +77,15 @@ int odam_detr_postprocess(odam_detr* m, const float* logits, const float* boxes,
                           const float* offset, const float* size, const float* depth, int B, const float* K9,
                           float img_w, float img_h, float* rows, void* stream);
 
+/* Threshold + greedy nms_3d (detr.py:124-125, 161-205) on ONE frame's rows [host][Q,16] as written by
+ * odam_detr_postprocess; keep_idx [host][Q] receives the kept query indices in descending-score order. */
+int odam_detr_select(const float* rows, int Q, float threshold, int nms_2d, int* keep_idx, int* n_keep);
+
+/* Per-launch timing of the contraction kernel (all conv / linear launches of a forward are bracketed by
+ * event pairs while enabled); read returns the totals of the most recent forward. */
+int odam_detr_profile_enable(odam_detr* m, int on);
+int odam_detr_profile_read(odam_detr* m, int* n_launches, double* total_ms, double* total_flops);
+
 /* ---- single-operator entry points (the same kernels the forward uses; for parity tests and reuse) ---- */
 /* NHWC convolution / linear:  x [dev][B,H,W,Cin] (Cin power of two >= 4), w_packed [dev][Cout][Kpad]
  * (k = (ky*KW+kx)*Cin+ci, zero padded to a multiple of 32), scale/bias/residual nullable, y [dev][B,Ho,Wo,Cout] */

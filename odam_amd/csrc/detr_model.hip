@@ -7,6 +7,7 @@
 // Layout: activations NHWC / [B*L, C] batch-major rows; every contraction runs on conv_gemm.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -79,6 +80,13 @@ struct odam_detr {
     float *tgt = nullptr, *tgtpos = nullptr, *dqk = nullptr, *dv = nullptr, *datt = nullptr, *dq = nullptr,
           *dtmp = nullptr, *dffn = nullptr, *hs = nullptr, *h1 = nullptr, *h2 = nullptr;
     const float* layer4 = nullptr;  // where the last forward left the layer4 map (NHWC)
+
+    // optional per-launch timing of the contraction kernel (bench.py roofline): event pairs around every
+    // conv_gemm launch of a forward, read back by odam_detr_profile_read
+    bool profile = false;
+    std::vector<hipEvent_t> ev;
+    std::vector<double> ev_flops;
+    size_t ev_used = 0;
 
     template <typename T>
     int dev_alloc(T** p, size_t n) {
@@ -174,6 +182,31 @@ int run_linear(const Conv& c, const float* x, int M, const float* res, bool relu
     return run_conv(c, x, 1, 1, M, res, relu, y, ldc, st);
 }
 
+// timed variants used by the forward: identical launches, bracketed by events when profiling is on
+int conv_t(odam_detr* m, const Conv& c, const float* x, int B, int H, int W, const float* res, bool relu, float* y,
+           hipStream_t st) {
+    if (!m->profile) return run_conv(c, x, B, H, W, res, relu, y, 0, st);
+    if (m->ev_used + 2 > m->ev.size()) {
+        for (int k = 0; k < 2; k++) {
+            hipEvent_t e;
+            ODAM_HIP(hipEventCreate(&e));
+            m->ev.push_back(e);
+        }
+        m->ev_flops.resize(m->ev.size() / 2);
+    }
+    const int Ho = conv_out(H, c.KH, c.stride, c.pad), Wo = conv_out(W, c.KW, c.stride, c.pad);
+    const int Cin_true = (c.KH == 7) ? 3 : c.Cin;  // the stem's 4th input channel is zero padding
+    m->ev_flops[m->ev_used / 2] = 2.0 * B * Ho * Wo * (double)c.Cout * c.KH * c.KW * Cin_true;
+    ODAM_HIP(hipEventRecord(m->ev[m->ev_used], st));
+    int rc = run_conv(c, x, B, H, W, res, relu, y, 0, st);
+    ODAM_HIP(hipEventRecord(m->ev[m->ev_used + 1], st));
+    m->ev_used += 2;
+    return rc;
+}
+int lin_t(odam_detr* m, const Conv& c, const float* x, int M, const float* res, bool relu, float* y, hipStream_t st) {
+    return conv_t(m, c, x, 1, 1, M, res, relu, y, st);
+}
+
 #define RC(call)                 \
     do {                         \
         int rc_ = (call);        \
@@ -201,6 +234,7 @@ extern "C" int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out) {
 extern "C" int odam_detr_destroy(odam_detr* m) {
     if (!m) return 0;
     for (void* p : m->allocs) (void)hipFree(p);
+    for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
     delete m;
     return 0;
 }
@@ -348,12 +382,13 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
     if (!m->finalized) return odam_fail(1, "odam_detr_forward: call odam_detr_finalize first");
     if (B < 1 || B > m->cfg.max_batch) return odam_fail(3, "odam_detr_forward: batch outside 1..max_batch");
     hipStream_t st = (hipStream_t)stream;
+    m->ev_used = 0;
     const odam_detr_cfg& c = m->cfg;
     const int E = c.hidden_dim, Hh = c.nheads, Q = c.num_queries;
 
     // ---- backbone (backbone.py:59-94) ----------------------------------------------------------
     RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, st));
-    RC(run_conv(m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, 0, st));
+    RC(conv_t(m, m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, st));
     RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, st));
     float* cur = m->bufA;
     float* nxt = m->bufB;
@@ -362,14 +397,14 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
         const Bottleneck& b = m->blocks[i];
         const int s = m->block_stride[i];
         const int Ho = conv_out(H, 3, s, 1), Wo = conv_out(W, 3, s, 1);
-        RC(run_conv(b.c1, cur, B, H, W, nullptr, true, m->t1, 0, st));
-        RC(run_conv(b.c2, m->t1, B, H, W, nullptr, true, m->t2, 0, st));
+        RC(conv_t(m, b.c1, cur, B, H, W, nullptr, true, m->t1, st));
+        RC(conv_t(m, b.c2, m->t1, B, H, W, nullptr, true, m->t2, st));
         const float* res = cur;
         if (b.has_ds) {
-            RC(run_conv(b.ds, cur, B, H, W, nullptr, false, m->dsb, 0, st));
+            RC(conv_t(m, b.ds, cur, B, H, W, nullptr, false, m->dsb, st));
             res = m->dsb;
         }
-        RC(run_conv(b.c3, m->t2, B, Ho, Wo, res, true, nxt, 0, st));
+        RC(conv_t(m, b.c3, m->t2, B, Ho, Wo, res, true, nxt, st));
         float* t = cur; cur = nxt; nxt = t;
         H = Ho; W = Wo;
     }
@@ -377,22 +412,22 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
     const int L = m->L, M = B * L, Mq = B * Q;
 
     // ---- input_proj + encoder (detr.py:70, transformer.py:154-167) -----------------------------
-    RC(run_conv(m->input_proj, cur, B, H, W, nullptr, false, m->src, 0, st));
+    RC(conv_t(m, m->input_proj, cur, B, H, W, nullptr, false, m->src, st));
     RC(odam_dk::launch_add_pos(m->src, m->pos, L, m->srcpos, M, st));
     for (size_t i = 0; i < m->enc.size(); i++) {
         const EncLayer& e = m->enc[i];
-        RC(run_linear(e.qk, m->srcpos, M, nullptr, false, m->qk, 0, st));
-        RC(run_linear(e.v, m->src, M, nullptr, false, m->v, 0, st));
+        RC(lin_t(m, e.qk, m->srcpos, M, nullptr, false, m->qk, st));
+        RC(lin_t(m, e.v, m->src, M, nullptr, false, m->v, st));
         RC(odam_dk::launch_attention(m->qk, 2 * E, m->qk + E, 2 * E, m->v, E, m->att, E, B, Hh, L, L, st));
-        RC(run_linear(e.out, m->att, M, m->src, false, m->tmp, 0, st));
+        RC(lin_t(m, e.out, m->att, M, m->src, false, m->tmp, st));
         RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n1.g, e.n1.b, m->src, nullptr, L, nullptr, M, st));
-        RC(run_linear(e.l1, m->src, M, nullptr, true, m->ffn, 0, st));
-        RC(run_linear(e.l2, m->ffn, M, m->src, false, m->tmp, 0, st));
+        RC(lin_t(m, e.l1, m->src, M, nullptr, true, m->ffn, st));
+        RC(lin_t(m, e.l2, m->ffn, M, m->src, false, m->tmp, st));
         RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n2.g, e.n2.b, m->src, m->pos, L, m->srcpos, M, st));
     }
     // memory = src, memory + pos = srcpos
-    RC(run_linear(m->cross_k_all, m->srcpos, M, nullptr, false, m->kc, 0, st));
-    RC(run_linear(m->cross_v_all, m->src, M, nullptr, false, m->vc, 0, st));
+    RC(lin_t(m, m->cross_k_all, m->srcpos, M, nullptr, false, m->kc, st));
+    RC(lin_t(m, m->cross_v_all, m->src, M, nullptr, false, m->vc, st));
 
     // ---- decoder (transformer.py:217-238) --------------------------------------------------------
     ODAM_HIP(hipMemsetAsync(m->tgt, 0, sizeof(float) * (size_t)Mq * E, st));
@@ -400,29 +435,29 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
     const int ldkv = c.dec_layers * E;
     for (size_t i = 0; i < m->dec.size(); i++) {
         const DecLayer& d = m->dec[i];
-        RC(run_linear(d.qk, m->tgtpos, Mq, nullptr, false, m->dqk, 0, st));
-        RC(run_linear(d.v, m->tgt, Mq, nullptr, false, m->dv, 0, st));
+        RC(lin_t(m, d.qk, m->tgtpos, Mq, nullptr, false, m->dqk, st));
+        RC(lin_t(m, d.v, m->tgt, Mq, nullptr, false, m->dv, st));
         RC(odam_dk::launch_attention(m->dqk, 2 * E, m->dqk + E, 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
-        RC(run_linear(d.out, m->datt, Mq, m->tgt, false, m->dtmp, 0, st));
+        RC(lin_t(m, d.out, m->datt, Mq, m->tgt, false, m->dtmp, st));
         RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n1.g, d.n1.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, st));
-        RC(run_linear(d.cq, m->tgtpos, Mq, nullptr, false, m->dq, 0, st));
+        RC(lin_t(m, d.cq, m->tgtpos, Mq, nullptr, false, m->dq, st));
         RC(odam_dk::launch_attention(m->dq, E, m->kc + i * E, ldkv, m->vc + i * E, ldkv, m->datt, E, B, Hh, Q, L, st));
-        RC(run_linear(d.cout, m->datt, Mq, m->tgt, false, m->dtmp, 0, st));
+        RC(lin_t(m, d.cout, m->datt, Mq, m->tgt, false, m->dtmp, st));
         RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n2.g, d.n2.b, m->tgt, nullptr, Q, nullptr, Mq, st));
-        RC(run_linear(d.l1, m->tgt, Mq, nullptr, true, m->dffn, 0, st));
-        RC(run_linear(d.l2, m->dffn, Mq, m->tgt, false, m->dtmp, 0, st));
+        RC(lin_t(m, d.l1, m->tgt, Mq, nullptr, true, m->dffn, st));
+        RC(lin_t(m, d.l2, m->dffn, Mq, m->tgt, false, m->dtmp, st));
         RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n3.g, d.n3.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, st));
     }
     float* hs = obj_features ? obj_features : m->hs;
     RC(odam_dk::launch_add_layernorm(m->tgt, nullptr, m->dec_norm.g, m->dec_norm.b, hs, nullptr, Q, nullptr, Mq, st));
 
     // ---- heads on the last decoder layer (detr.py:73-88) ----------------------------------------
-    RC(run_linear(m->class_embed, hs, Mq, nullptr, false, logits, 0, st));
+    RC(lin_t(m, m->class_embed, hs, Mq, nullptr, false, logits, st));
     float* outs[5] = {boxes, offset, angle, size, depth};
     for (int k = 0; k < 5; k++) {
-        RC(run_linear(m->mlp[k][0], hs, Mq, nullptr, true, m->h1, 0, st));
-        RC(run_linear(m->mlp[k][1], m->h1, Mq, nullptr, true, m->h2, 0, st));
-        RC(run_linear(m->mlp[k][2], m->h2, Mq, nullptr, false, outs[k], 0, st));
+        RC(lin_t(m, m->mlp[k][0], hs, Mq, nullptr, true, m->h1, st));
+        RC(lin_t(m, m->mlp[k][1], m->h1, Mq, nullptr, true, m->h2, st));
+        RC(lin_t(m, m->mlp[k][2], m->h2, Mq, nullptr, false, outs[k], st));
     }
     RC(odam_dk::launch_sigmoid(boxes, Mq * 4, st));
     return 0;
@@ -475,4 +510,87 @@ extern "C" int odam_op_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H,
     if (!x || !y || C % 4) return odam_fail(1, "odam_op_maxpool3x3s2_nhwc: bad argument");
     return odam_dk::launch_maxpool3x3s2(x, y, B, H, W, C, conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1),
                                         (hipStream_t)stream);
+}
+
+// ---- per-launch timing of the contraction kernel (roofline measurement) ---------------------------------
+extern "C" int odam_detr_profile_enable(odam_detr* m, int on) {
+    if (!m) return odam_fail(1, "odam_detr_profile_enable: null model");
+    m->profile = on != 0;
+    m->ev_used = 0;
+    return 0;
+}
+
+extern "C" int odam_detr_profile_read(odam_detr* m, int* n_launches, double* total_ms, double* total_flops) {
+    if (!m || !n_launches || !total_ms || !total_flops) return odam_fail(1, "odam_detr_profile_read: null argument");
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i + 1 < m->ev_used; i += 2) {
+        ODAM_HIP(hipEventSynchronize(m->ev[i + 1]));
+        float t = 0.0f;
+        ODAM_HIP(hipEventElapsedTime(&t, m->ev[i], m->ev[i + 1]));
+        ms += t;
+        fl += m->ev_flops[i / 2];
+    }
+    *n_launches = (int)(m->ev_used / 2);
+    *total_ms = ms;
+    *total_flops = fl;
+    return 0;
+}
+
+// ---- threshold + greedy 3D/2D NMS on one frame's post-processed rows (host, float32 as the reference's numpy) --
+// detr.py:124-125 (keep = score > threshold, in query order) and :161-205 (nms_3d):
+// candidates sorted by descending score; a later candidate is suppressed by a kept one when
+// (same class and 3D-AABB IoU > 0.25) or (nms_2d and 2D IoU > 0.5).  keep_idx receives query indices in kept order.
+extern "C" int odam_detr_select(const float* rows, int Q, float threshold, int nms_2d, int* keep_idx, int* n_keep) {
+    if (!rows || !keep_idx || !n_keep || Q < 0) return odam_fail(1, "odam_detr_select: bad argument");
+    std::vector<int> cand;
+    for (int q = 0; q < Q; q++)
+        if (rows[(size_t)q * 16] > threshold) cand.push_back(q);
+    std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return rows[(size_t)a * 16] < rows[(size_t)b * 16]; });
+    std::reverse(cand.begin(), cand.end());
+    const int n = (int)cand.size();
+    std::vector<char> sup(n, 0);
+    auto box3 = [&](int q, float lo[3], float hi[3]) {
+        const float* r = rows + (size_t)q * 16;
+        for (int k = 0; k < 3; k++) {
+            lo[k] = (-r[10 + k]) / 2.0f + r[6 + k];
+            hi[k] = r[10 + k] / 2.0f + r[6 + k];
+        }
+    };
+    int nk = 0;
+    for (int i = 0; i < n; i++) {
+        if (sup[i]) continue;
+        const int s = cand[i];
+        keep_idx[nk++] = s;
+        float slo[3], shi[3];
+        box3(s, slo, shi);
+        const float* rs = rows + (size_t)s * 16;
+        for (int j = i + 1; j < n; j++) {
+            if (sup[j]) continue;
+            const int t = cand[j];
+            const float* rt = rows + (size_t)t * 16;
+            float tlo[3], thi[3];
+            box3(t, tlo, thi);
+            float inter = 1.0f, va = 1.0f, vb = 1.0f;
+            {
+                const float dx = std::max(0.0f, std::min(shi[0], thi[0]) - std::max(slo[0], tlo[0]));
+                const float dy = std::max(0.0f, std::min(shi[1], thi[1]) - std::max(slo[1], tlo[1]));
+                const float dz = std::max(0.0f, std::min(shi[2], thi[2]) - std::max(slo[2], tlo[2]));
+                inter = dx * dy * dz;
+                va = (shi[0] - slo[0]) * (shi[1] - slo[1]) * (shi[2] - slo[2]);
+                vb = (thi[0] - tlo[0]) * (thi[1] - tlo[1]) * (thi[2] - tlo[2]);
+            }
+            const float iou3 = inter / (va + vb - inter);
+            if (rt[1] == rs[1] && iou3 > 0.25f) { sup[j] = 1; continue; }
+            if (nms_2d) {
+                const float ix = std::max(0.0f, std::min(rs[4], rt[4]) - std::max(rs[2], rt[2]));
+                const float iy = std::max(0.0f, std::min(rs[5], rt[5]) - std::max(rs[3], rt[3]));
+                const float ia = ix * iy;
+                const float aa = (rs[4] - rs[2]) * (rs[5] - rs[3]);
+                const float ab = (rt[4] - rt[2]) * (rt[5] - rt[3]);
+                if (ia / (aa + ab - ia) > 0.5f) sup[j] = 1;
+            }
+        }
+    }
+    *n_keep = nk;
+    return 0;
 }

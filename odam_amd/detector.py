@@ -41,44 +41,6 @@ def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000):
     return pos.reshape(h * w, 2 * num_pos_feats).contiguous()
 
 
-def iou_2d(a, b):  # box_utils.py:123-144
-    x_min = max(a[0, 0], b[0, 0]); y_min = max(a[0, 1], b[0, 1])
-    x_max = min(a[1, 0], b[1, 0]); y_max = min(a[1, 1], b[1, 1])
-    inter = max(0, (x_max - x_min)) * max(0, (y_max - y_min))
-    iou = inter / (np.prod(a[1] - a[0]) + np.prod(b[1] - b[0]) - inter)
-    assert iou <= 1 and iou >= 0, "invalid IoU value"
-    return iou
-
-
-def iou_3d(a, b):  # box_utils.py:424-447
-    x_min = max(a[0, 0], b[0, 0]); y_min = max(a[0, 1], b[0, 1]); z_min = max(a[0, 2], b[0, 2])
-    x_max = min(a[1, 0], b[1, 0]); y_max = min(a[1, 1], b[1, 1]); z_max = min(a[1, 2], b[1, 2])
-    inter = max(0, (x_max - x_min)) * max(0, (y_max - y_min)) * max(0, (z_max - z_min))
-    iou = inter / (np.prod(a[1] - a[0]) + np.prod(b[1] - b[0]) - inter)
-    assert iou <= 1 and iou >= 0, "invalid IoU value"
-    return iou
-
-
-def nms_3d(class_, scores, t_cos, dimensions, bbox_2d, nms_2d=True):
-    """Greedy score-ordered suppression: same class and 3D-AABB IoU > 0.25, or 2D IoU > 0.5 (detr.py:161-205)."""
-    orders = np.argsort(scores)[::-1]
-    keep, suppressed = [], set()
-    boxes = [np.array([[-d[0], -d[1], -d[2]], [d[0], d[1], d[2]]]) / 2. + t[None, :] for d, t in zip(dimensions, t_cos)]
-    for i, s in enumerate(orders):
-        if s in suppressed:
-            continue
-        keep.append(s)
-        for t in orders[i + 1:]:
-            if t in suppressed:
-                continue
-            if class_[t] == class_[s] and iou_3d(boxes[s], boxes[t]) > 0.25:
-                suppressed.add(t)
-                continue
-            if nms_2d and iou_2d(bbox_2d[s], bbox_2d[t]) > 0.5:
-                suppressed.add(t)
-    return keep
-
-
 class Detector:
     """DETR forward on the GPU library.  One native handle per input size (the workspace and the
     position table depend on it), created lazily at the first call with that size."""
@@ -215,18 +177,58 @@ class Detector:
 
     @staticmethod
     def select(rows, threshold, nms_2d=True, n_bins=30):
-        """host part: threshold, greedy NMS, packaging -- one frame's [Q,16] rows"""
-        keep = rows[:, 0] > np.float32(threshold)
-        r = rows[keep]
-        score = r[:, 0]
-        cls = r[:, 1].astype(np.int64)
-        boxes = r[:, 2:6].reshape(-1, 2, 2)
-        t_co = r[:, 6:9]
-        angle = (r[:, 9] * np.float32(180 / n_bins)).astype(np.float32)
-        dims = r[:, 10:13]
-        k = nms_3d(cls, score, t_co, dims, boxes, nms_2d)
-        return dict(bboxes=boxes[k], dimensions=dims[k], angles=angle[k], translates=t_co[k], classes=cls[k],
-                    scores=score[k])
+        """host part: threshold + greedy NMS (odam_detr_select, C++) and packaging -- one frame's [Q,16] rows"""
+        rows = np.ascontiguousarray(rows, np.float32)
+        Q = rows.shape[0]
+        keep = np.zeros(max(Q, 1), np.int32)
+        n = ctypes.c_int()
+        _lib.check(_lib.lib().odam_detr_select(rows.ctypes.data_as(_lib.c_float_p), ctypes.c_int(Q),
+                                               ctypes.c_float(threshold), ctypes.c_int(int(bool(nms_2d))),
+                                               keep.ctypes.data_as(_lib.c_int_p), ctypes.byref(n)), "odam_detr_select")
+        r = rows[keep[:n.value]]
+        return dict(bboxes=r[:, 2:6].reshape(-1, 2, 2).copy(), dimensions=r[:, 10:13].copy(),
+                    angles=(r[:, 9] * np.float32(180 / n_bins)).astype(np.float32), translates=r[:, 6:9].copy(),
+                    classes=r[:, 1].astype(np.int64), scores=r[:, 0].copy())
+
+    def detect_resident(self, frames, img_size, intr_mat):
+        """Forward + per-query post-processing over frames already resident on the device
+        ([N,3,H,W] float32), max_batch at a time, everything enqueued back to back; one device->host copy of
+        the [N,Q,16] rows at the end.  Returns the rows as numpy."""
+        N, _, H, W = frames.shape
+        h = self._handle(H, W)
+        a = self.arch
+        Q = a["num_queries"]
+        dev = self.device
+        L = _lib.lib()
+        rows = torch.empty(N, Q, 16, device=dev, dtype=torch.float32)
+        mb = self.max_batch
+        if not hasattr(self, "_scratch") or self._scratch[0].shape[0] != mb:
+            mk = lambda n: torch.empty(mb, Q, n, device=dev, dtype=torch.float32)
+            self._scratch = [mk(a["num_classes1"]), mk(4), mk(a["angle_bins"]), mk(2), mk(3), mk(1)]
+        lg, bx, an, of, sz, dp = self._scratch
+        K9 = np.ascontiguousarray(np.asarray(intr_mat, np.float64)[:3, :3], np.float32)
+        img_w, img_h = img_size
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            for b0 in range(0, N, mb):
+                B = min(mb, N - b0)
+                _lib.check(L.odam_detr_forward(h, _lib.ptr(frames[b0:b0 + B]), ctypes.c_int(B), _lib.ptr(lg), _lib.ptr(bx),
+                                               _lib.ptr(an), _lib.ptr(of), _lib.ptr(sz), _lib.ptr(dp), ctypes.c_void_p(0),
+                                               stream), "odam_detr_forward")
+                _lib.check(L.odam_detr_postprocess(h, _lib.ptr(lg), _lib.ptr(bx), _lib.ptr(an), _lib.ptr(of), _lib.ptr(sz),
+                                                   _lib.ptr(dp), ctypes.c_int(B), K9.ctypes.data_as(_lib.c_float_p),
+                                                   ctypes.c_float(img_w), ctypes.c_float(img_h), _lib.ptr(rows[b0:b0 + B]),
+                                                   stream), "odam_detr_postprocess")
+        return rows.cpu().numpy()
+
+    def profile(self, H, W, on):
+        _lib.check(_lib.lib().odam_detr_profile_enable(self._handle(H, W), ctypes.c_int(int(on))), "profile_enable")
+
+    def profile_read(self, H, W):
+        n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib().odam_detr_profile_read(self._handle(H, W), ctypes.byref(n), ctypes.byref(ms),
+                                                     ctypes.byref(fl)), "profile_read")
+        return n.value, ms.value, fl.value
 
     def postprocess(self, out, img_size, threshold, intr_mat, nms_2d=True):
         rows = self.postprocess_rows(out, img_size, intr_mat)

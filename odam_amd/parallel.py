@@ -1,0 +1,110 @@
+"""Data-parallel layout of a scene over the GPUs of one node (one process per GPU, torch.distributed;
+backend "nccl" is RCCL over xGMI on ROCm, "gloo" in the CPU tests).
+
+The path shards twice: detection is stateless per frame (src/processor.py:259-289),
+super-quadric fits are independent per object (src/scripts/run_multi_view.py:44-69); association between
+them is sequential and replicated.  Two tiny collectives carry everything:
+  1. all-gather of fixed-shape detection blocks  float32[F_local, 30, 15] + int32[F_local]   (before association)
+  2. all-gather of fitted parameters / boxes     float32[n_local, 9] (+ [n_local, 8, 3])       (after the fit)
+This replaces the reference's pickle-based variable-size gather (src/utils/misc.py:90-130), which its
+inference path never calls.  Messages are <= a few MB per scene: latency-bound, one collective each.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+MAX_DETS = 30   # processor.py:318-319
+DET_COLS = 15   # the 64 shape-code columns are constant -1 with no_code=True (processor.py:286-287)
+
+
+def world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def frame_shard(n_frames, rank, world_size):
+    """contiguous block of frame indices owned by `rank` (blocks differ by at most one frame)"""
+    base, rem = divmod(n_frames, world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def pack_detections(per_frame_rows):
+    """list (per local frame) of lists of 79-float rows -> (float32[F,30,15], int32[F]) truncated to 30 like
+    process_frame does"""
+    F = len(per_frame_rows)
+    blk = np.full((F, MAX_DETS, DET_COLS), -1.0, np.float32)
+    cnt = np.zeros(F, np.int32)
+    for f, rows in enumerate(per_frame_rows):
+        n = min(len(rows), MAX_DETS)
+        cnt[f] = n
+        if n:
+            blk[f, :n] = np.asarray(rows, np.float64)[:n, :DET_COLS]
+    return blk, cnt
+
+
+def unpack_detections(blk, cnt):
+    """inverse of pack_detections: list of [n,79] float64 arrays (code columns restored to -1)"""
+    out = []
+    for f in range(len(cnt)):
+        n = int(cnt[f])
+        rows = np.full((n, 79), -1.0)
+        rows[:, :DET_COLS] = blk[f, :n].astype(np.float64)
+        out.append(rows)
+    return out
+
+
+def allgather_detections(blk, cnt, n_frames, device=None):
+    """Collective #1.  Every rank passes its block for frame_shard(n_frames, rank, world); returns the
+    blocks of the whole scene in frame order on every rank."""
+    rank, ws = world()
+    if ws == 1:
+        return blk, cnt
+    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    per = -(-n_frames // ws)  # padded shard length so all_gather_into_tensor sees equal shapes
+    pb = torch.full((per, MAX_DETS, DET_COLS), -1.0, dtype=torch.float32, device=dev)
+    pc = torch.zeros(per, dtype=torch.int32, device=dev)
+    pb[:len(cnt)] = torch.from_numpy(blk).to(dev)
+    pc[:len(cnt)] = torch.from_numpy(cnt).to(dev)
+    gb = torch.empty((ws * per, MAX_DETS, DET_COLS), dtype=torch.float32, device=dev)
+    gc = torch.empty(ws * per, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(gb, pb)
+    dist.all_gather_into_tensor(gc, pc)
+    gb, gc = gb.cpu().numpy(), gc.cpu().numpy()
+    ob, oc = [], []
+    for r in range(ws):
+        s, e = frame_shard(n_frames, r, ws)
+        ob.append(gb[r * per: r * per + (e - s)])
+        oc.append(gc[r * per: r * per + (e - s)])
+    return np.concatenate(ob), np.concatenate(oc)
+
+
+def object_shard(view_counts, rank, world_size):
+    """objects sorted by view count (descending) dealt round-robin: the indices owned by `rank`"""
+    order = np.argsort(-np.asarray(view_counts), kind="stable")
+    return [int(i) for i in order[rank::world_size]]
+
+
+def allgather_rows(local, n_total, owner_lists, device=None):
+    """Collective #2.  `local` float32[n_local, ...] rows for owner_lists[rank] (same trailing shape on all
+    ranks) -> float32[n_total, ...] in object order on every rank."""
+    rank, ws = world()
+    local = np.ascontiguousarray(local, np.float32)
+    if ws == 1:
+        out = np.zeros((n_total,) + local.shape[1:], np.float32)
+        out[owner_lists[0]] = local
+        return out
+    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    per = max(len(o) for o in owner_lists)
+    pad = torch.zeros((per,) + local.shape[1:], dtype=torch.float32, device=dev)
+    if len(local):
+        pad[:len(local)] = torch.from_numpy(local).to(dev)
+    g = torch.empty((ws * per,) + local.shape[1:], dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(g, pad)
+    g = g.cpu().numpy()
+    out = np.zeros((n_total,) + local.shape[1:], np.float32)
+    for r in range(ws):
+        idx = owner_lists[r]
+        out[idx] = g[r * per: r * per + len(idx)]
+    return out
