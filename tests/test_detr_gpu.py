@@ -1,0 +1,213 @@
+"""gfx950 detector kernels and the full DETR forward (through the C ABI) against torch CPU references,
+the detector oracle and the reference-generated golden vectors."""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import REPO
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+
+pytestmark = pytest.mark.gpu
+K = np.array([[577.87, 0.0, 319.5], [0.0, 577.87, 239.5], [0.0, 0.0, 1.0]])
+KEYS = ("pred_logits", "pred_boxes", "pred_angle", "pred_offset", "pred_size", "pred_depth")
+DEV = "cuda:0"
+
+
+def _st():
+    return ctypes.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
+
+
+def _pack(w):
+    Cout, Cin, KH, KW = w.shape
+    CinP = (Cin + 3) // 4 * 4
+    wp = torch.zeros(Cout, KH, KW, CinP); wp[..., :Cin] = w.permute(0, 2, 3, 1)
+    Kk = KH * KW * CinP; Kpad = (Kk + 31) // 32 * 32
+    out = torch.zeros(Cout, Kpad); out[:, :Kk] = wp.reshape(Cout, Kk)
+    return out, CinP, Kpad
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p,relu,res", [
+    (2, 37, 45, 64, 64, 1, 1, 0, True, False),      # layer1 1x1, N = 64 tile
+    (1, 40, 53, 64, 64, 3, 1, 1, True, False),      # 3x3 stride 1, ragged M
+    (2, 33, 41, 128, 128, 3, 2, 1, True, False),    # 3x3 stride 2, odd sizes (layer2.0)
+    (1, 80, 106, 3, 64, 7, 2, 3, True, False),      # stem 7x7/2, Cin 3 -> 4, K 196 -> 224
+    (2, 25, 34, 256, 1024, 1, 1, 0, True, True),    # expand + residual + relu
+    (2, 50, 67, 512, 1024, 1, 2, 0, False, False),  # strided 1x1 downsample
+    (1, 1, 300, 256, 19, 1, 1, 0, False, False),    # class head: N = 19
+    (3, 25, 34, 2048, 256, 1, 1, 0, False, False),  # input_proj, K = 2048
+    (1, 1, 1, 256, 1, 1, 1, 0, False, False),       # depth head on one token
+])
+def test_conv_gemm_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
+    from odam_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(B * 1000 + H + Cin + Cout)
+    x = torch.randn(B, Cin, H, W); w = torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5
+    sc = torch.rand(Cout) + 0.5; bi = torch.randn(Cout)
+    y = F.conv2d(x, w, None, s, p) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)
+    r = torch.randn_like(y) if res else None
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    wp, CinP, Kpad = _pack(w)
+    xh = torch.zeros(B, H, W, CinP); xh[..., :Cin] = x.permute(0, 2, 3, 1)
+    dx, dw, dsc, dbi = xh.to(DEV), wp.to(DEV), sc.to(DEV), bi.to(DEV)
+    dr = r.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None
+    dy = torch.empty(B, y.shape[2], y.shape[3], Cout, device=DEV)
+    _lib.check(L.odam_op_conv2d_nhwc(_lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dbi), _lib.ptr(dr), _lib.ptr(dy),
+                                     B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), _st()), "conv")
+    got = dy.cpu().permute(0, 3, 1, 2)
+    assert (got - y).abs().max().item() <= 3e-6 * max(y.abs().max().item(), 1.0)   # fp32, different sum order
+
+
+@pytest.mark.parametrize("B,Lq,Lk", [(2, 850, 850), (3, 100, 100), (2, 100, 850), (1, 33, 70), (1, 1, 1)])
+def test_attention_vs_torch(B, Lq, Lk):
+    from odam_amd import _lib
+    torch.manual_seed(Lq + Lk)
+    q = torch.randn(B, Lq, 256); k = torch.randn(B, Lk, 256); v = torch.randn(B, Lk, 256)
+    qh = q.view(B, Lq, 8, 32).transpose(1, 2) * (1.0 / 32) ** 0.5
+    kh = k.view(B, Lk, 8, 32).transpose(1, 2); vh = v.view(B, Lk, 8, 32).transpose(1, 2)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2), -1) @ vh).transpose(1, 2).reshape(B, Lq, 256)
+    dq, dk, dv = q.to(DEV), k.to(DEV), v.to(DEV)
+    do = torch.empty(B, Lq, 256, device=DEV)
+    _lib.check(_lib.lib().odam_op_attention(_lib.ptr(dq), 256, _lib.ptr(dk), 256, _lib.ptr(dv), 256, _lib.ptr(do), 256,
+                                            B, 8, Lq, Lk, _st()), "attention")
+    assert (do.cpu() - ref).abs().max().item() <= 5e-6
+
+
+def test_layernorm_and_maxpool_vs_torch():
+    from odam_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(0)
+    x = torch.randn(777, 256); r = torch.randn(777, 256); g = torch.rand(256) + 0.5; b = torch.randn(256)
+    ref = F.layer_norm(x + r, (256,), g, b, 1e-5)
+    dx, dr, dg, db = x.to(DEV), r.to(DEV), g.to(DEV), b.to(DEV)
+    dy = torch.empty(777, 256, device=DEV)
+    _lib.check(L.odam_op_add_layernorm(_lib.ptr(dx), _lib.ptr(dr), _lib.ptr(dg), _lib.ptr(db), _lib.ptr(dy), 777, _st()), "ln")
+    assert (dy.cpu() - ref).abs().max().item() <= 5e-6
+    x = torch.randn(2, 64, 41, 53)
+    ref = F.max_pool2d(x, 3, 2, 1)
+    dx = x.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dy = torch.empty(2, ref.shape[2], ref.shape[3], 64, device=DEV)
+    _lib.check(L.odam_op_maxpool3x3s2_nhwc(_lib.ptr(dx), _lib.ptr(dy), 2, 41, 53, 64, _st()), "pool")
+    assert torch.equal(dy.cpu().permute(0, 3, 1, 2), ref)
+
+
+@pytest.fixture(scope="module")
+def model():
+    from odam_amd import detector, weights
+    sd = weights.make_state_dict(seed=0)
+    det = detector.Detector(max_batch=4, device=DEV)
+    det.load_state_dict(sd)
+    yield det, sd
+    det.close()
+
+
+def test_forward_vs_reference_golden(model, golden):
+    """the reference's own DETR output (imported in the build container) at 2 x 3x256x320"""
+    det, _ = model
+    z = golden("detr_small.npz")
+    torch.manual_seed(int(z["img_seed"]))
+    img = torch.randn(2, 3, 256, 320)
+    out = det(img.to(DEV))
+    for k in KEYS:
+        assert np.abs(out[k].cpu().numpy() - z[k]).max() <= 1e-4, k
+    assert np.array_equal(out["pred_logits"].argmax(-1).cpu().numpy(), z["pred_logits"].argmax(-1))   # class labels: exact
+    post = det.postprocess(out, (640, 480), 0.6, K)
+    for b in range(2):
+        assert np.array_equal(post["classes"][b], z[f"post{b}_classes"])
+        for k in ("bboxes", "dimensions", "angles", "translates", "scores"):
+            assert np.allclose(post[k][b], z[f"post{b}_{k}"], rtol=1e-4, atol=1e-3), (b, k)
+
+
+def test_full_size_forward_vs_oracle(model):
+    """BASELINE config size (800x1066 from a 640x480 frame): taps + outputs + discrete decisions vs the oracle"""
+    import detr_oracle as O
+    det, sd = model
+    torch.manual_seed(7)
+    img = torch.randn(2, 3, 800, 1066)
+    ref = O.detr_forward(sd, img, return_taps=True)
+    out = det(img.to(DEV))
+    l4, mem = det.debug_taps(2, 800, 1066)
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    assert rel(l4.cpu(), ref["_layer4"]) <= 2e-5        # 53 stacked fp32 convolutions
+    assert rel(mem.cpu(), ref["_memory"]) <= 2e-5
+    for k in KEYS + ("pred_obj_features",):
+        assert (out[k].cpu() - ref[k]).abs().max().item() <= 2e-4, k
+    pc = out["pred_logits"].cpu().softmax(-1)[..., :-1]; pr = ref["pred_logits"].softmax(-1)[..., :-1]
+    assert torch.equal(pc.argmax(-1), pr.argmax(-1))
+    assert torch.equal(pc.max(-1).values > 0.6, pr.max(-1).values > 0.6)
+    pp = det.postprocess(out, (640, 480), 0.6, K); pref = O.postprocess(ref, (640, 480), 0.6, K)
+    for b in range(2):
+        assert np.array_equal(pp["classes"][b], pref["classes"][b])
+        assert np.allclose(pp["translates"][b], pref["translates"][b], rtol=1e-4, atol=1e-4)
+
+
+def test_batch_size_does_not_change_results(model):
+    det, _ = model
+    torch.manual_seed(9)
+    img = torch.randn(4, 3, 256, 320, device=DEV)
+    a = det(img)
+    b = [det(img[i:i + 1]) for i in range(4)]
+    for k in KEYS:
+        assert torch.allclose(a[k], torch.cat([x[k] for x in b]), rtol=0, atol=2e-6), k
+
+
+def test_postprocess_rows_vs_reference_golden(model, golden):
+    det, _ = model
+    z = golden("detr_post.npz")
+    out = {k: torch.from_numpy(z[k]).to(DEV) for k in KEYS}
+    out["_hw"] = (256, 320)
+    det(torch.zeros(1, 3, 256, 320, device=DEV))  # make sure the handle for this size exists
+    post = det.postprocess(out, (640, 480), 0.6, K)
+    for b in range(4):
+        assert np.array_equal(post["classes"][b], z[f"post{b}_classes"])
+        for k in ("bboxes", "dimensions", "angles", "translates", "scores"):
+            assert np.allclose(post[k][b], z[f"post{b}_{k}"], rtol=1e-5, atol=2e-4), (b, k)
+
+
+def test_run_detector_rows_vs_reference_golden(model, golden):
+    from odam_amd import synth, transforms
+    from odam_amd.processor import OdamProcess
+    det, _ = model
+    ref = golden("detr_small.npz")["run_detector_rows"]
+    proc = OdamProcess(det, None, transforms.get_transforms(), None)
+    proc.init_sequence(K, 968, 1296)
+    from PIL import Image
+    rows = np.asarray(proc.run_detector(Image.fromarray(next(synth.make_frames(1, seed=5))), 7, np.eye(4))).reshape(-1, 79)
+    assert rows.shape == ref.shape
+    assert np.array_equal(rows[:, :2], ref[:, :2])
+    assert np.allclose(rows, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_resnet101_configuration_vs_oracle():
+    """BASELINE config 4 backbone (R101) at a reduced input"""
+    import detr_oracle as O
+    from odam_amd import detector, weights
+    sd = weights.make_state_dict(backbone="resnet101", seed=1)
+    det = detector.Detector(backbone="resnet101", max_batch=2, device=DEV)
+    det.load_state_dict(sd)
+    torch.manual_seed(3)
+    img = torch.randn(2, 3, 192, 256)
+    ref = O.detr_forward(sd, img, blocks=(3, 4, 23, 3))
+    out = det(img.to(DEV))
+    for k in KEYS:
+        assert (out[k].cpu() - ref[k]).abs().max().item() <= 3e-4, k
+    assert torch.equal(out["pred_logits"].cpu().argmax(-1), ref["pred_logits"].argmax(-1))
+    det.close()
+
+
+def test_missing_weight_is_an_error():
+    from odam_amd import detector, weights, _lib
+    sd = weights.make_state_dict(seed=0)
+    del sd["transformer.decoder.norm.weight"]
+    det = detector.Detector(max_batch=1, device=DEV)
+    det.load_state_dict(sd)
+    with pytest.raises(_lib.OdamError, match="transformer.decoder.norm.weight"):
+        det(torch.zeros(1, 3, 64, 64, device=DEV))

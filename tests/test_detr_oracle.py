@@ -1,0 +1,103 @@
+"""Detector oracle (oracle/detr_oracle.py) and the product's host-side detector code against vectors produced
+by the reference's own DETR / postprocess / run_detector (tests/golden/make_golden_detr.py).  CPU only."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import REPO
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+import detr_oracle as O  # noqa: E402
+
+K = np.array([[577.87, 0.0, 319.5], [0.0, 577.87, 239.5], [0.0, 0.0, 1.0]])
+KEYS = ("pred_logits", "pred_boxes", "pred_angle", "pred_offset", "pred_size", "pred_depth")
+POST = ("bboxes", "dimensions", "angles", "translates", "classes", "scores")
+
+
+@pytest.fixture(scope="module")
+def sd():
+    from odam_amd import weights
+    return weights.make_state_dict(seed=0)
+
+
+def test_forward_matches_reference_detr(sd, golden):
+    z = golden("detr_small.npz")
+    torch.manual_seed(int(z["img_seed"]))
+    img = torch.randn(2, 3, 256, 320)
+    out = O.detr_forward(sd, img)
+    for k in KEYS:
+        assert np.abs(out[k].numpy() - z[k]).max() <= 2e-5, k
+    assert np.array_equal(out["pred_logits"].argmax(-1).numpy(), z["pred_logits"].argmax(-1))
+    post = O.postprocess(out, (640, 480), 0.6, K)
+    for b in range(2):
+        assert np.array_equal(post["classes"][b], z[f"post{b}_classes"])
+        for k in POST:
+            assert np.allclose(post[k][b], z[f"post{b}_{k}"], rtol=1e-5, atol=1e-4), (b, k)
+
+
+def test_position_embedding_bit_exact(golden):
+    from odam_amd.detector import sine_position_embedding
+    ref = golden("detr_small.npz")["pos_25x34"]                      # [1,256,25,34]
+    assert np.array_equal(O.position_embedding(25, 34).numpy(), ref)
+    mine = sine_position_embedding(25, 34).numpy().reshape(25, 34, 256).transpose(2, 0, 1)[None]
+    assert np.array_equal(mine, ref)
+
+
+def _rows16(pred, img_w, img_h):
+    """numpy float32 restatement of the per-query arithmetic (what odam_detr_postprocess computes on device)"""
+    f32 = np.float32
+    lg = torch.from_numpy(pred["pred_logits"]).softmax(-1)[..., :-1]
+    score, cls = lg.max(-1)
+    bx = pred["pred_boxes"]
+    x0 = (bx[..., 0] - f32(0.5) * bx[..., 2]) * f32(img_w); y0 = (bx[..., 1] - f32(0.5) * bx[..., 3]) * f32(img_h)
+    x1 = (bx[..., 0] + f32(0.5) * bx[..., 2]) * f32(img_w); y1 = (bx[..., 1] + f32(0.5) * bx[..., 3]) * f32(img_h)
+    d = pred["pred_depth"][..., 0]
+    scx = pred["pred_offset"][..., 0] * f32(img_w) + (x0 + x1) / f32(2); scy = pred["pred_offset"][..., 1] * f32(img_h) + (y0 + y1) / f32(2)
+    c3x = (scx - f32(K[0, 2])) / f32(K[0, 0]) * d; c3y = (scy - f32(K[1, 2])) / f32(K[1, 1]) * d
+    rows = np.zeros(bx.shape[:2] + (16,), np.float32)
+    rows[..., 0] = score.numpy(); rows[..., 1] = cls.numpy()
+    rows[..., 2], rows[..., 3], rows[..., 4], rows[..., 5] = x0, y0, x1, y1
+    rows[..., 6], rows[..., 7], rows[..., 8] = c3x, c3y, d
+    rows[..., 9] = pred["pred_angle"].argmax(-1)
+    rows[..., 10:13] = pred["pred_size"]
+    return rows
+
+
+def test_select_nms_matches_reference_postprocess(golden):
+    """odam_detr_select (C++ threshold + greedy 3D/2D NMS) against DETR.postprocess/nms_3d of the reference on
+    hand-built predictions with near-threshold scores and heavy overlaps."""
+    from odam_amd.detector import Detector
+    z = golden("detr_post.npz")
+    pred = {k: z[k] for k in KEYS}
+    rows = _rows16(pred, 640, 480)
+    for b in range(rows.shape[0]):
+        s = Detector.select(rows[b], 0.6, True, 30)
+        assert len(s["scores"]) == len(z[f"post{b}_scores"]) > 5
+        assert np.array_equal(s["classes"], z[f"post{b}_classes"])
+        for k in POST:
+            assert np.allclose(s[k], z[f"post{b}_{k}"], rtol=1e-6, atol=1e-4), (b, k)
+    # the oracle's python NMS agrees as well
+    post = O.postprocess({k: torch.from_numpy(v) for k, v in pred.items()}, (640, 480), 0.6, K)
+    for b in range(rows.shape[0]):
+        assert np.array_equal(post["classes"][b], z[f"post{b}_classes"])
+        assert np.allclose(post["scores"][b], z[f"post{b}_scores"], rtol=1e-6)
+
+
+def test_run_detector_rows_match_reference(sd, golden):
+    """processor.detection_rows packing (79 columns) on the oracle's predictions for the frame the reference's
+    OdamProcess.run_detector saw (same transforms object)."""
+    from odam_amd import synth, transforms
+    from odam_amd.processor import detection_rows
+    ref = golden("detr_small.npz")["run_detector_rows"]
+    frame = next(synth.make_frames(1, seed=5))
+    x, _ = transforms.get_transforms()(frame, None)
+    out = O.detr_forward(sd, x[None])
+    post = O.postprocess(out, (640, 480), 0.6, K)
+    rows = np.asarray(detection_rows(post, 0, 7, 1296, 968), np.float64).reshape(-1, 79)
+    assert rows.shape == ref.shape and rows.shape[0] >= 1
+    assert np.array_equal(rows[:, :2], ref[:, :2])                       # frame id, class label: exact
+    assert np.allclose(rows, ref, rtol=1e-4, atol=1e-5)
+    assert np.all(rows[:, 15:] == -1)

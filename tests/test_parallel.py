@@ -1,0 +1,69 @@
+"""Sharding + collectives of the multi-GPU path, world_size 2 on the gloo backend (CPU)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def test_shards_cover_everything():
+    from odam_amd import parallel
+    for n, ws in [(1000, 8), (7, 3), (5, 8), (0, 2)]:
+        spans = [parallel.frame_shard(n, r, ws) for r in range(ws)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(ws - 1))
+        assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+    counts = [300, 10, 250, 12, 11, 100, 40]
+    owners = [parallel.object_shard(counts, r, 3) for r in range(3)]
+    assert sorted(sum(owners, [])) == list(range(len(counts)))
+    assert owners[0][0] == 0 and owners[1][0] == 2          # the two largest go to different ranks
+
+
+def test_pack_unpack_roundtrip():
+    from odam_amd import parallel
+    rs = np.random.RandomState(0)
+    per = []
+    for n in (0, 3, 35):
+        rows = -np.ones((n, 79)); rows[:, :15] = rs.normal(size=(n, 15)).astype(np.float32)
+        per.append(rows.tolist())
+    blk, cnt = parallel.pack_detections(per)
+    assert cnt.tolist() == [0, 3, 30]                        # truncated to 30 like process_frame
+    back = parallel.unpack_detections(blk, cnt)
+    assert np.array_equal(back[1], np.asarray(per[1]))
+    assert np.array_equal(back[2], np.asarray(per[2])[:30])
+
+
+def _worker(rank, ws, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from odam_amd import parallel
+    n_frames = 11
+    full_rows = [[[float(f), float(k)] + [0.5 * f + k] * 13 + [-1.0] * 64 for k in range(f % 4)] for f in range(n_frames)]
+    s, e = parallel.frame_shard(n_frames, rank, ws)
+    blk, cnt = parallel.pack_detections(full_rows[s:e])
+    gb, gc = parallel.allgather_detections(blk, cnt, n_frames, "cpu")
+    ok1 = gc.tolist() == [f % 4 for f in range(n_frames)]
+    back = parallel.unpack_detections(gb, gc)
+    ok2 = all(np.array_equal(back[f], np.asarray(full_rows[f]).reshape(-1, 79)) for f in range(n_frames))
+    counts = [30, 5, 22, 9, 14]
+    owners = [parallel.object_shard(counts, r, ws) for r in range(ws)]
+    local = np.stack([np.full(9, 100.0 + i, np.float32) for i in owners[rank]]) if owners[rank] else np.zeros((0, 9), np.float32)
+    allp = parallel.allgather_rows(local, len(counts), owners, "cpu")
+    ok3 = np.array_equal(allp[:, 0], 100.0 + np.arange(len(counts)))
+    q.put((rank, ok1, ok2, ok3))
+    dist.destroy_process_group()
+
+
+def test_allgather_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
