@@ -18,7 +18,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     constexpr int B_LD = BN / 32;
     static_assert(WM * WN == 4, "4 wavefronts per workgroup");
 
-    extern __shared__ __align__(16) float smem[];
+    __shared__ __align__(16) float smem[2 * (BM + BN) * LDS_STRIDE];   // 36 / 54 / 72 KiB, static
     float* As = smem;                         // [2][BM][LDS_STRIDE]
     float* Bs = smem + 2 * BM * LDS_STRIDE;   // [2][BN][LDS_STRIDE]
 
@@ -131,7 +131,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     }
 
     // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
+    // Residual values of a whole 32x32 tile are fetched first (16 independent loads in flight per lane),
+    // then combined and stored: the loads must not queue one by one behind the stores.
     const int half = lane >> 5;
+    const float* __restrict__ resp = a.res;
+    float* __restrict__ outp = a.C;
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
@@ -140,15 +144,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         const float bi = (a.bias && n_ok) ? a.bias[n] : 0.0f;
 #pragma unroll
         for (int i = 0; i < TM; i++) {
+            const int mb = m0 + wm * (BM / WM) + i * 32 + 4 * half;
+            float rv[16];
 #pragma unroll
             for (int r = 0; r < 16; r++) {
-                const int m = m0 + wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (n_ok && m < a.M) {
-                    float v = acc[i][j][r] * sc + bi;
-                    if (a.res) v += a.res[(size_t)m * a.ldc + n];
-                    if (a.relu) v = v > 0.0f ? v : 0.0f;
-                    a.C[(size_t)m * a.ldc + n] = v;
-                }
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                rv[r] = (resp && n_ok && m < a.M) ? resp[(size_t)m * a.ldc + n] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * sc + bi;
+                v += rv[r];
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                if (n_ok && m < a.M) outp[(size_t)m * a.ldc + n] = v;
             }
         }
     }
@@ -156,15 +165,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
-    static bool attr_set = false;
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    if (!attr_set) {
-        ODAM_HIP(hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr_set = true;
-    }
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
