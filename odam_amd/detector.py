@@ -46,7 +46,9 @@ class Detector:
     position table depend on it), created lazily at the first call with that size."""
 
     def __init__(self, backbone="resnet50", hidden_dim=256, nheads=8, dim_feedforward=2048, enc_layers=6,
-                 dec_layers=6, num_queries=100, num_classes=18, angle_bins=30, max_batch=8, device="cuda:0"):
+                 dec_layers=6, num_queries=100, num_classes=18, angle_bins=30, max_batch=8, device="cuda:0",
+                 n_streams=2):
+        self.n_streams = max(1, int(n_streams))
         self.arch = dict(backbone=backbone, hidden_dim=hidden_dim, nheads=nheads, dim_feedforward=dim_feedforward,
                          enc_layers=enc_layers, dec_layers=dec_layers, num_queries=num_queries,
                          num_classes1=num_classes + 1, angle_bins=angle_bins)
@@ -77,6 +79,7 @@ class Detector:
         for h in self._handles.values():
             _lib.lib().odam_detr_destroy(h)
         self._handles = {}
+        self._streams = None
 
     def __del__(self):
         try:
@@ -84,8 +87,8 @@ class Detector:
         except Exception:
             pass
 
-    def _handle(self, H, W):
-        key = (H, W)
+    def _handle(self, H, W, idx=0):
+        key = (H, W, idx)
         if key in self._handles:
             return self._handles[key]
         if self._sd is None:
@@ -191,35 +194,77 @@ class Detector:
                     classes=r[:, 1].astype(np.int64), scores=r[:, 0].copy())
 
     def detect_resident(self, frames, img_size, intr_mat):
-        """Forward + per-query post-processing over frames already resident on the device
-        ([N,3,H,W] float32), max_batch at a time, everything enqueued back to back; one device->host copy of
-        the [N,Q,16] rows at the end.  Returns the rows as numpy."""
+        """Forward + per-query post-processing over frames already resident on the device ([N,3,H,W] float32):
+        all rows [N,Q,16] as one numpy array (see detect_resident_chunks for the streaming form)."""
+        out = np.empty((frames.shape[0], self.num_queries, 16), np.float32)
+        for c0, rows in self.detect_resident_chunks(frames, img_size, intr_mat, chunk=1 << 30):
+            out[c0:c0 + rows.shape[0]] = rows
+        return out
+
+    def detect_resident_chunks(self, frames, img_size, intr_mat, chunk=128):
+        """Forward + per-query post-processing over resident frames, where (1) batches alternate between `n_streams` HIP streams, each with its own
+        native handle/workspace, so the tile-quantisation tails, launch gaps and HBM-bound layers of one batch
+        are filled by kernels of another (frames are independent); (2) the rows come back in chunks while the
+        GPU keeps working: everything is enqueued first (forward + post-processing per batch, then per chunk an
+        asynchronous copy into pinned host memory + an event), and the generator yields
+        (first_frame, rows[n,Q,16]) as each chunk's event completes -- host-side thresholding / NMS of chunk i
+        overlaps the kernels of chunks i+1.. ."""
         N, _, H, W = frames.shape
-        h = self._handle(H, W)
         a = self.arch
         Q = a["num_queries"]
         dev = self.device
         L = _lib.lib()
-        rows = torch.empty(N, Q, 16, device=dev, dtype=torch.float32)
         mb = self.max_batch
-        if not hasattr(self, "_scratch") or self._scratch[0].shape[0] != mb:
+        ns = self.n_streams
+        handles = [self._handle(H, W, k) for k in range(ns)]
+        chunk = max(mb, (chunk // mb) * mb)
+        rows = torch.empty(N, Q, 16, device=dev, dtype=torch.float32)
+        if getattr(self, "_pinned", None) is None or self._pinned.shape[0] < N:
+            self._pinned = torch.empty(N, Q, 16, dtype=torch.float32, pin_memory=True)
+        host = self._pinned[:N]
+        if getattr(self, "_streams", None) is None or len(self._streams) != ns:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
             mk = lambda n: torch.empty(mb, Q, n, device=dev, dtype=torch.float32)
-            self._scratch = [mk(a["num_classes1"]), mk(4), mk(a["angle_bins"]), mk(2), mk(3), mk(1)]
-        lg, bx, an, of, sz, dp = self._scratch
+            self._mscratch = [[mk(a["num_classes1"]), mk(4), mk(a["angle_bins"]), mk(2), mk(3), mk(1)] for _ in range(ns)]
         K9 = np.ascontiguousarray(np.asarray(intr_mat, np.float64)[:3, :3], np.float32)
         img_w, img_h = img_size
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        main = torch.cuda.current_stream(dev)
+        start = torch.cuda.Event()
+        start.record(main)
+        for st in self._streams:
+            st.wait_event(start)          # inputs produced on the caller's stream are visible
+        events = []
+        nb = 0
         with torch.cuda.device(dev):
-            for b0 in range(0, N, mb):
-                B = min(mb, N - b0)
-                _lib.check(L.odam_detr_forward(h, _lib.ptr(frames[b0:b0 + B]), ctypes.c_int(B), _lib.ptr(lg), _lib.ptr(bx),
-                                               _lib.ptr(an), _lib.ptr(of), _lib.ptr(sz), _lib.ptr(dp), ctypes.c_void_p(0),
-                                               stream), "odam_detr_forward")
-                _lib.check(L.odam_detr_postprocess(h, _lib.ptr(lg), _lib.ptr(bx), _lib.ptr(an), _lib.ptr(of), _lib.ptr(sz),
-                                                   _lib.ptr(dp), ctypes.c_int(B), K9.ctypes.data_as(_lib.c_float_p),
-                                                   ctypes.c_float(img_w), ctypes.c_float(img_h), _lib.ptr(rows[b0:b0 + B]),
-                                                   stream), "odam_detr_postprocess")
-        return rows.cpu().numpy()
+            for c0 in range(0, N, chunk):
+                c1 = min(N, c0 + chunk)
+                used = set()
+                for b0 in range(c0, c1, mb):
+                    B = min(mb, c1 - b0)
+                    k = nb % ns
+                    nb += 1
+                    used.add(k)
+                    lg, bx, an, of, sz, dp = self._mscratch[k]
+                    sp = ctypes.c_void_p(self._streams[k].cuda_stream)
+                    _lib.check(L.odam_detr_forward(handles[k], _lib.ptr(frames[b0:b0 + B]), ctypes.c_int(B), _lib.ptr(lg),
+                                                   _lib.ptr(bx), _lib.ptr(an), _lib.ptr(of), _lib.ptr(sz), _lib.ptr(dp),
+                                                   ctypes.c_void_p(0), sp), "odam_detr_forward")
+                    _lib.check(L.odam_detr_postprocess(handles[k], _lib.ptr(lg), _lib.ptr(bx), _lib.ptr(an), _lib.ptr(of),
+                                                       _lib.ptr(sz), _lib.ptr(dp), ctypes.c_int(B),
+                                                       K9.ctypes.data_as(_lib.c_float_p), ctypes.c_float(img_w),
+                                                       ctypes.c_float(img_h), _lib.ptr(rows[b0:b0 + B]), sp),
+                               "odam_detr_postprocess")
+                for k in used:               # the chunk's copy waits for every stream that produced part of it
+                    e = torch.cuda.Event()
+                    e.record(self._streams[k])
+                    main.wait_event(e)
+                host[c0:c1].copy_(rows[c0:c1], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                events.append((c0, c1, ev))
+        for c0, c1, ev in events:
+            ev.synchronize()
+            yield c0, host[c0:c1].numpy()
 
     def profile(self, H, W, on):
         _lib.check(_lib.lib().odam_detr_profile_enable(self._handle(H, W), ctypes.c_int(int(on))), "profile_enable")

@@ -96,36 +96,43 @@ def _edge_lines(bbox, img_h, img_w, thr=EDGE_THRESHOLD):
     return out
 
 
-def _object_constraints(track, frame_to_img, img_h, img_w):
-    """Per observed frame of one track (in image order): image index, bbox-edge lines, T_wo, dims.
+def _object_constraints(track, frame_to_img, img_h, img_w, thr=EDGE_THRESHOLD):
+    """Per observed frame of one track, in image order, vectorised over the observations.
 
-    tracking_gt_utils.py:145-211 walks every image and tests membership; here the membership is
-    a dictionary lookup per observation (first row of a frame id wins, as np.where(...)[0][0] does).
+    tracking_gt_utils.py:145-211 walks every image, tests membership and builds per-frame dicts; here the
+    membership is one dictionary lookup per observation (first row of a frame id wins, as
+    np.where(...)[0][0] does) and the bbox-edge constraints go straight into arrays:
+      tgt[n,4], mask[n,4] in the order x_min, x_max, y_min, y_max (sq_libs.py:438): mask = edge farther
+      than `thr` px from the border (quadric_helper.py:87-107); tgt = float32(-float32(-pixel)), i.e. what
+      `-gt` is after sq_libs.py:448 stores the line's last entry in a float32 tensor.
+    Returns class, image ids [n], tgt, mask, rotation matrices [n,3,3], t_wo [3], dims [n,3].
     """
     frames = track[:, 0].astype(np.int32)
     first_row = {}
     for r, fid in enumerate(frames.tolist()):
         first_row.setdefault(fid, r)
     obs = sorted((img_id, r) for fid, r in first_row.items() for img_id in frame_to_img.get(fid, ()))
+    img_ids = np.array([o[0] for o in obs], np.int64)
+    rows = np.array([o[1] for o in obs], np.int64)
     obj_class = int(np.median(track[:, 1]))
     t_wo = np.mean(track[:, 9:12], axis=0)
-    img_ids, lines, T_wos, dims = [], [], [], []
-    for img_id, r in obs:
-        T = np.eye(4)
-        T[:3, :3] = rotz(track[r, 12])
-        T[:3, 3] = t_wo
-        T_wos.append(T)
-        dims.append(track[r, 6:9])
-        lines.append(_edge_lines(track[r, 2:6].reshape(2, 2), img_h, img_w))
-        img_ids.append(img_id)
-    return obj_class, img_ids, lines, T_wos, dims
+    sub = track[rows]
+    c, s_ = np.cos(sub[:, 12]), np.sin(sub[:, 12])          # box_utils.rotz per observation
+    R = np.zeros((len(rows), 3, 3))
+    R[:, 0, 0], R[:, 0, 1], R[:, 1, 0], R[:, 1, 1], R[:, 2, 2] = c, -s_, s_, c, 1.0
+    vals = sub[:, [2, 4, 3, 5]]                              # x_min, x_max, y_min, y_max
+    lims = np.array([img_w, img_w, img_h, img_h], np.float64)
+    mask = ((vals > thr) & (vals < lims - thr)).astype(np.float32)
+    tgt = np.where(mask > 0, (-((-vals).astype(np.float32))), np.float32(0)).astype(np.float32)
+    return obj_class, img_ids, tgt, mask, R, t_wo, sub[:, 6:9]
 
 
-def averaging_T_wos(T_wos):  # tracking_gt_utils.py:59-66
-    T_wos = np.asarray(T_wos)
+def averaging_T_wos(R_wos, t_wo):
+    """tracking_gt_utils.py:59-66 for T_wos that all carry the same translation (load_pred_object gives every
+    per-frame T_wo the track's mean t_wo, :148/:186-189): mean rotation by scipy, mean of n equal vectors."""
     out = np.eye(4)
-    out[:3, :3] = Rotation.from_matrix(T_wos[:, :3, :3]).mean().as_matrix()
-    out[:3, 3] = np.mean(T_wos[:, :3, 3], axis=0)
+    out[:3, :3] = Rotation.from_matrix(R_wos).mean().as_matrix()
+    out[:3, 3] = np.mean(np.repeat(t_wo[None, :], len(R_wos), axis=0), axis=0)
     return out
 
 
@@ -178,9 +185,9 @@ def optim_process(tracks, img_names, T_wcs, P_cws, img_h, img_w, K, representati
     inits, classes, bboxes_dl, fit_ids = [], [], [], []
     fit_P, fit_tgt, fit_mask, fit_counts = [], [], [], []
     for obj_id in range(n_objs):
-        obj_class, img_ids, lines, T_wos, dims = _object_constraints(np.asarray(tracks[obj_id]), frame_to_img,
-                                                                     img_h, img_w)
-        T_wo = averaging_T_wos(T_wos)
+        obj_class, img_ids, tgt, mask, R_wos, t_wo, dims = _object_constraints(np.asarray(tracks[obj_id]),
+                                                                             frame_to_img, img_h, img_w)
+        T_wo = averaging_T_wos(R_wos, t_wo)
         scales = np.mean(np.asarray(dims), axis=0)
         bboxes_dl.append(get_3d_box(scales, T_wo[:3, :3], T_wo[:3, 3]))
         yaw = Rotation.from_matrix(T_wo[:3, :3]).as_euler("zxy")[0]
@@ -188,14 +195,13 @@ def optim_process(tracks, img_names, T_wcs, P_cws, img_h, img_w, K, representati
             raise KeyError(obj_class)  # sq_libs.py:464 (CLASS_MAPPER covers classes 0..7 only)
         inits.append(_sq.init_params(T_wo[:3, 3], yaw, scales, representation))
         classes.append(obj_class)
-        valid = [(i, l) for i, l in zip(img_ids, lines) if len(l) > 0]
-        if len(valid) >= n_views:
-            tgt, mask = _sq.lines_to_targets([l for _, l in valid])
+        valid = mask.any(axis=1)       # frames with at least one constrained edge (run_multi_view.py:51-54)
+        if int(valid.sum()) >= n_views:
             fit_ids.append(obj_id)
-            fit_P.append(P_all[[i for i, _ in valid]].astype(np.float32).reshape(-1, 12))
-            fit_tgt.append(tgt)
-            fit_mask.append(mask)
-            fit_counts.append(len(valid))
+            fit_P.append(P_all[img_ids[valid]].astype(np.float32).reshape(-1, 12))
+            fit_tgt.append(tgt[valid])
+            fit_mask.append(mask[valid])
+            fit_counts.append(int(valid.sum()))
 
     params = {i: inits[i] for i in range(n_objs)}
     points = {}

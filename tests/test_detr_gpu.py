@@ -211,3 +211,20 @@ def test_missing_weight_is_an_error():
     det.load_state_dict(sd)
     with pytest.raises(_lib.OdamError, match="transformer.decoder.norm.weight"):
         det(torch.zeros(1, 3, 64, 64, device=DEV))
+
+
+def test_streamed_detection_equals_plain_forward(model):
+    """multi-stream, chunked detect_resident_chunks returns the same rows as forward + postprocess_rows"""
+    det, _ = model
+    torch.manual_seed(11)
+    frames = torch.randn(10, 3, 256, 320, device=DEV)
+    plain = det.postprocess_rows(det(frames), (640, 480), K)
+    got = np.zeros_like(plain)
+    seen = []
+    for c0, rows in det.detect_resident_chunks(frames, (640, 480), K, chunk=4):
+        got[c0:c0 + rows.shape[0]] = rows
+        seen.append((c0, rows.shape[0]))
+    assert sum(n for _, n in seen) == 10 and [c for c, _ in seen] == sorted(c for c, _ in seen)
+    assert np.allclose(got, plain, rtol=0, atol=2e-6)
+    assert np.array_equal(got[..., 1], plain[..., 1])          # class labels
+    assert np.allclose(det.detect_resident(frames, (640, 480), K), plain, rtol=0, atol=2e-6)
