@@ -53,18 +53,26 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per forward; 0 = by shard size")
     ap.add_argument("--streams", type=int, default=0, help="concurrent HIP streams; 0 = by shard size")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo + "
+                    "--one-device let several ranks share one GPU for a functional check of the N > 1 path")
+    ap.add_argument("--one-device", action="store_true")
     args = ap.parse_args()
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.one_device:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
     if ws > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=ws)
     device = f"cuda:{local_rank}"
-    torch.cuda.set_device(local_rank)
 
+    coll_dev = device if args.backend == "nccl" else "cpu"
     N = args.frames
     f0, f1 = parallel.frame_shard(N, rank, ws)
     K = synth.K_SCANNET
@@ -102,7 +110,7 @@ def main():
         e1.record()          # after the last chunk's copy on the issuing stream: end of the detection phase
         det_ms.append((e0, e1))
         blk, cnt = parallel.pack_detections(per_frame)
-        blk, cnt = parallel.allgather_detections(blk, cnt, N, device)
+        blk, cnt = parallel.allgather_detections(blk, cnt, N, coll_dev)
         n_det = int(cnt.sum())
         fitted = None
         for _ in range(2):  # optim -> (merge) -> optim
@@ -112,7 +120,7 @@ def main():
             local = np.concatenate([out["params"].reshape(len(mine), 9),
                                     np.asarray(out["bboxes_qc"], np.float32).reshape(len(mine), 24)], 1) \
                 if mine else np.zeros((0, 33), np.float32)
-            fitted = parallel.allgather_rows(local, len(tracks), owners, device)
+            fitted = parallel.allgather_rows(local, len(tracks), owners, coll_dev)
         return n_det, fitted
 
     def sync():
@@ -139,7 +147,7 @@ def main():
     n_launch, conv_ms, conv_flops = detector.profile_read(H, W)
     detector.profile(H, W, False)
     if ws > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
 

@@ -131,11 +131,59 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     }
 
     // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
-    // Residual values of a whole 32x32 tile are fetched first (16 independent loads in flight per lane),
-    // then combined and stored: the loads must not queue one by one behind the stores.
     const int half = lane >> 5;
     const float* __restrict__ resp = a.res;
     float* __restrict__ outp = a.C;
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;   // this wave's sub-tile
+    if ((a.Cout & 3) == 0 && (a.ldc & 3) == 0) {
+        // Wide path: the accumulator layout (one column per lane) would give 4-byte accesses; the sub-tile is
+        // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
+        // 16-byte residual loads and 16-byte stores, 256 contiguous bytes per 16 lanes.
+        constexpr int EP_LD = WCOLS + 4;
+        static_assert(4 * WROWS * EP_LD <= 2 * (BM + BN) * LDS_STRIDE, "epilogue staging fits the tile buffers");
+        float* Ep = smem + wave * (WROWS * EP_LD);
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    Ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+        __syncthreads();
+        constexpr int LPR = WCOLS / 4;          // lanes per row
+        constexpr int RPI = 64 / LPR;           // rows per wave-instruction
+        const int c4 = (lane % LPR) * 4;
+        const int n = n0 + wn * WCOLS + c4;
+        const bool n_ok = n < a.Cout;           // Cout % 4 == 0: the four channels are in or out together
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+        if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
+        constexpr int NIT = WROWS / RPI;
+        float4 rv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int m = m0 + wm * WROWS + it * RPI + lane / LPR;
+            rv[it] = (resp && n_ok && m < a.M) ? *reinterpret_cast<const float4*>(resp + (size_t)m * a.ldc + n)
+                                               : float4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int row = it * RPI + lane / LPR;
+            const int m = m0 + wm * WROWS + row;
+            const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4]);
+            float4 o;
+            o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
+            o.x += rv[it].x; o.y += rv[it].y; o.z += rv[it].z; o.w += rv[it].w;
+            if (a.relu) {
+                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            }
+            if (n_ok && m < a.M) *reinterpret_cast<float4*>(outp + (size_t)m * a.ldc + n) = o;
+        }
+        return;
+    }
+    // Narrow path (channel counts that are not a multiple of 4: the prediction heads): residual values of a
+    // whole 32x32 tile are fetched first, then combined and stored.
 #pragma unroll
     for (int j = 0; j < TN; j++) {
         const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);

@@ -1,0 +1,46 @@
+"""per-layer TFLOP/s of conv_gemm launches from a rocprofv3 kernel trace of tests/native/prof_detr.py"""
+import csv, sys
+path, B = sys.argv[1], int(sys.argv[2])
+nrep = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+rows = [r for r in csv.DictReader(open(path)) if "conv_gemm" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+n = len(rows) // nrep
+convs = rows[(nrep - 1) * n:]
+def co(n, k, s, p): return (n + 2 * p - k) // s + 1
+H, W = 800, 1066
+seq = []
+H1, W1 = co(H, 7, 2, 3), co(W, 7, 2, 3); seq.append(("stem7x7", B * H1 * W1, 64, 147))
+h, w = co(H1, 3, 2, 1), co(W1, 3, 2, 1); inpl = 64
+for l, nb in enumerate((3, 4, 6, 3)):
+    pl = 64 * 2 ** l
+    for i in range(nb):
+        s = 2 if (i == 0 and l > 0) else 1
+        ho, wo = co(h, 3, s, 1), co(w, 3, s, 1)
+        seq.append((f"l{l+1}.{i}.c1", B * h * w, pl, inpl)); seq.append((f"l{l+1}.{i}.c2", B * ho * wo, pl, pl * 9))
+        if i == 0: seq.append((f"l{l+1}.{i}.ds", B * ho * wo, pl * 4, inpl))
+        seq.append((f"l{l+1}.{i}.c3", B * ho * wo, pl * 4, pl)); inpl = pl * 4; h, w = ho, wo
+M = B * h * w; Mq = B * 100
+seq.append(("input_proj", M, 256, 2048))
+for i in range(6):
+    seq += [(f"enc{i}.qk", M, 512, 256), (f"enc{i}.v", M, 256, 256), (f"enc{i}.out", M, 256, 256), (f"enc{i}.l1", M, 2048, 256), (f"enc{i}.l2", M, 256, 2048)]
+seq += [("cross_k", M, 1536, 256), ("cross_v", M, 1536, 256)]
+for i in range(6):
+    seq += [(f"dec{i}.qk", Mq, 512, 256), (f"dec{i}.v", Mq, 256, 256), (f"dec{i}.out", Mq, 256, 256), (f"dec{i}.cq", Mq, 256, 256), (f"dec{i}.cout", Mq, 256, 256), (f"dec{i}.l1", Mq, 2048, 256), (f"dec{i}.l2", Mq, 256, 2048)]
+seq.append(("cls", Mq, 19, 256))
+for nm, no in (("bbox", 4), ("off", 2), ("ang", 30), ("size", 3), ("depth", 1)):
+    seq += [(nm + "0", Mq, 256, 256), (nm + "1", Mq, 256, 256), (nm + "2", Mq, no, 256)]
+assert len(convs) == len(seq), (len(convs), len(seq))
+agg = {}
+for r, (name, m, nn, k) in zip(convs, seq):
+    us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    fl = 2.0 * m * nn * k
+    cfg = r["Kernel_Name"].split("<")[1].split(">")[0]
+    grp = name.split(".")[0] if name[0] == "l" and name[1].isdigit() else ("enc" if name.startswith("enc") else "dec" if name.startswith("dec") else name if name in ("stem7x7", "input_proj") else "cross" if name.startswith("cross") else "heads")
+    a = agg.setdefault(grp, [0, 0]); a[0] += us; a[1] += fl
+    if name.startswith(("stem", "l1.0", "l1.1", "l2.0", "l2.1", "l3.0", "l3.1", "l4.0", "l4.1", "input", "enc0", "cross", "dec0")):
+        print(f"{name:12s} M={m:8d} N={nn:5d} K={k:5d} cfg={cfg:14s} wgs={int(r['Grid_Size_X'])//256:6d} {us:8.1f} us  {fl/us/1e6:6.1f} TF")
+print()
+tu = tf = 0
+for g, (us, fl) in agg.items():
+    print(f"{g:12s} {us/1e3:7.2f} ms {fl/1e9:8.1f} GF  {fl/us/1e6:6.1f} TF"); tu += us; tf += fl
+print(f"{'total':12s} {tu/1e3:7.2f} ms {tf/1e9:8.1f} GF  {tf/tu/1e6:6.1f} TF")
