@@ -1,6 +1,6 @@
 // sq_fit.hip -- persistent per-object super-quadric multi-view fit for gfx950 (MI355X).
 //
-// One 512-thread workgroup (8 wavefronts of 64) owns one object for all Adam steps; parameters,
+// One 1024-thread workgroup (16 wavefronts of 64) owns one object for all Adam steps; parameters,
 // Adam moments, the 1000 surface points, the sampler's theta buffers / CDF and the per-view
 // gradient rows live in LDS for the whole fit, so HBM sees only the view constraints
 // (48 + 32 bytes per view) streamed once per step through L2 and one 36-byte result per object.
@@ -40,7 +40,10 @@
 namespace {
 using namespace odam_sq;
 
-constexpr int NT = 512;         // threads per workgroup (8 wavefronts, 2 per SIMD -> 256 VGPRs each)
+#ifndef ODAM_SQ_NT
+#define ODAM_SQ_NT 1024
+#endif
+constexpr int NT = ODAM_SQ_NT;  // threads per workgroup
 constexpr int NW = NT / 64;     // wavefronts per workgroup
 constexpr int BUFP = 208;       // padded theta-buffer length
 constexpr int QCAP = 200;       // pending arcs per curve per level (sum of n over a level <= 199)
@@ -171,10 +174,16 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
     int Pn = 1;
     while (Pn < F) Pn <<= 1;
     const float invF = 1.0f / (float)F;
-    int chunk = (F + NW - 1) / NW;
-    if (chunk > 16) chunk = 16;
-    if (chunk < 1) chunk = 1;
-    const int nchunks = (F + chunk - 1) / chunk;
+    // lanes per view in phase E: the power of two that minimises rounds x (points per lane + per-round overhead)
+    int S = 1;
+    {
+        int best_cost = 0x7fffffff;
+        for (int c = 1; c <= 64; c <<= 1) {
+            const int rounds = (F * c + NT - 1) / NT;
+            const int cost = rounds * ((N_PTS + c - 1) / c + 24);
+            if (cost < best_cost) { best_cost = cost; S = c; }
+        }
+    }
 
     for (int it = 0; it <= A.n_iters; ++it) {
         // ---------------- A: shape scalars ------------------------------------------------------
@@ -187,7 +196,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             L.shape[tid] = sg * 1.4f + 0.2f;                                      // e   -> [5], [6]
         }
         __syncthreads();
-        const Shape S = load_shape(L.shape);
+        const Shape S_ = load_shape(L.shape);
         float p[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) p[k] = L.p[k];
@@ -198,7 +207,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             const int j = tid >> 6;  // lanes 0 of waves 0..3 evaluate the four end points
             if (lane == 0 && j < 4) {
                 const int c = j >> 1, end = j & 1;
-                const float a1 = S.a[0], a2 = c ? S.a[1] : S.a[2], e = S.e[c];
+                const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
                 const float ta = c ? PI_F : PI_F / 2;
                 const float th = end ? -ta : ta;
                 float cx, cy;
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                 const int c = w >> 8, i = w & 255;
                 if (i >= (c ? n1 : n0)) continue;
                 const Arc nd = L.q[(c * 2 + (lvl & 1)) * QCAP + i];
-                const float a1 = S.a[0], a2 = c ? S.a[1] : S.a[2], e = S.e[c];
+                const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
                 Arc lf, rt;
                 float th;
                 const int slot = arc_step(nd, a1, a2, e, th, lf, rt);
@@ -242,11 +251,11 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             const int grp = w >> 8, k = w & 255;
             if (k >= BUF) continue;
             if (grp == 0) {
-                if (k >= 1) L.term[k] = (S.a[0] + S.a[1]) * fexp(cosf_(L.buf[k]), S.e[0]);
+                if (k >= 1) L.term[k] = (S_.a[0] + S_.a[1]) * fexp(cosf_(L.buf[k]), S_.e[0]);
             } else {
                 const int c = grp - 1;
                 float ct, st, fc, fs;
-                entry_factors(L.buf[c * BUFP + k], S.e[c], ct, st, fc, fs);
+                entry_factors(L.buf[c * BUFP + k], S_.e[c], ct, st, fc, fs);
                 L.fac[(4 * c + 0) * BUFP + k] = ct; L.fac[(4 * c + 1) * BUFP + k] = st;
                 L.fac[(4 * c + 2) * BUFP + k] = fc; L.fac[(4 * c + 3) * BUFP + k] = fs;
             }
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             }
             const int ke = lo, ko = A.omega_idx[i];
             float raw[3], po[3], pw[3];
-            surface_point(S, p, L.fac[2 * BUFP + ke], L.fac[3 * BUFP + ke], L.fac[6 * BUFP + ko],
+            surface_point(S_, p, L.fac[2 * BUFP + ke], L.fac[3 * BUFP + ke], L.fac[6 * BUFP + ko],
                           L.fac[7 * BUFP + ko], raw, po, pw);
             L.pwx[i] = pw[0]; L.pwy[i] = pw[1]; L.pwz[i] = pw[2];
             L.ie[i] = (unsigned short)ke;
@@ -294,35 +303,26 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         }
 
         // ---------------- E: projected extents + per-view gradient rows -----------------------
-        float px[PTS_PER_LANE], py[PTS_PER_LANE], pz[PTS_PER_LANE];
+        // A view is owned by S consecutive lanes (S = largest power of two <= NT / F, at most one wavefront):
+        // each walks every S-th surface point keeping its four running extremes (value, first index), an
+        // S-lane xor butterfly merges them, then the closed-form gradient of the view's four edges runs on
+        // those same lanes and is added in the order (d0 + d1) + (d2 + d3).
+        for (int v0 = 0; v0 < F; v0 += NT / S) {
+            const int f = v0 + tid / S;
+            const int sub = tid & (S - 1);
+            const bool vf = f < F;
+            float Mv[12];
 #pragma unroll
-        for (int j = 0; j < PTS_PER_LANE; j++) {
-            const int i = lane + 64 * j;
-            const bool ok = i < N_PTS;
-            px[j] = ok ? L.pwx[i] : 0.0f;
-            py[j] = ok ? L.pwy[i] : 0.0f;
-            pz[j] = ok ? L.pwz[i] : 0.0f;
-        }
-        for (int ch = wid; ch < nchunks; ch += NW) {
-            const int base = ch * chunk;
-            float my_ext = 0.0f;
-            int my_win = NONE;
-            for (int vi = 0; vi < chunk; ++vi) {
-                const int f = base + vi;
-                if (f >= F) break;
-                const float* M = Pm + (size_t)12 * f;
-                const float m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3];
-                const float m4 = M[4], m5 = M[5], m6 = M[6], m7 = M[7];
-                const float m8 = M[8], m9 = M[9], m10 = M[10], m11 = M[11];
-                float bv0 = 1000000.0f, bv1 = -1000000.0f, bv2 = 1000000.0f, bv3 = -1000000.0f;
-                int bi0 = NONE, bi1 = NONE, bi2 = NONE, bi3 = NONE;
-#pragma unroll
-                for (int j = 0; j < PTS_PER_LANE; j++) {
-                    const int i = lane + 64 * j;
-                    const float qz = proj_row(px[j], py[j], pz[j], m8, m9, m10, m11);
-                    if (i < N_PTS && qz > 0.5f) {
-                        const float qx = proj_row(px[j], py[j], pz[j], m0, m1, m2, m3);
-                        const float qy = proj_row(px[j], py[j], pz[j], m4, m5, m6, m7);
+            for (int k = 0; k < 12; k++) Mv[k] = vf ? Pm[(size_t)12 * f + k] : 0.0f;
+            float bv0 = 1000000.0f, bv1 = -1000000.0f, bv2 = 1000000.0f, bv3 = -1000000.0f;
+            int bi0 = NONE, bi1 = NONE, bi2 = NONE, bi3 = NONE;
+            if (vf) {
+                for (int i = sub; i < N_PTS; i += S) {
+                    const float wx = L.pwx[i], wy = L.pwy[i], wz = L.pwz[i];
+                    const float qz = proj_row(wx, wy, wz, Mv[8], Mv[9], Mv[10], Mv[11]);
+                    if (qz > 0.5f) {
+                        const float qx = proj_row(wx, wy, wz, Mv[0], Mv[1], Mv[2], Mv[3]);
+                        const float qy = proj_row(wx, wy, wz, Mv[4], Mv[5], Mv[6], Mv[7]);
                         const float den = absf(qz) + 1e-6f;
                         const float u = qx / den, v = qy / den;
                         if (u < bv0) { bv0 = u; bi0 = i; }
@@ -331,58 +331,75 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                         if (v > bv3) { bv3 = v; bi3 = i; }
                     }
                 }
-#pragma unroll
-                for (int sft = 32; sft >= 1; sft >>= 1) {
-                    merge_min(bv0, bi0, __shfl_xor(bv0, sft), __shfl_xor(bi0, sft));
-                    merge_max(bv1, bi1, __shfl_xor(bv1, sft), __shfl_xor(bi1, sft));
-                    merge_min(bv2, bi2, __shfl_xor(bv2, sft), __shfl_xor(bi2, sft));
-                    merge_max(bv3, bi3, __shfl_xor(bv3, sft), __shfl_xor(bi3, sft));
-                }
-                if ((lane >> 2) == vi) {
-                    const int d = lane & 3;
-                    my_ext = (d == 0) ? bv0 : (d == 1) ? bv1 : (d == 2) ? bv2 : bv3;
-                    my_win = (d == 0) ? bi0 : (d == 1) ? bi1 : (d == 2) ? bi2 : bi3;
-                }
             }
-            // closed-form gradient: lane = (view in chunk) * 4 + direction
-            const int f = base + (lane >> 2);
-            const int d = lane & 3;
-            const bool active = ((lane >> 2) < chunk) && (f < F);
+            for (int sft = S >> 1; sft >= 1; sft >>= 1) {
+                merge_min(bv0, bi0, __shfl_xor(bv0, sft), __shfl_xor(bi0, sft));
+                merge_max(bv1, bi1, __shfl_xor(bv1, sft), __shfl_xor(bi1, sft));
+                merge_min(bv2, bi2, __shfl_xor(bv2, sft), __shfl_xor(bi2, sft));
+                merge_max(bv3, bi3, __shfl_xor(bv3, sft), __shfl_xor(bi3, sft));
+            }
+            // directions owned by this lane: S >= 4 -> {sub} for sub < 4; S == 2 -> {2 sub, 2 sub + 1}; S == 1 -> all
+            const int nd = (S >= 4) ? ((sub < 4) ? 1 : 0) : (4 / S);
+            const int d0 = (S >= 4) ? sub : sub * nd;
             float g9[9];
-            float lm = 0.0f;
-            if (active) {
-                const bool has = (my_win != NONE);
-                Winner W;
-                if (has) {
-                    const int ke = L.ie[my_win], ko = L.io[my_win];
-                    W.ce = L.fac[0 * BUFP + ke]; W.se = L.fac[1 * BUFP + ke];
-                    W.f1 = L.fac[2 * BUFP + ke]; W.fz = L.fac[3 * BUFP + ke];
-                    W.cw = L.fac[4 * BUFP + ko]; W.sw = L.fac[5 * BUFP + ko];
-                    W.f2 = L.fac[6 * BUFP + ko]; W.fs2 = L.fac[7 * BUFP + ko];
-                    surface_point(S, p, W.f1, W.fz, W.f2, W.fs2, W.raw, W.po, W.pw);
+#pragma unroll
+            for (int k = 0; k < 9; k++) g9[k] = 0.0f;
+            float gp[9];   // partial of the first pair when one lane owns all four directions
+#pragma unroll
+            for (int k = 0; k < 9; k++) gp[k] = 0.0f;
+            for (int dd = 0; dd < nd; dd++) {
+                const int d = d0 + dd;
+                float e9[9];
+                float lm = 0.0f;
+                if (vf) {
+                    const float ext = (d == 0) ? bv0 : (d == 1) ? bv1 : (d == 2) ? bv2 : bv3;
+                    const int win = (d == 0) ? bi0 : (d == 1) ? bi1 : (d == 2) ? bi2 : bi3;
+                    const bool has = (win != NONE);
+                    Winner W;
+                    if (has) {
+                        const int ke = L.ie[win], ko = L.io[win];
+                        W.ce = L.fac[0 * BUFP + ke]; W.se = L.fac[1 * BUFP + ke];
+                        W.f1 = L.fac[2 * BUFP + ke]; W.fz = L.fac[3 * BUFP + ke];
+                        W.cw = L.fac[4 * BUFP + ko]; W.sw = L.fac[5 * BUFP + ko];
+                        W.f2 = L.fac[6 * BUFP + ko]; W.fs2 = L.fac[7 * BUFP + ko];
+                        surface_point(S_, p, W.f1, W.fz, W.f2, W.fs2, W.raw, W.po, W.pw);
+                    } else {
+                        W = Winner{};
+                    }
+                    lm = edge_grad(d, ext, has, tgt[4 * f + d], msk[4 * f + d], invF, Mv, S_, p, W, n_opt == 9, e9);
+                    if (want_loss) L.lterm[f * 4 + d] = lm;
                 } else {
-                    W = Winner{};
+#pragma unroll
+                    for (int k = 0; k < 9; k++) e9[k] = 0.0f;
                 }
-                float Mv[12];
+                // within-lane order: (d0 + d1) [+ (d2 + d3)]
+                if (dd == 0) {
 #pragma unroll
-                for (int k = 0; k < 12; k++) Mv[k] = Pm[(size_t)12 * f + k];
-                lm = edge_grad(d, my_ext, has, tgt[4 * f + d], msk[4 * f + d], invF, Mv, S, p, W,
-                               n_opt == 9, g9);
-            } else {
+                    for (int k = 0; k < 9; k++) g9[k] = e9[k];
+                } else if (dd == 1) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) g9[k] = 0.0f;
-            }
+                    for (int k = 0; k < 9; k++) g9[k] = g9[k] + e9[k];
+                } else if (dd == 2) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                g9[k] = g9[k] + __shfl_xor(g9[k], 1);   // (d0+d1), (d2+d3)
-                g9[k] = g9[k] + __shfl_xor(g9[k], 2);   // (d0+d1)+(d2+d3)
-            }
-            if (active) {
-                if (d == 0) {
+                    for (int k = 0; k < 9; k++) gp[k] = e9[k];
+                } else {
 #pragma unroll
-                    for (int k = 0; k < 9; k++) L.vgrad[f * 9 + k] = g9[k];
+                    for (int k = 0; k < 9; k++) g9[k] = g9[k] + (gp[k] + e9[k]);
                 }
-                if (want_loss) L.lterm[f * 4 + d] = lm;
+            }
+            if (S >= 4) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    g9[k] = g9[k] + __shfl_xor(g9[k], 1);   // (d0+d1), (d2+d3)
+                    g9[k] = g9[k] + __shfl_xor(g9[k], 2);   // (d0+d1)+(d2+d3)
+                }
+            } else if (S == 2) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) g9[k] = g9[k] + __shfl_xor(g9[k], 1);
+            }
+            if (vf && sub == 0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) L.vgrad[f * 9 + k] = g9[k];
             }
         }
         for (int idx = tid; idx < (Pn - F) * 9; idx += NT) L.vgrad[F * 9 + idx] = 0.0f;
