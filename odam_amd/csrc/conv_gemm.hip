@@ -1,6 +1,8 @@
 // conv_gemm.hip -- see conv_gemm.h
 #include "conv_gemm.h"
 
+#include <cstdlib>
+
 #include "odam_err.h"
 
 namespace odam_cg {
@@ -11,12 +13,14 @@ constexpr int BK = 32;
 constexpr int LDS_STRIDE = BK + 4;  // 144-byte rows: 16-byte aligned, conflict-free for ds_read_b128
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a) {
+    constexpr int NTH = 64 * WM * WN;  // threads per workgroup
+    constexpr int RPP = NTH / 8;       // tile rows staged per pass (8 float4 per 32-float row)
     constexpr int TM = BM / WM / 32;   // 32x32 MFMA tiles per wave along M
     constexpr int TN = BN / WN / 32;
-    constexpr int A_LD = BM / 32;      // float4 loads per thread for the A tile
-    constexpr int B_LD = BN / 32;
-    static_assert(WM * WN == 4, "4 wavefronts per workgroup");
+    constexpr int A_LD = BM / RPP;     // float4 loads per thread for the A tile
+    constexpr int B_LD = BN / RPP;
+    static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows divide over the loader threads");
 
     __shared__ __align__(16) float smem[2 * (BM + BN) * LDS_STRIDE];   // 36 / 54 / 72 KiB, static
     float* As = smem;                         // [2][BM][LDS_STRIDE]
@@ -27,19 +31,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     const int wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (a.Cout + BN - 1) / BN;
-    const int tile_m = blockIdx.x / tiles_n;
-    const int tile_n = blockIdx.x - tile_m * tiles_n;
+    // Workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD a contiguous run
+    // of tile ids, so the n-tiles that re-read one A row block (and neighbouring m-tiles that share filter
+    // taps) meet in one L2.  Bijective for any grid size; placement only changes speed, never results.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / tiles_n;
+    const int tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread gather bookkeeping (rows are fixed over the K loop) ---------------------
     const int c4 = tid & 7;    // which float4 of the 32-wide k slice
-    const int r0 = tid >> 3;   // 0..31
+    const int r0 = tid >> 3;   // 0..RPP-1
     int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
     bool a_ok[A_LD];
     const int hw = a.Ho * a.Wo;
 #pragma unroll
     for (int i = 0; i < A_LD; i++) {
-        const int m = m0 + r0 + 32 * i;
+        const int m = m0 + r0 + RPP * i;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? m : 0;
         const int b = mm / hw;
@@ -54,7 +66,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     bool b_ok[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; i++) {
-        const int n = n0 + r0 + 32 * i;
+        const int n = n0 + r0 + RPP * i;
         b_ok[i] = n < a.Cout;
         w_ptr[i] = a.Wt + (size_t)(b_ok[i] ? n : 0) * a.Kpad + c4 * 4;
     }
@@ -83,10 +95,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
     auto store_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < A_LD; i++)
-            *reinterpret_cast<float4*>(&As[(buf * BM + r0 + 32 * i) * LDS_STRIDE + c4 * 4]) = ra[i];
+            *reinterpret_cast<float4*>(&As[(buf * BM + r0 + RPP * i) * LDS_STRIDE + c4 * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_LD; i++)
-            *reinterpret_cast<float4*>(&Bs[(buf * BN + r0 + 32 * i) * LDS_STRIDE + c4 * 4]) = rb[i];
+            *reinterpret_cast<float4*>(&Bs[(buf * BN + r0 + RPP * i) * LDS_STRIDE + c4 * 4]) = rb[i];
     };
 
     floatx16 acc[TM][TN];
@@ -140,7 +152,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
         // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
         // 16-byte residual loads and 16-byte stores, 256 contiguous bytes per 16 lanes.
         constexpr int EP_LD = WCOLS + 4;
-        static_assert(4 * WROWS * EP_LD <= 2 * (BM + BN) * LDS_STRIDE, "epilogue staging fits the tile buffers");
+        static_assert(WM * WN * WROWS * EP_LD <= 2 * (BM + BN) * LDS_STRIDE, "epilogue staging fits the tile buffers");
         float* Ep = smem + wave * (WROWS * EP_LD);
 #pragma unroll
         for (int i = 0; i < TM; i++)
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvGemmArgs a) {
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -223,9 +235,11 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (a.Kpad % BK != 0 || a.Cin < 4 || (a.Cin & (a.Cin - 1)) != 0 || a.KW > 7 || a.KH * a.KW > 64)
         return odam_fail(1, "conv_gemm: unsupported shape (Kpad % 32, Cin power of two >= 4, KW <= 7)");
     if (a.M <= 0 || a.Cout <= 0) return 0;
-    if (a.Cout <= 64) return launch_cfg<128, 64, 4, 1>(a, stream);
+    static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 3;  // 8-wave tiles (+2-3 %)
+    if (a.Cout <= 64) return (variant & 2) ? launch_cfg<128, 64, 4, 2>(a, stream) : launch_cfg<128, 64, 4, 1>(a, stream);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
     if (tiles128 < 128) return launch_cfg<64, 64, 2, 2>(a, stream);
+    if (variant & 1) return launch_cfg<128, 128, 4, 2>(a, stream);
     return launch_cfg<128, 128, 2, 2>(a, stream);
 }
 

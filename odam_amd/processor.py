@@ -12,8 +12,8 @@ What is different underneath:
   * `_prepare_tracks` evaluates the surface of ALL live tracks in one odam_sq_points_batch launch
     instead of one CPU sampler call per track (processor.py:181-207).
   * `optim_process` batches every object's 200-step fit into one kernel launch (odam_amd.multi_view).
-The associator (src/models/associator.py) and the track merge (src/scripts/run_merge.py) are the
-reference's own and stay caller-supplied / imported: they are outside this build's hot path.
+The associator (src/models/associator.py) is the reference's own and stays caller-supplied; the track merge
+between the two fit passes is restated in odam_amd/merge.py (run_merge.py:79-130).
 """
 import logging
 from copy import deepcopy
@@ -21,7 +21,7 @@ from copy import deepcopy
 import numpy as np
 import torch
 
-from . import multi_view
+from . import merge, multi_view
 from .sq import init_params
 
 
@@ -264,14 +264,8 @@ class OdamProcess:
 
     # ---- back end (processor.py:347-368) -----------------------------------------------------------
     def merge_process(self, data):
-        try:
-            from src.scripts.run_merge import merge_process  # the reference's own, when on PYTHONPATH
-        except Exception as e:  # pragma: no cover
-            raise NotImplementedError(
-                "track merging (src/scripts/run_merge.py) is outside this build's hot path; put the reference "
-                "tree on PYTHONPATH or merge the tracks yourself") from e
-        self.logger.info("merging tracks")
-        return merge_process(data, self.usable_frames)
+        self.logger.info("Merging tracks")
+        return merge.merge_process(data, self.usable_frames)
 
     def optim_process(self, tracks):
         m = self.sequence_meta

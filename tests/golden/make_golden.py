@@ -150,6 +150,9 @@ def main():
     import refenv
     mode = sys.argv[1] if len(sys.argv) > 1 else "all"
     refenv.setup()
+    if mode == "merge":
+        gen_merge(os.path.join(HERE, "sq_merge.npz"))
+        return
     if mode == "avx2-child":  # second dispatch of the same reference; results handed back through a file
         from odam_amd import synth
         finals = np.stack([run_plain(synth.make_sq_problem(F, s), synth.make_sq_problem(F, s)["class_id"])
@@ -164,7 +167,62 @@ def main():
     gen_sampler(os.path.join(HERE, "sq_sampler.npz"))
     gen_steps(os.path.join(HERE, "sq_steps.npz"), z["finals"])
     gen_optim(os.path.join(HERE, "sq_optim.npz"), z["params"])
+    gen_merge(os.path.join(HERE, "sq_merge.npz"))
     print("golden vectors written to", HERE)
+
+
+
+def gen_merge(out):
+    """optim_process -> merge_process of the reference on a scene whose tracks are fragmented.
+    scikit-learn >= 1.2 renamed AgglomerativeClustering(affinity=) to metric=; the reference's call is adapted
+    by keyword only."""
+    import sklearn.cluster as skc
+    from odam_amd import synth
+    orig = skc.AgglomerativeClustering
+
+    def compat(*a, affinity=None, **k):
+        if affinity is not None:
+            k["metric"] = affinity
+        return orig(*a, **k)
+    import src.scripts.run_merge as rm
+    rm.AgglomerativeClustering = compat
+
+    class _OldNumpy:
+        """numpy < 1.24 turned a ragged list into an object array (run_merge.py:27-28 relies on it); newer numpy
+        raises -- same result, spelled explicitly"""
+        def __getattr__(self, k):
+            return getattr(np, k)
+
+        def asarray(self, x, *a, **k):
+            try:
+                return np.asarray(x, *a, **k)
+            except ValueError:
+                out = np.empty(len(x), object)
+                for i, v in enumerate(x):
+                    out[i] = v
+                return out
+    rm.np = _OldNumpy()
+    scene = synth.make_scene(160, 6, seed=9, min_views=24, max_views=90)
+    tracks = []
+    for i, t in enumerate(scene["tracks"]):
+        if i % 2 == 0 and len(t) >= 24:      # split into two interleaved fragments of one physical object
+            tracks += [t[0::2].copy(), t[1::2].copy()]
+        else:
+            tracks.append(t.copy())
+    scene = dict(scene, tracks=tracks)
+    from src.scripts.run_multi_view import optim_process
+    res = optim_process([t.copy() for t in tracks], scene["img_names"], scene["T_wcs"], scene["P_cws"], 480, 640,
+                        scene["K"], "super_quadric", True, 200, 10)
+    data = {"tracks": [t.copy() for t in tracks], "bboxes_qc": res["bboxes_qc"]}
+    merged = rm.merge_process(data, scene["img_names"])
+    d = dict(n_tracks=np.int32(len(tracks)), n_merged=np.int32(len(merged)), img_names=np.asarray(scene["img_names"]),
+             bboxes_qc=np.asarray(res["bboxes_qc"]))
+    for i, t in enumerate(tracks):
+        d[f"track{i}"] = t
+    for i, t in enumerate(merged):
+        d[f"merged{i}"] = t
+    np.savez_compressed(out, **d)
+    print("merge golden:", len(tracks), "tracks ->", len(merged))
 
 
 if __name__ == "__main__":
