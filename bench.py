@@ -145,6 +145,7 @@ def main():
     detector(frames[:args.batch])
     torch.cuda.synchronize()
     n_launch, conv_ms, conv_flops = detector.profile_read(H, W)
+    att_n, att_ms, att_flops = detector.profile_read_attention(H, W)
     detector.profile(H, W, False)
     if ws > 1:
         t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
@@ -198,6 +199,12 @@ def main():
                                                 "ms_per_forward": conv_ms, "batch": args.batch,
                                                 "measured": "one forward alone on one stream, HIP event pair around every launch"}}
 
+    if att_ms > 0:
+        result["attention_kernel"] = {"achieved": att_flops / (att_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
+                                      "unit": "TFLOP/s", "frac": att_flops / (att_ms * 1e-3) / PEAK_FP32_MFMA,
+                                      "launches_per_forward": att_n, "ms_per_forward": att_ms, "batch": args.batch,
+                                      "measured": "QK^T + PV flops of the fused attention kernel / its launch durations "
+                                                  "(HIP events, one forward alone on one stream)"}
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, tracks, N)
     if rank == 0:

@@ -85,6 +85,7 @@ int odam_detr_select(const float* rows, int Q, float threshold, int nms_2d, int*
  * event pairs while enabled); read returns the totals of the most recent forward. */
 int odam_detr_profile_enable(odam_detr* m, int on);
 int odam_detr_profile_read(odam_detr* m, int* n_launches, double* total_ms, double* total_flops);
+int odam_detr_profile_read_attention(odam_detr* m, int* n_launches, double* total_ms, double* total_flops);
 
 /* ---- single-operator entry points (the same kernels the forward uses; for parity tests and reuse) ---- */
 /* NHWC convolution / linear:  x [dev][B,H,W,Cin] (Cin power of two >= 4), w_packed [dev][Cout][Kpad]

@@ -87,6 +87,9 @@ struct odam_detr {
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;
     size_t ev_used = 0;
+    std::vector<hipEvent_t> aev;      // same for the fused attention kernel
+    std::vector<double> aev_flops;
+    size_t aev_used = 0;
 
     template <typename T>
     int dev_alloc(T** p, size_t n) {
@@ -206,6 +209,24 @@ int conv_t(odam_detr* m, const Conv& c, const float* x, int B, int H, int W, con
 int lin_t(odam_detr* m, const Conv& c, const float* x, int M, const float* res, bool relu, float* y, hipStream_t st) {
     return conv_t(m, c, x, 1, 1, M, res, relu, y, st);
 }
+int att_t(odam_detr* m, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+          int B, int H, int Lq, int Lk, hipStream_t st) {
+    if (!m->profile) return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, st);
+    if (m->aev_used + 2 > m->aev.size()) {
+        for (int k = 0; k < 2; k++) {
+            hipEvent_t e;
+            ODAM_HIP(hipEventCreate(&e));
+            m->aev.push_back(e);
+        }
+        m->aev_flops.resize(m->aev.size() / 2);
+    }
+    m->aev_flops[m->aev_used / 2] = 4.0 * B * H * (double)Lq * Lk * 32;   // QK^T + PV, 2 flop per MAC
+    ODAM_HIP(hipEventRecord(m->aev[m->aev_used], st));
+    int rc = odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, st);
+    ODAM_HIP(hipEventRecord(m->aev[m->aev_used + 1], st));
+    m->aev_used += 2;
+    return rc;
+}
 
 #define RC(call)                 \
     do {                         \
@@ -235,6 +256,7 @@ extern "C" int odam_detr_destroy(odam_detr* m) {
     if (!m) return 0;
     for (void* p : m->allocs) (void)hipFree(p);
     for (hipEvent_t e : m->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : m->aev) (void)hipEventDestroy(e);
     delete m;
     return 0;
 }
@@ -383,6 +405,7 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
     if (B < 1 || B > m->cfg.max_batch) return odam_fail(3, "odam_detr_forward: batch outside 1..max_batch");
     hipStream_t st = (hipStream_t)stream;
     m->ev_used = 0;
+    m->aev_used = 0;
     const odam_detr_cfg& c = m->cfg;
     const int E = c.hidden_dim, Hh = c.nheads, Q = c.num_queries;
 
@@ -418,7 +441,7 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
         const EncLayer& e = m->enc[i];
         RC(lin_t(m, e.qk, m->srcpos, M, nullptr, false, m->qk, st));
         RC(lin_t(m, e.v, m->src, M, nullptr, false, m->v, st));
-        RC(odam_dk::launch_attention(m->qk, 2 * E, m->qk + E, 2 * E, m->v, E, m->att, E, B, Hh, L, L, st));
+        RC(att_t(m, m->qk, 2 * E, m->qk + E, 2 * E, m->v, E, m->att, E, B, Hh, L, L, st));
         RC(lin_t(m, e.out, m->att, M, m->src, false, m->tmp, st));
         RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n1.g, e.n1.b, m->src, nullptr, L, nullptr, M, st));
         RC(lin_t(m, e.l1, m->src, M, nullptr, true, m->ffn, st));
@@ -437,11 +460,11 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
         const DecLayer& d = m->dec[i];
         RC(lin_t(m, d.qk, m->tgtpos, Mq, nullptr, false, m->dqk, st));
         RC(lin_t(m, d.v, m->tgt, Mq, nullptr, false, m->dv, st));
-        RC(odam_dk::launch_attention(m->dqk, 2 * E, m->dqk + E, 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
+        RC(att_t(m, m->dqk, 2 * E, m->dqk + E, 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
         RC(lin_t(m, d.out, m->datt, Mq, m->tgt, false, m->dtmp, st));
         RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n1.g, d.n1.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, st));
         RC(lin_t(m, d.cq, m->tgtpos, Mq, nullptr, false, m->dq, st));
-        RC(odam_dk::launch_attention(m->dq, E, m->kc + i * E, ldkv, m->vc + i * E, ldkv, m->datt, E, B, Hh, Q, L, st));
+        RC(att_t(m, m->dq, E, m->kc + i * E, ldkv, m->vc + i * E, ldkv, m->datt, E, B, Hh, Q, L, st));
         RC(lin_t(m, d.cout, m->datt, Mq, m->tgt, false, m->dtmp, st));
         RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n2.g, d.n2.b, m->tgt, nullptr, Q, nullptr, Mq, st));
         RC(lin_t(m, d.l1, m->tgt, Mq, nullptr, true, m->dffn, st));
@@ -531,6 +554,22 @@ extern "C" int odam_detr_profile_read(odam_detr* m, int* n_launches, double* tot
         fl += m->ev_flops[i / 2];
     }
     *n_launches = (int)(m->ev_used / 2);
+    *total_ms = ms;
+    *total_flops = fl;
+    return 0;
+}
+
+extern "C" int odam_detr_profile_read_attention(odam_detr* m, int* n_launches, double* total_ms, double* total_flops) {
+    if (!m || !n_launches || !total_ms || !total_flops) return odam_fail(1, "odam_detr_profile_read_attention: null argument");
+    double ms = 0.0, fl = 0.0;
+    for (size_t i = 0; i + 1 < m->aev_used; i += 2) {
+        ODAM_HIP(hipEventSynchronize(m->aev[i + 1]));
+        float t = 0.0f;
+        ODAM_HIP(hipEventElapsedTime(&t, m->aev[i], m->aev[i + 1]));
+        ms += t;
+        fl += m->aev_flops[i / 2];
+    }
+    *n_launches = (int)(m->aev_used / 2);
     *total_ms = ms;
     *total_flops = fl;
     return 0;

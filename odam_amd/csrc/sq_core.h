@@ -44,11 +44,9 @@ struct Arc {
     int n, off;
 };
 
-// sampling.cpp:92-124: midpoint, split count, the two child arcs.  Returns the slot it fills.
-ODAM_HD int arc_step(const Arc& nd, float a1, float a2, float e, float& th, Arc& left, Arc& right) {
-    th = (nd.ta + nd.tb) / 2;
-    float cx, cy;
-    xy(th, a1, a2, e, cx, cy);
+// sampling.cpp:96-124 given the midpoint theta and its curve point C: split count and the two child arcs.
+// Returns the buffer slot the midpoint fills.
+ODAM_HD int arc_split(const Arc& nd, float th, float cx, float cy, Arc& left, Arc& right) {
     float dA = dist(nd.ax, nd.ay, cx, cy);
     float dB = dist(cx, cy, nd.bx, nd.by);
     int nA = (int)__builtin_roundf((dA / (dA + dB)) * (float)(nd.n - 1));
@@ -58,6 +56,14 @@ ODAM_HD int arc_step(const Arc& nd, float a1, float a2, float e, float& th, Arc&
     right.ax = cx; right.ay = cy; right.bx = nd.bx; right.by = nd.by;
     right.ta = th; right.tb = nd.tb; right.n = nB; right.off = nd.off + nA + 1;
     return nA + nd.off;
+}
+
+// sampling.cpp:92-124: midpoint, curve point, split.
+ODAM_HD int arc_step(const Arc& nd, float a1, float a2, float e, float& th, Arc& left, Arc& right) {
+    th = (nd.ta + nd.tb) / 2;
+    float cx, cy;
+    xy(th, a1, a2, e, cx, cy);
+    return arc_split(nd, th, cx, cy, left, right);
 }
 
 // derived shape of a parameter vector p = translate[3], angle, scales[3], shapes[2]

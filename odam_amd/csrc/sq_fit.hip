@@ -49,6 +49,12 @@ constexpr int BUFP = 208;       // padded theta-buffer length
 constexpr int QCAP = 200;       // pending arcs per curve per level (sum of n over a level <= 199)
 constexpr int PTS_PER_LANE = 16;  // ceil(1000 / 64)
 constexpr int NONE = 0x7fffffff;
+constexpr int TABN = 513;        // dyadic theta table: depth 9 of the parameter bisection
+
+struct QArc {                    // pending arc + its position in the dyadic table (-1: deeper than the table)
+    Arc a;
+    int qa, qb;
+};
 
 struct FitArgs {
     const float* init_params;
@@ -88,13 +94,16 @@ struct Lds {
     float* cdf;     // [BUFP]
     float* term;    // [BUFP]
     float* fac;     // [8][BUFP]  ce, se, f1, fz, cw, sw, f2, fs2
-    Arc* q;         // [2 curves][2][QCAP]
+    QArc* q;        // [2 curves][2][QCAP]
+    float* tth;     // [2][TABN] theta, curve point x, y of every dyadic parameter position
+    float* tcx;
+    float* tcy;
     float* vgrad;   // [pn][9]
     float* lterm;   // [pn][4]
 };
 
 __host__ __device__ inline size_t lds_words(int pn) {
-    return 12 * 6 + 8 + 8 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 8 +
+    return 12 * 6 + 8 + 8 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
            (size_t)pn * 9 + (size_t)pn * 4;
 }
 
@@ -118,7 +127,10 @@ __device__ inline Lds carve(float* base, int pn) {
     L.cdf = w; w += BUFP;
     L.term = w; w += BUFP;
     L.fac = w; w += 8 * BUFP;
-    L.q = (Arc*)w; w += 2 * 2 * QCAP * 8;
+    L.q = (QArc*)w; w += 2 * 2 * QCAP * 10;
+    L.tth = w; w += 2 * 520;
+    L.tcx = w; w += 2 * 520;
+    L.tcy = w; w += 2 * 520;
     L.vgrad = w; w += (size_t)pn * 9;
     L.lterm = w;
     return L;
@@ -201,50 +213,93 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
 #pragma unroll
         for (int k = 0; k < 9; k++) p[k] = L.p[k];
 
-        // ---------------- B: breadth-first arc subdivision -------------------------------------
-        // curve 0: eta  (a1, a3, e1) from +pi/2 to -pi/2;  curve 1: omega (a1, a2, e2) from +pi to -pi
-        {
-            const int j = tid >> 6;  // lanes 0 of waves 0..3 evaluate the four end points
-            if (lane == 0 && j < 4) {
-                const int c = j >> 1, end = j & 1;
-                const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
-                const float ta = c ? PI_F : PI_F / 2;
-                const float th = end ? -ta : ta;
-                float cx, cy;
-                xy(th, a1, a2, e, cx, cy);
-                Arc* root = &L.q[(c * 2 + 0) * QCAP];
-                if (end == 0) {
-                    root->ax = cx; root->ay = cy; root->ta = th;
-                    root->n = BUF - 2; root->off = 1;
-                    L.buf[c * BUFP] = th;
-                } else {
-                    root->bx = cx; root->by = cy; root->tb = th;
-                    L.buf[c * BUFP + BUF - 1] = th;
+        // ---------------- B: arc subdivision ------------------------------------------------------
+        // curve 0: eta  (a1, a3, e1) from +pi/2 to -pi/2;  curve 1: omega (a1, a2, e2) from +pi to -pi.
+        // The reference bisects the PARAMETER interval at every node (sampling.cpp:92); only the slot counts
+        // depend on the arc lengths.  So the theta of every node down to depth 9 is known up front:
+        //   B1  all 2 x 513 dyadic thetas and their curve points (the trig/pow work) in ONE parallel pass,
+        //   B2  the breadth-first slot allocation then needs two distances, a division and a round per node;
+        //       nodes deeper than the table (rare, strongly unbalanced curves) evaluate their point on the fly.
+        for (int w = tid; w < 2 * TABN; w += NT) {
+            const int c = w / TABN, q = w - c * TABN;
+            const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
+            const float ta = c ? PI_F : PI_F / 2;
+            float lo = ta, hi = -ta, th;
+            if (q == 0) th = lo;
+            else if (q == TABN - 1) th = hi;
+            else {
+                int lq = 0, hq = TABN - 1;
+                for (;;) {
+                    const int mq = (lq + hq) >> 1;
+                    th = (lo + hi) / 2;
+                    if (q == mq) break;
+                    if (q < mq) { hq = mq; hi = th; } else { lq = mq; lo = th; }
                 }
             }
-            if (tid < 6) L.cnt[tid] = (tid < 2) ? 1 : 0;
+            float cx, cy;
+            xy(th, a1, a2, e, cx, cy);
+            L.tth[w] = th; L.tcx[w] = cx; L.tcy[w] = cy;
+        }
+        if (tid < 6) L.cnt[tid] = (tid < 2) ? 1 : 0;
+        if (tid < 2) {   // roots: the whole parameter range, 199 interior slots starting at 1
+            QArc* root = &L.q[(tid * 2 + 0) * QCAP];
+            root->qa = 0; root->qb = TABN - 1; root->a.n = BUF - 2; root->a.off = 1;
+            const float ta = tid ? PI_F : PI_F / 2;
+            L.buf[tid * BUFP] = ta;
+            L.buf[tid * BUFP + BUF - 1] = -ta;
         }
         __syncthreads();
-        for (int lvl = 0; lvl < BUF; ++lvl) {
-            const int cur = lvl % 3, nxt = (lvl + 1) % 3, clr = (lvl + 2) % 3;
-            const int n0 = L.cnt[cur * 2 + 0], n1 = L.cnt[cur * 2 + 1];
-            if ((n0 | n1) == 0) break;
-            if (tid < 2) L.cnt[clr * 2 + tid] = 0;
-            for (int w = tid; w < 512; w += NT) {
-                const int c = w >> 8, i = w & 255;
-                if (i >= (c ? n1 : n0)) continue;
-                const Arc nd = L.q[(c * 2 + (lvl & 1)) * QCAP + i];
-                const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
-                Arc lf, rt;
-                float th;
-                const int slot = arc_step(nd, a1, a2, e, th, lf, rt);
-                L.buf[c * BUFP + slot] = th;
-                Arc* qn = &L.q[(c * 2 + ((lvl + 1) & 1)) * QCAP];
-                if (lf.n > 0) qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = lf;
-                if (rt.n > 0) qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = rt;
+#ifndef SQ_ABLATE_B
+        // B2: one wavefront per curve walks its levels with wave-level synchronisation only (no workgroup barrier
+        // per level: a level is ~200 nodes at most, 4 passes of 64 lanes); the other wavefronts wait at the
+        // barrier below.
+        if (wid < 2) {
+            const int c = wid;
+            const int t0 = c * TABN;
+            for (int lvl = 0; lvl < BUF; ++lvl) {
+                const int cur = lvl % 3, nxt = (lvl + 1) % 3, clr = (lvl + 2) % 3;
+                const int n = L.cnt[cur * 2 + c];
+                if (n == 0) break;
+                if (lane == 0) L.cnt[clr * 2 + c] = 0;
+                for (int i = lane; i < n; i += 64) {
+                    QArc nd = L.q[(c * 2 + (lvl & 1)) * QCAP + i];
+                    Arc lf, rt;
+                    float th;
+                    int slot, qm = -1;
+                    if (nd.qa >= 0) {   // table-backed: end points and midpoint come from B1
+                        qm = (nd.qa + nd.qb) >> 1;
+                        nd.a.ax = L.tcx[t0 + nd.qa]; nd.a.ay = L.tcy[t0 + nd.qa]; nd.a.ta = L.tth[t0 + nd.qa];
+                        nd.a.bx = L.tcx[t0 + nd.qb]; nd.a.by = L.tcy[t0 + nd.qb]; nd.a.tb = L.tth[t0 + nd.qb];
+                        th = L.tth[t0 + qm];
+                        slot = arc_split(nd.a, th, L.tcx[t0 + qm], L.tcy[t0 + qm], lf, rt);
+                    } else {
+                        const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
+                        slot = arc_step(nd.a, a1, a2, e, th, lf, rt);
+                    }
+                    L.buf[c * BUFP + slot] = th;
+                    QArc* qn = &L.q[(c * 2 + ((lvl + 1) & 1)) * QCAP];
+                    if (lf.n > 0) {
+                        QArc o; o.a = lf;
+                        const bool tab = (qm >= 0) && (qm - nd.qa >= 2);
+                        o.qa = tab ? nd.qa : -1; o.qb = tab ? qm : -1;
+                        qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = o;
+                    }
+                    if (rt.n > 0) {
+                        QArc o; o.a = rt;
+                        const bool tab = (qm >= 0) && (nd.qb - qm >= 2);
+                        o.qa = tab ? qm : -1; o.qb = tab ? nd.qb : -1;
+                        qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = o;
+                    }
+                }
+                // LDS operations of one wavefront complete in order; the fences keep the compiler from moving
+                // the next level's reads above this level's writes
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
-            __syncthreads();
         }
+        __syncthreads();
+#endif
 
         // ---------------- C: CDF and per-entry factors ----------------------------------------
         for (int w = tid; w < 768; w += NT) {
@@ -261,6 +316,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             }
         }
         __syncthreads();
+#ifndef SQ_ABLATE_SCAN
         if (tid == 0) {  // sampling.cpp:141-146: strictly ordered float32 running sum
             float c = 0.001f;
             L.cdf[0] = c;
@@ -270,6 +326,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             }
             L.misc[0] = c;
         }
+#endif
         __syncthreads();
         if (tid < BUF) L.cdf[tid] = L.cdf[tid] / L.misc[0];
         __syncthreads();

@@ -275,6 +275,12 @@ class Detector:
                                                      ctypes.byref(fl)), "profile_read")
         return n.value, ms.value, fl.value
 
+    def profile_read_attention(self, H, W):
+        n, ms, fl = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        _lib.check(_lib.lib().odam_detr_profile_read_attention(self._handle(H, W), ctypes.byref(n), ctypes.byref(ms),
+                                                               ctypes.byref(fl)), "profile_read_attention")
+        return n.value, ms.value, fl.value
+
     def postprocess(self, out, img_size, threshold, intr_mat, nms_2d=True):
         rows = self.postprocess_rows(out, img_size, intr_mat)
         res = {k: [] for k in ("bboxes", "dimensions", "angles", "translates", "classes", "scores")}
