@@ -30,6 +30,7 @@ from odam_amd.processor import detection_rows  # noqa: E402
 
 FLOPS_PER_FRAME_R50 = 163.1e9   # SURVEY.md section 2.2 / BASELINE.md (2 x MAC, 800x1066 input)
 PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+TRAFFIC_BYTES_PER_FRAME_PMC = (2 * 10860962.0 + 6627384.5) * 1024 / 8   # profiles/r1_detr_forward_B8_pmc_*.csv
 
 
 def build_frames(n_local, device, seed):
@@ -188,7 +189,11 @@ def main():
         ach = flops_per_frame * n_local * args.steps / (det_phase_ms * 1e-3)
         iso = conv_flops / (conv_ms * 1e-3)
         result["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
-                              "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA, "traffic": None,
+                              "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA,
+                              # HBM-side bytes of this kernel per frame from rocprofv3 PMC passes of a B=8 forward
+                              # (profiles/r1_detr_forward_B8_pmc_*.csv): (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / 8;
+                              # counters cannot be read from inside this process, so the figure is the recorded one
+                              "traffic": TRAFFIC_BYTES_PER_FRAME_PMC, "traffic_unit": "bytes per frame (all launches)",
                               "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv / linear, v_mfma_f32_32x32x2_f32)",
                               "launches_per_forward": n_launch,
                               "algorithmic_gflop_per_frame": flops_per_frame / 1e9,

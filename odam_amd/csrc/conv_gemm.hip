@@ -118,24 +118,35 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     const int frag_k = (lane >> 5) * 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
         const float* Ab = &As[(cur * BM + wm * (BM / WM) + frag_row) * LDS_STRIDE + frag_k];
         const float* Bb = &Bs[(cur * BN + wn * (BN / WN) + frag_row) * LDS_STRIDE + frag_k];
+        // fragments of k-group 0 first, then the next tile's global loads are issued under that LDS latency;
+        // every k-group's fragments are fetched one group ahead of the MFMAs that consume them
+        float4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE);
+        if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
         for (int q = 0; q < BK / 8; q++) {
-            float4 af[TM], bf[TN];
+            const int pb = q & 1;
+            if (q + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; i++) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + q * 8);
+                for (int i = 0; i < TM; i++)
+                    af[pb ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + (q + 1) * 8);
 #pragma unroll
-            for (int j = 0; j < TN; j++) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE + q * 8);
+                for (int j = 0; j < TN; j++)
+                    bf[pb ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE + (q + 1) * 8);
+            }
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].x, bf[pb][j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].y, bf[pb][j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].z, bf[pb][j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].w, bf[pb][j].w, acc[i][j], 0, 0, 0);
                 }
         }
         if (kt + 1 < nk) store_tile(cur ^ 1);
@@ -152,45 +163,47 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
         // 16-byte residual loads and 16-byte stores, 256 contiguous bytes per 16 lanes.
         constexpr int EP_LD = WCOLS + 4;
-        static_assert(WM * WN * WROWS * EP_LD <= 2 * (BM + BN) * LDS_STRIDE, "epilogue staging fits the tile buffers");
-        float* Ep = smem + wave * (WROWS * EP_LD);
+        static_assert(WM * WN * 32 * EP_LD <= 2 * (BM + BN) * LDS_STRIDE, "epilogue staging fits the tile buffers");
+        float* Ep = smem + wave * (32 * EP_LD);     // one 32-row slab per wave, reused for each of its TM row tiles
+        constexpr int LPR = WCOLS / 4;              // lanes per row
+        constexpr int RPI = 64 / LPR;               // rows per wave-instruction
+        constexpr int NIT = 32 / RPI;
+        const int c4 = (lane % LPR) * 4;
+        const int n = n0 + wn * WCOLS + c4;
+        const bool n_ok = n < a.Cout;               // Cout % 4 == 0: the four channels are in or out together
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+        if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
 #pragma unroll
-        for (int i = 0; i < TM; i++)
+        for (int i = 0; i < TM; i++) {
+            float4 rv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {   // residual rows of this slab: issued before the LDS round trip
+                const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
+                rv[it] = (resp && n_ok && m < a.M) ? *reinterpret_cast<const float4*>(resp + (size_t)m * a.ldc + n)
+                                                   : float4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (i > 0) __syncthreads();          // previous slab fully read before it is overwritten
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++)
-                    Ep[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-        __syncthreads();
-        constexpr int LPR = WCOLS / 4;          // lanes per row
-        constexpr int RPI = 64 / LPR;           // rows per wave-instruction
-        const int c4 = (lane % LPR) * 4;
-        const int n = n0 + wn * WCOLS + c4;
-        const bool n_ok = n < a.Cout;           // Cout % 4 == 0: the four channels are in or out together
-        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
-        if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
-        constexpr int NIT = WROWS / RPI;
-        float4 rv[NIT];
+                    Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+            __syncthreads();
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int m = m0 + wm * WROWS + it * RPI + lane / LPR;
-            rv[it] = (resp && n_ok && m < a.M) ? *reinterpret_cast<const float4*>(resp + (size_t)m * a.ldc + n)
-                                               : float4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int row = it * RPI + lane / LPR;
-            const int m = m0 + wm * WROWS + row;
-            const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4]);
-            float4 o;
-            o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
-            o.x += rv[it].x; o.y += rv[it].y; o.z += rv[it].z; o.w += rv[it].w;
-            if (a.relu) {
-                o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-                o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+            for (int it = 0; it < NIT; it++) {
+                const int row = it * RPI + lane / LPR;
+                const int m = m0 + wm * WROWS + i * 32 + row;
+                const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4]);
+                float4 o;
+                o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
+                o.x += rv[it].x; o.y += rv[it].y; o.z += rv[it].z; o.w += rv[it].w;
+                if (a.relu) {
+                    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                    o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                }
+                if (n_ok && m < a.M) *reinterpret_cast<float4*>(outp + (size_t)m * a.ldc + n) = o;
             }
-            if (n_ok && m < a.M) *reinterpret_cast<float4*>(outp + (size_t)m * a.ldc + n) = o;
         }
         return;
     }
@@ -239,6 +252,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (a.Cout <= 64) return (variant & 2) ? launch_cfg<128, 64, 4, 2>(a, stream) : launch_cfg<128, 64, 4, 1>(a, stream);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
     if (tiles128 < 128) return launch_cfg<64, 64, 2, 2>(a, stream);
+    if ((variant & 4) && tiles128 >= 2048) return launch_cfg<256, 128, 4, 2>(a, stream);
     if (variant & 1) return launch_cfg<128, 128, 4, 2>(a, stream);
     return launch_cfg<128, 128, 2, 2>(a, stream);
 }
