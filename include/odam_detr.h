@@ -35,6 +35,8 @@ typedef struct {
     int angle_bins;        /* 30 */
     int max_batch;         /* frames per forward call */
     int img_h, img_w;      /* network input size, e.g. 800 x 1066 for a 640x480 frame (transforms.py:78-96) */
+    int dtype;             /* 0: fp32 everywhere (parity mode).  1: bf16 weights + activations in memory, bf16 MFMA
+                              with fp32 accumulation, fp32 softmax / LayerNorm / head outputs (BASELINE config 4) */
 } odam_detr_cfg;
 
 int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out);
@@ -93,6 +95,11 @@ int odam_detr_profile_read_attention(odam_detr* m, int* n_launches, double* tota
 int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const float* scale, const float* bias,
                         const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                         int stride, int pad, int Kpad, int relu, void* stream);
+/* same kernel in bf16 mode: x, w_packed, residual, y are raw bfloat16 (Cin a power of two >= 8, Kpad % 64 == 0);
+ * out_f32 != 0 writes y as fp32 */
+int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* scale, const float* bias,
+                             const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
+                             int stride, int pad, int Kpad, int relu, int out_f32, void* stream);
 int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                       int B, int H, int Lq, int Lk, void* stream);
 int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y, int M,

@@ -11,7 +11,8 @@
 // projections, the FFN and the prediction heads (reference: src/models/backbone.py:59-94 via
 // torchvision ResNet, src/models/detr.py:45,70,73-78, src/models/transformer.py:132-238).
 //
-// Matrix core use: v_mfma_f32_32x32x2_f32 (exact fp32 multiply-accumulate, 157 TFLOP/s peak).
+// Matrix core use: v_mfma_f32_32x32x2_f32 (exact fp32 multiply-accumulate, 157 TFLOP/s peak); the bf16 mode
+// (BASELINE config 4) runs the same tiling on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
 // Workgroup = 256 threads = 4 wavefronts; tile BM x BN x 32; A and W tiles staged through LDS
 // with a 4-float row pad (conflict-free ds_read_b128), register-staged double buffering so the
 // global loads of tile t+1 fly under the MFMAs of tile t.
@@ -21,20 +22,25 @@
 
 namespace odam_cg {
 
+constexpr int ODAM_CG_F32 = 0;
+constexpr int ODAM_CG_BF16 = 1;
+
 struct ConvGemmArgs {
-    const float* A;      // NHWC input [B, H, W, Cin], Cin a power of two >= 4
-    const float* Wt;     // [Cout][Kpad], k-major, zero padded to Kpad (multiple of 32)
-    const float* scale;  // [Cout] or nullptr
-    const float* bias;   // [Cout] or nullptr
-    const float* res;    // [M, Cout] or nullptr
-    float* C;            // [M, Cout]
+    const void* A;       // NHWC input [B, H, W, Cin] fp32 or bf16; Cin a power of two >= one 16-byte chunk (4 / 8)
+    const void* Wt;      // [Cout][Kpad] same type, k-major, zero padded to a multiple of the k-tile (32 / 64)
+    const float* scale;  // [Cout] fp32 or nullptr
+    const float* bias;   // [Cout] fp32 or nullptr
+    const void* res;     // [M, Cout] activation type, or nullptr
+    void* C;             // [M, Cout] activation type (fp32 when out_f32)
     int B, H, W, Cin, log2Cin;
     int Ho, Wo, Cout;
     int KH, KW, stride, pad;
     int Kpad;
     int relu;
     int M;
-    int ldc;             // row stride of C / res in floats (>= Cout)
+    int ldc;             // row stride of C / res in elements (>= Cout)
+    int dtype;           // ODAM_CG_F32 / ODAM_CG_BF16: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, fp32 accumulate
+    int out_f32;         // bf16 mode only: write C as fp32
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);

@@ -8,23 +8,34 @@
 namespace odam_cg {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 4;  // 144-byte rows: 16-byte aligned, conflict-free for ds_read_b128
+// One k-tile is 8 chunks of 16 bytes per row in both precisions: 32 fp32 or 64 bf16 values; LDS rows are
+// padded by one chunk (144-byte rows: 16-byte aligned, conflict-free for ds_read_b128).
+constexpr int LDS_STRIDE = 36;  // floats per LDS row
 
-template <int BM, int BN, int WM, int WN>
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+template <int BM, int BN, int WM, int WN, bool BF16>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a) {
-    constexpr int NTH = 64 * WM * WN;  // threads per workgroup
-    constexpr int RPP = NTH / 8;       // tile rows staged per pass (8 float4 per 32-float row)
-    constexpr int TM = BM / WM / 32;   // 32x32 MFMA tiles per wave along M
+    using T = typename std::conditional<BF16, unsigned short, float>::type;
+    constexpr int EPC = BF16 ? 8 : 4;   // elements per 16-byte chunk
+    constexpr int BKE = 8 * EPC;        // elements per k-tile (32 fp32 / 64 bf16)
+    constexpr int NTH = 64 * WM * WN;   // threads per workgroup
+    constexpr int RPP = NTH / 8;        // tile rows staged per pass (8 chunks per row)
+    constexpr int TM = BM / WM / 32;    // 32x32 MFMA tiles per wave along M
     constexpr int TN = BN / WN / 32;
-    constexpr int A_LD = BM / RPP;     // float4 loads per thread for the A tile
+    constexpr int A_LD = BM / RPP;      // 16-byte loads per thread for the A tile
     constexpr int B_LD = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows divide over the loader threads");
 
     __shared__ __align__(16) float smem[2 * (BM + BN) * LDS_STRIDE];   // 36 / 54 / 72 KiB, static
     float* As = smem;                         // [2][BM][LDS_STRIDE]
     float* Bs = smem + 2 * BM * LDS_STRIDE;   // [2][BN][LDS_STRIDE]
+
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(a.A);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(a.Wt);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -44,7 +55,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-thread gather bookkeeping (rows are fixed over the K loop) ---------------------
-    const int c4 = tid & 7;    // which float4 of the 32-wide k slice
+    const int c4 = tid & 7;    // which 16-byte chunk of the k slice
     const int r0 = tid >> 3;   // 0..RPP-1
     int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
     bool a_ok[A_LD];
@@ -62,20 +73,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         a_ix0[i] = ox * a.stride - a.pad;
         a_base[i] = ((b * a.H + a_iy0[i]) * a.W + a_ix0[i]) * a.Cin;
     }
-    const float* w_ptr[B_LD];
+    const T* w_ptr[B_LD];
     bool b_ok[B_LD];
 #pragma unroll
     for (int i = 0; i < B_LD; i++) {
         const int n = n0 + r0 + RPP * i;
         b_ok[i] = n < a.Cout;
-        w_ptr[i] = a.Wt + (size_t)(b_ok[i] ? n : 0) * a.Kpad + c4 * 4;
+        w_ptr[i] = Wg + (size_t)(b_ok[i] ? n : 0) * a.Kpad + c4 * EPC;
     }
     const int ntaps = a.KH * a.KW;
     const int kw_inv = (65536 + a.KW - 1) / a.KW;  // tap / KW for tap < 64, KW <= 7
 
     float4 ra[A_LD], rb[B_LD];
     auto load_tile = [&](int kt) {
-        const int k0 = kt * BK + c4 * 4;
+        const int k0 = kt * BKE + c4 * EPC;
         const int tap = k0 >> a.log2Cin;
         const int ci = k0 & (a.Cin - 1);
         const int ky = (tap * kw_inv) >> 16;
@@ -86,11 +97,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         for (int i = 0; i < A_LD; i++) {
             const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
             const bool ok = a_ok[i] && tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            ra[i] = ok ? *reinterpret_cast<const float4*>(a.A + (size_t)(a_base[i] + koff)) : float4{0.f, 0.f, 0.f, 0.f};
+            ra[i] = ok ? *reinterpret_cast<const float4*>(Ag + (size_t)(a_base[i] + koff)) : float4{0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < B_LD; i++)
-            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(w_ptr[i] + kt * BK) : float4{0.f, 0.f, 0.f, 0.f};
+            rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(w_ptr[i] + kt * BKE) : float4{0.f, 0.f, 0.f, 0.f};
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
@@ -109,11 +120,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    const int nk = a.Kpad / BK;
+    const int nk = a.Kpad / BKE;
     load_tile(0);
     store_tile(0);
     __syncthreads();
 
+    // Operand fragments: lane (row = lane & 31, half = lane >> 5) reads the 16-byte chunk 2 g + half of its row for
+    // k-group g = 0..3.  fp32: 4 values = the k slots of four v_mfma_f32_32x32x2_f32 steps (A and B use the same
+    // (step, half) -> k map, so the k order inside a group is free).  bf16: 8 values = exactly the operand of one
+    // v_mfma_f32_32x32x16_bf16 (lane half h holds k = 8 h + j).
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
     for (int kt = 0; kt < nk; ++kt) {
@@ -129,9 +144,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE);
         if (kt + 1 < nk) load_tile(kt + 1);
 #pragma unroll
-        for (int q = 0; q < BK / 8; q++) {
+        for (int q = 0; q < 4; q++) {
             const int pb = q & 1;
-            if (q + 1 < BK / 8) {
+            if (q + 1 < 4) {
 #pragma unroll
                 for (int i = 0; i < TM; i++)
                     af[pb ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + (q + 1) * 8);
@@ -143,10 +158,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].x, bf[pb][j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].y, bf[pb][j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].z, bf[pb][j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].w, bf[pb][j].w, acc[i][j], 0, 0, 0);
+                    if constexpr (BF16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[pb][i]),
+                                                                            __builtin_bit_cast(bf16x8, bf[pb][j]),
+                                                                            acc[i][j], 0, 0, 0);
+                    } else {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].x, bf[pb][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].y, bf[pb][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].z, bf[pb][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[pb][i].w, bf[pb][j].w, acc[i][j], 0, 0, 0);
+                    }
                 }
         }
         if (kt + 1 < nk) store_tile(cur ^ 1);
@@ -154,22 +175,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     }
 
     // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
+    // bf16 mode: residual and output are bf16 unless out_f32 asks for an fp32 result (the prediction heads).
     const int half = lane >> 5;
-    const float* __restrict__ resp = a.res;
-    float* __restrict__ outp = a.C;
+    const bool res_f32 = !BF16;
+    const bool out_f32 = !BF16 || a.out_f32;
+    auto load_res1 = [&](size_t idx) -> float {
+        return res_f32 ? reinterpret_cast<const float*>(a.res)[idx]
+                       : bf2f(reinterpret_cast<const unsigned short*>(a.res)[idx]);
+    };
+    auto store1 = [&](size_t idx, float v) {
+        if (out_f32) reinterpret_cast<float*>(a.C)[idx] = v;
+        else reinterpret_cast<unsigned short*>(a.C)[idx] = f2bf(v);
+    };
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;   // this wave's sub-tile
     if ((a.Cout & 3) == 0 && (a.ldc & 3) == 0) {
         // Wide path: the accumulator layout (one column per lane) would give 4-byte accesses; the sub-tile is
         // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
-        // 16-byte residual loads and 16-byte stores, 256 contiguous bytes per 16 lanes.
+        // 16-byte (fp32) / 8-byte (bf16) residual loads and stores, 256 / 128 contiguous bytes per 16 lanes.
         constexpr int EP_LD = WCOLS + 4;
         static_assert(WM * WN * 32 * EP_LD <= 2 * (BM + BN) * LDS_STRIDE, "epilogue staging fits the tile buffers");
         float* Ep = smem + wave * (32 * EP_LD);     // one 32-row slab per wave, reused for each of its TM row tiles
         constexpr int LPR = WCOLS / 4;              // lanes per row
         constexpr int RPI = 64 / LPR;               // rows per wave-instruction
         constexpr int NIT = 32 / RPI;
-        const int c4 = (lane % LPR) * 4;
-        const int n = n0 + wn * WCOLS + c4;
+        const int c4e = (lane % LPR) * 4;
+        const int n = n0 + wn * WCOLS + c4e;
         const bool n_ok = n < a.Cout;               // Cout % 4 == 0: the four channels are in or out together
         float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
         if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
@@ -180,8 +210,16 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 #pragma unroll
             for (int it = 0; it < NIT; it++) {   // residual rows of this slab: issued before the LDS round trip
                 const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
-                rv[it] = (resp && n_ok && m < a.M) ? *reinterpret_cast<const float4*>(resp + (size_t)m * a.ldc + n)
-                                                   : float4{0.f, 0.f, 0.f, 0.f};
+                rv[it] = float4{0.f, 0.f, 0.f, 0.f};
+                if (a.res && n_ok && m < a.M) {
+                    const size_t idx = (size_t)m * a.ldc + n;
+                    if (res_f32) {
+                        rv[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + idx);
+                    } else {
+                        const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(a.res) + idx);
+                        rv[it] = float4{bf2f(u.x), bf2f(u.y), bf2f(u.z), bf2f(u.w)};
+                    }
+                }
             }
             if (i > 0) __syncthreads();          // previous slab fully read before it is overwritten
 #pragma unroll
@@ -194,7 +232,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             for (int it = 0; it < NIT; it++) {
                 const int row = it * RPI + lane / LPR;
                 const int m = m0 + wm * WROWS + i * 32 + row;
-                const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4]);
+                const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
                 float4 o;
                 o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
                 o.x += rv[it].x; o.y += rv[it].y; o.z += rv[it].z; o.w += rv[it].w;
@@ -202,7 +240,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
                     o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
                     o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
                 }
-                if (n_ok && m < a.M) *reinterpret_cast<float4*>(outp + (size_t)m * a.ldc + n) = o;
+                if (n_ok && m < a.M) {
+                    const size_t idx = (size_t)m * a.ldc + n;
+                    if (out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + idx) = o;
+                    } else {
+                        ushort4 u = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+                        *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + idx) = u;
+                    }
+                }
             }
         }
         return;
@@ -222,7 +268,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int m = mb + (r & 3) + 8 * (r >> 2);
-                rv[r] = (resp && n_ok && m < a.M) ? resp[(size_t)m * a.ldc + n] : 0.0f;
+                rv[r] = (a.res && n_ok && m < a.M) ? load_res1((size_t)m * a.ldc + n) : 0.0f;
             }
 #pragma unroll
             for (int r = 0; r < 16; r++) {
@@ -230,7 +276,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
                 float v = acc[i][j][r] * sc + bi;
                 v += rv[r];
                 if (a.relu) v = v > 0.0f ? v : 0.0f;
-                if (n_ok && m < a.M) outp[(size_t)m * a.ldc + n] = v;
+                if (n_ok && m < a.M) store1((size_t)m * a.ldc + n, v);
             }
         }
     }
@@ -239,20 +285,23 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
+    if (a.dtype == ODAM_CG_BF16)
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
+    else
+        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
-    if (a.Kpad % BK != 0 || a.Cin < 4 || (a.Cin & (a.Cin - 1)) != 0 || a.KW > 7 || a.KH * a.KW > 64)
-        return odam_fail(1, "conv_gemm: unsupported shape (Kpad % 32, Cin power of two >= 4, KW <= 7)");
+    const int epc = (a.dtype == ODAM_CG_BF16) ? 8 : 4;
+    if (a.Kpad % (8 * epc) != 0 || a.Cin < epc || (a.Cin & (a.Cin - 1)) != 0 || a.KW > 7 || a.KH * a.KW > 64)
+        return odam_fail(1, "conv_gemm: unsupported shape (Kpad % k-tile, Cin a power of two >= one 16-byte chunk, KW <= 7)");
     if (a.M <= 0 || a.Cout <= 0) return 0;
     static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 3;  // 8-wave tiles (+2-3 %)
     if (a.Cout <= 64) return (variant & 2) ? launch_cfg<128, 64, 4, 2>(a, stream) : launch_cfg<128, 64, 4, 1>(a, stream);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
     if (tiles128 < 128) return launch_cfg<64, 64, 2, 2>(a, stream);
-    if ((variant & 4) && tiles128 >= 2048) return launch_cfg<256, 128, 4, 2>(a, stream);
     if (variant & 1) return launch_cfg<128, 128, 4, 2>(a, stream);
     return launch_cfg<128, 128, 2, 2>(a, stream);
 }

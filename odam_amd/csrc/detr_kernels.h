@@ -1,5 +1,6 @@
 // detr_kernels.h -- launchers of the non-GEMM detector kernels (attention, normalisation, layout,
-// pooling, post-processing).  All tensors are fp32, row-major, batch-major ([B, L, C] / NHWC).
+// pooling, post-processing).  Row-major, batch-major ([B, L, C] / NHWC) tensors; `dtype` 0 = fp32 activations,
+// 1 = bf16 activations in memory (arithmetic stays fp32; BASELINE config 4).  Tables (pos, gamma, beta) are fp32.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -8,25 +9,29 @@ namespace odam_dk {
 // Fused multi-head attention, head dim 32 (hidden 256 / 8 heads, transformer.py:138-139):
 //   O[b, q, h*32:(h+1)*32] = softmax_k( (Q[b,q,h] / sqrt(32)) . K[b,k,h] ) V[b,k,h]
 // Q/K/V/O are addressed as base + (b*L + row) * ld + h*32, so fused projection buffers work.
-int launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
-                     int B, int H, int Lq, int Lk, hipStream_t stream);
+int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                     int B, int H, int Lq, int Lk, int dtype, hipStream_t stream);
 
 // y = LayerNorm(x + r) * gamma + beta over C = 256 (eps 1e-5); r may be null.
 // If y_pos != null also writes y_pos = y + pos[row % L]  (the next layer's q/k input).
-int launch_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y,
-                         const float* pos, int L, float* y_pos, int M, hipStream_t stream);
+int launch_add_layernorm(const void* x, const void* r, const float* gamma, const float* beta, void* y,
+                         const float* pos, int L, void* y_pos, int M, int dtype, hipStream_t stream);
 
 // out[m] = (x ? x[m] : 0) + pos[m % L], rows of 256 floats
-int launch_add_pos(const float* x, const float* pos, int L, float* out, int M, hipStream_t stream);
+int launch_add_pos(const void* x, const float* pos, int L, void* out, int M, int dtype, hipStream_t stream);
 
-// [B,3,H,W] -> [B,H,W,4] (4th channel zero)
-int launch_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t stream);
+// fp32 [B,3,H,W] -> [B,H,W,4] fp32 (4th channel zero) or [B,H,W,8] bf16 (one 16-byte chunk per pixel)
+int launch_nchw_to_nhwc4(const float* in, void* out, int B, int H, int W, int dtype, hipStream_t stream);
 
 // NHWC max-pool 3x3 stride 2 pad 1 (torchvision ResNet stem)
-int launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t stream);
+int launch_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, int dtype,
+                        hipStream_t stream);
 
 // NHWC [B,H,W,C] -> NCHW [B,C,H,W]  (only for exposing intermediate features to tests)
-int launch_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream);
+int launch_nhwc_to_nchw(const void* in, float* out, int B, int H, int W, int C, int dtype, hipStream_t stream);
+
+// activation buffer (n elements, n % 4 == 0) -> fp32 copy
+int launch_to_f32(const void* in, float* out, size_t n, int dtype, hipStream_t stream);
 
 int launch_sigmoid(float* x, int n, hipStream_t stream);
 

@@ -6,6 +6,23 @@
 namespace odam_dk {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned short bf16_t;   // raw bfloat16 bits (bf16 mode: activations in HBM are bf16, arithmetic stays fp32)
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    const ushort4 u = *reinterpret_cast<const ushort4*>(p);
+    return float4{bf2f(u.x), bf2f(u.y), bf2f(u.z), bf2f(u.w)};
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    *reinterpret_cast<ushort4*>(p) = ushort4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+}
+#define ODAM_DISPATCH(dtype, KERNEL, ...)                                                  \
+    do {                                                                                  \
+        if ((dtype) == 1) { KERNEL(bf16_t, __VA_ARGS__); } else { KERNEL(float, __VA_ARGS__); } \
+    } while (0)
 
 // =================================================================================================
 // Fused attention, d_head = 32, fp32 on v_mfma_f32_32x32x2_f32.
@@ -28,10 +45,11 @@ constexpr int ATT_LD = ATT_D + 4;   // LDS row stride (floats)
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-__global__ __launch_bounds__(256) void attention_kernel(const float* __restrict__ Q, int ldq,
-                                                        const float* __restrict__ K, int ldk,
-                                                        const float* __restrict__ V, int ldv,
-                                                        float* __restrict__ O, int ldo, int Lq, int Lk) {
+template <typename T>
+__global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q, int ldq,
+                                                        const T* __restrict__ K, int ldk,
+                                                        const T* __restrict__ V, int ldv,
+                                                        T* __restrict__ O, int ldo, int Lq, int Lk) {
     __shared__ __align__(16) float Ks[2][ATT_KT][ATT_LD];
     __shared__ __align__(16) float Vs[2][ATT_KT][ATT_LD];
 
@@ -39,9 +57,9 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int half = lane >> 5, col = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const float* Qb = Q + (size_t)b * Lq * ldq + h * ATT_D;
-    const float* Kb = K + (size_t)b * Lk * ldk + h * ATT_D;
-    const float* Vb = V + (size_t)b * Lk * ldv + h * ATT_D;
+    const T* Qb = Q + (size_t)b * Lq * ldq + h * ATT_D;
+    const T* Kb = K + (size_t)b * Lk * ldk + h * ATT_D;
+    const T* Vb = V + (size_t)b * Lk * ldv + h * ATT_D;
 
     // this lane's 16 query channels d = 16*half + s, pre-scaled by sqrt(1/32)
     float qreg[16];
@@ -50,8 +68,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
         const float scale = (float)0.1767766952966369;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
-            float4 v = (q < Lq) ? *reinterpret_cast<const float4*>(Qb + (size_t)q * ldq + 16 * half + 4 * g)
-                                : float4{0.f, 0.f, 0.f, 0.f};
+            float4 v = (q < Lq) ? ld4(Qb + (size_t)q * ldq + 16 * half + 4 * g) : float4{0.f, 0.f, 0.f, 0.f};
             qreg[4 * g + 0] = v.x * scale; qreg[4 * g + 1] = v.y * scale;
             qreg[4 * g + 2] = v.z * scale; qreg[4 * g + 3] = v.w * scale;
         }
@@ -61,8 +78,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     auto load_kv = [&](int kt, float4& kv, float4& vv) {
         const int key = kt * ATT_KT + lr;
         if (key < Lk) {
-            kv = *reinterpret_cast<const float4*>(Kb + (size_t)key * ldk + lc);
-            vv = *reinterpret_cast<const float4*>(Vb + (size_t)key * ldv + lc);
+            kv = ld4(Kb + (size_t)key * ldk + lc);
+            vv = ld4(Vb + (size_t)key * ldv + lc);
         } else {
             kv = float4{0.f, 0.f, 0.f, 0.f};
             vv = float4{0.f, 0.f, 0.f, 0.f};
@@ -138,20 +155,22 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* __restrict_
     const int q = q0 + col;
     if (q < Lq) {
         const float inv = 1.0f / l_run;
-        float* Ob = O + ((size_t)b * Lq + q) * ldo + h * ATT_D;
+        T* Ob = O + ((size_t)b * Lq + q) * ldo + h * ATT_D;
 #pragma unroll
         for (int g = 0; g < 4; g++) {
             float4 v = {oacc[4 * g + 0] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
-            *reinterpret_cast<float4*>(Ob + 8 * g + 4 * half) = v;  // channels acc_row(4g..4g+3, half)
+            st4(Ob + 8 * g + 4 * half, v);  // channels acc_row(4g..4g+3, half)
         }
     }
 }
 
-int launch_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
-                     int B, int H, int Lq, int Lk, hipStream_t stream) {
+int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                     int B, int H, int Lq, int Lk, int dtype, hipStream_t stream) {
     if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
     dim3 grid((Lq + 127) / 128, H, B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk);
+#define ODAM_K(T, ...) hipLaunchKernelGGL(attention_kernel<T>, grid, dim3(256), 0, stream, (const T*)Q, ldq, (const T*)K, ldk, (const T*)V, ldv, (T*)O, ldo, Lq, Lk)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -166,17 +185,18 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-__global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restrict__ x, const float* __restrict__ r,
+template <typename T>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const T* __restrict__ x, const T* __restrict__ r,
                                                             const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            const float* __restrict__ beta, T* __restrict__ y,
                                                             const float* __restrict__ pos, int L,
-                                                            float* __restrict__ y_pos, int M) {
+                                                            T* __restrict__ y_pos, int M) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= M) return;
-    float4 v = *reinterpret_cast<const float4*>(x + (size_t)row * 256 + lane * 4);
+    float4 v = ld4(x + (size_t)row * 256 + lane * 4);
     if (r) {
-        const float4 t = *reinterpret_cast<const float4*>(r + (size_t)row * 256 + lane * 4);
+        const float4 t = ld4(r + (size_t)row * 256 + lane * 4);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
     }
     const float mean = wave_sum((v.x + v.y) + (v.z + v.w)) * (1.0f / 256.0f);
@@ -186,40 +206,44 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const float* __restr
     const float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4);
     const float4 be = *reinterpret_cast<const float4*>(beta + lane * 4);
     float4 o = {dx * rstd * g.x + be.x, dy * rstd * g.y + be.y, dz * rstd * g.z + be.z, dw * rstd * g.w + be.w};
-    *reinterpret_cast<float4*>(y + (size_t)row * 256 + lane * 4) = o;
+    st4(y + (size_t)row * 256 + lane * 4, o);
     if (y_pos) {
         const float4 p = *reinterpret_cast<const float4*>(pos + (size_t)(row % L) * 256 + lane * 4);
         float4 o2 = {o.x + p.x, o.y + p.y, o.z + p.z, o.w + p.w};
-        *reinterpret_cast<float4*>(y_pos + (size_t)row * 256 + lane * 4) = o2;
+        st4(y_pos + (size_t)row * 256 + lane * 4, o2);
     }
 }
 
-int launch_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y,
-                         const float* pos, int L, float* y_pos, int M, hipStream_t stream) {
+int launch_add_layernorm(const void* x, const void* r, const float* gamma, const float* beta, void* y,
+                         const float* pos, int L, void* y_pos, int M, int dtype, hipStream_t stream) {
     if (M <= 0) return 0;
-    hipLaunchKernelGGL(add_layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, x, r, gamma, beta, y, pos, L,
-                       y_pos, M);
+#define ODAM_K(T, ...) hipLaunchKernelGGL(add_layernorm_kernel<T>, dim3((M + 3) / 4), dim3(256), 0, stream, (const T*)x, (const T*)r, gamma, beta, (T*)y, pos, L, (T*)y_pos, M)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
     ODAM_HIP(hipGetLastError());
     return 0;
 }
 
-__global__ __launch_bounds__(256) void add_pos_kernel(const float* __restrict__ x, const float* __restrict__ pos,
-                                                      int L, float* __restrict__ out, int M) {
+template <typename T>
+__global__ __launch_bounds__(256) void add_pos_kernel(const T* __restrict__ x, const float* __restrict__ pos,
+                                                      int L, T* __restrict__ out, int M) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // float4 index
     if (i >= (size_t)M * 64) return;
     const int row = (int)(i >> 6), c4 = (int)(i & 63);
     float4 p = *reinterpret_cast<const float4*>(pos + (size_t)(row % L) * 256 + c4 * 4);
     if (x) {
-        const float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+        const float4 v = ld4(x + i * 4);
         p.x += v.x; p.y += v.y; p.z += v.z; p.w += v.w;
     }
-    *reinterpret_cast<float4*>(out + i * 4) = p;
+    st4(out + i * 4, p);
 }
 
-int launch_add_pos(const float* x, const float* pos, int L, float* out, int M, hipStream_t stream) {
+int launch_add_pos(const void* x, const float* pos, int L, void* out, int M, int dtype, hipStream_t stream) {
     if (M <= 0) return 0;
     const size_t n4 = (size_t)M * 64;
-    hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, pos, L, out, M);
+#define ODAM_K(T, ...) hipLaunchKernelGGL(add_pos_kernel<T>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const T*)x, pos, L, (T*)out, M)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -227,26 +251,34 @@ int launch_add_pos(const float* x, const float* pos, int L, float* out, int M, h
 // =================================================================================================
 // layout / pooling
 // =================================================================================================
-__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restrict__ in, T* __restrict__ out,
                                                             int HW, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // pixel index over B*H*W
     if (i >= total) return;
     const size_t b = i / HW, p = i - b * HW;
     const float* s = in + b * 3 * (size_t)HW + p;
     float4 v = {s[0], s[HW], s[2 * (size_t)HW], 0.0f};
-    *reinterpret_cast<float4*>(out + i * 4) = v;
+    if constexpr (sizeof(T) == 2) {      // bf16: one 16-byte chunk = 8 channels per pixel (3 real + 5 zero)
+        st4(out + i * 8, v);
+        st4(out + i * 8 + 4, float4{0.f, 0.f, 0.f, 0.f});
+    } else {
+        st4(out + i * 4, v);
+    }
 }
 
-int launch_nchw_to_nhwc4(const float* in, float* out, int B, int H, int W, hipStream_t stream) {
+int launch_nchw_to_nhwc4(const float* in, void* out, int B, int H, int W, int dtype, hipStream_t stream) {
     const size_t total = (size_t)B * H * W;
     if (!total) return 0;
-    hipLaunchKernelGGL(nchw_to_nhwc4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out,
-                       H * W, total);
+#define ODAM_K(T, ...) hipLaunchKernelGGL(nchw_to_nhwc4_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, (T*)out, H * W, total)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
     ODAM_HIP(hipGetLastError());
     return 0;
 }
 
-__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ in, float* __restrict__ out, int H,
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_kernel(const T* __restrict__ in, T* __restrict__ out, int H,
                                                       int W, int C4, int Ho, int Wo, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // over B*Ho*Wo*C4
     if (i >= total) return;
@@ -264,37 +296,58 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
         for (int dx = 0; dx < 3; dx++) {
             const int ix = ox * 2 - 1 + dx;
             if ((unsigned)ix >= (unsigned)W) continue;
-            const float4 v = *reinterpret_cast<const float4*>(in + (((b * H + iy) * W + ix) * (size_t)C4 + c4) * 4);
+            const float4 v = ld4(in + (((b * H + iy) * W + ix) * (size_t)C4 + c4) * 4);
             m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
         }
     }
-    *reinterpret_cast<float4*>(out + i * 4) = m;
+    st4(out + i * 4, m);
 }
 
-int launch_maxpool3x3s2(const float* in, float* out, int B, int H, int W, int C, int Ho, int Wo, hipStream_t stream) {
+int launch_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, int dtype,
+                        hipStream_t stream) {
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     if (!total) return 0;
-    hipLaunchKernelGGL(maxpool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, H, W,
-                       C / 4, Ho, Wo, total);
+#define ODAM_K(T, ...) hipLaunchKernelGGL(maxpool_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const T*)in, (T*)out, H, W, C / 4, Ho, Wo, total)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
     ODAM_HIP(hipGetLastError());
     return 0;
 }
 
-__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out,
                                                            int HW, int C, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // output index over B*C*HW
     if (i >= total) return;
     const size_t p = i % HW;
     const size_t c = (i / HW) % C;
     const size_t b = i / ((size_t)HW * C);
-    out[i] = in[(b * HW + p) * C + c];
+    if constexpr (sizeof(T) == 2) out[i] = bf2f(in[(b * HW + p) * C + c]);
+    else out[i] = in[(b * HW + p) * C + c];
 }
 
-int launch_nhwc_to_nchw(const float* in, float* out, int B, int H, int W, int C, hipStream_t stream) {
+int launch_nhwc_to_nchw(const void* in, float* out, int B, int H, int W, int C, int dtype, hipStream_t stream) {
     const size_t total = (size_t)B * H * W * C;
     if (!total) return 0;
-    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out,
-                       H * W, C, total);
+#define ODAM_K(T, ...) hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const T*)in, out, H * W, C, total)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_f32_kernel(const T* __restrict__ in, float* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) *reinterpret_cast<float4*>(out + i * 4) = ld4(in + i * 4);
+}
+
+int launch_to_f32(const void* in, float* out, size_t n, int dtype, hipStream_t stream) {
+    const size_t n4 = n / 4;
+    if (!n4) return 0;
+#define ODAM_K(T, ...) hipLaunchKernelGGL(to_f32_kernel<T>, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, (const T*)in, out, n4)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
     ODAM_HIP(hipGetLastError());
     return 0;
 }

@@ -29,7 +29,7 @@ struct HostTensor {
 };
 
 struct Conv {          // packed convolution / linear layer on device
-    float* w = nullptr;      // [Cout][Kpad]
+    void* w = nullptr;       // [Cout][Kpad], fp32 or bf16
     float* scale = nullptr;  // [Cout] or null
     float* bias = nullptr;   // [Cout] or null
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
@@ -72,14 +72,16 @@ struct odam_detr {
     // geometry
     int H1, W1, H2, W2, fh, fw, L;
 
-    // workspace
-    float *x4 = nullptr, *stem_out = nullptr, *bufA = nullptr, *bufB = nullptr, *t1 = nullptr, *t2 = nullptr,
-          *dsb = nullptr;
-    float *src = nullptr, *srcpos = nullptr, *qk = nullptr, *v = nullptr, *att = nullptr, *tmp = nullptr, *ffn = nullptr;
-    float *kc = nullptr, *vc = nullptr;
-    float *tgt = nullptr, *tgtpos = nullptr, *dqk = nullptr, *dv = nullptr, *datt = nullptr, *dq = nullptr,
-          *dtmp = nullptr, *dffn = nullptr, *hs = nullptr, *h1 = nullptr, *h2 = nullptr;
-    const float* layer4 = nullptr;  // where the last forward left the layer4 map (NHWC)
+    // workspace (activations: fp32 or bf16 according to cfg.dtype; sizes in bytes = elements * es)
+    char *x4 = nullptr, *stem_out = nullptr, *bufA = nullptr, *bufB = nullptr, *t1 = nullptr, *t2 = nullptr,
+         *dsb = nullptr;
+    char *src = nullptr, *srcpos = nullptr, *qk = nullptr, *v = nullptr, *att = nullptr, *tmp = nullptr, *ffn = nullptr;
+    char *kc = nullptr, *vc = nullptr;
+    char *tgt = nullptr, *tgtpos = nullptr, *dqk = nullptr, *dv = nullptr, *datt = nullptr, *dq = nullptr,
+         *dtmp = nullptr, *dffn = nullptr, *hs = nullptr, *h1 = nullptr, *h2 = nullptr;
+    const char* layer4 = nullptr;  // where the last forward left the layer4 map (NHWC)
+    int es = 4;                    // bytes per activation / weight element
+    int dt = 0;                    // 0 fp32, 1 bf16
 
     // optional per-launch timing of the contraction kernel (bench.py roofline): event pairs around every
     // conv_gemm launch of a forward, read back by odam_detr_profile_read
@@ -102,6 +104,22 @@ struct odam_detr {
         ODAM_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
         return 0;
     }
+    // weights in the model's element type: fp32 as is, bf16 rounded to nearest even on the host
+    int upload_w(void** p, const std::vector<float>& v) {
+        if (dt == 0) return upload((float**)p, v);
+        std::vector<unsigned short> h(v.size());
+        for (size_t i = 0; i < v.size(); i++) {
+            unsigned u;
+            std::memcpy(&u, &v[i], 4);
+            if ((u & 0x7fffffffu) > 0x7f800000u) h[i] = (unsigned short)((u >> 16) | 0x40);  // NaN stays NaN
+            else h[i] = (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        unsigned short* d = nullptr;
+        if (int rc = dev_alloc(&d, h.size())) return rc;
+        ODAM_HIP(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        *p = d;
+        return 0;
+    }
 };
 
 namespace {
@@ -122,9 +140,10 @@ const HostTensor* find(odam_detr* m, const std::string& name) {
 int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad) {
     const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
     const int KH = w.shape.size() > 2 ? (int)w.shape[2] : 1, KW = w.shape.size() > 3 ? (int)w.shape[3] : 1;
-    const int CinP = (Cin + 3) / 4 * 4;
+    const int epc = m->dt ? 8 : 4;             // elements per 16-byte chunk
+    const int CinP = (Cin + epc - 1) / epc * epc;
     const int K = KH * KW * CinP;
-    const int Kpad = (K + 31) / 32 * 32;
+    const int Kpad = (K + 8 * epc - 1) / (8 * epc) * (8 * epc);
     std::vector<float> p((size_t)Cout * Kpad, 0.0f);
     for (int o = 0; o < Cout; o++)
         for (int ci = 0; ci < Cin; ci++)
@@ -132,7 +151,7 @@ int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad) {
                 for (int kx = 0; kx < KW; kx++)
                     p[(size_t)o * Kpad + (ky * KW + kx) * CinP + ci] = w.data[(((size_t)o * Cin + ci) * KH + ky) * KW + kx];
     c.Cin = CinP; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
-    return m->upload(&c.w, p);
+    return m->upload_w(&c.w, p);
 }
 
 // rows [r0, r1) of a [N, K] Linear weight (+ bias) as a 1x1 layer
@@ -140,7 +159,7 @@ int pack_linear(odam_detr* m, Conv& c, const HostTensor& w, const HostTensor* b,
     const int K = (int)w.shape[1];
     std::vector<float> p(w.data.begin() + (size_t)r0 * K, w.data.begin() + (size_t)r1 * K);
     c.Cin = K; c.Cout = r1 - r0; c.KH = c.KW = 1; c.stride = 1; c.pad = 0; c.Kpad = K;
-    if (int rc = m->upload(&c.w, p)) return rc;
+    if (int rc = m->upload_w(&c.w, p)) return rc;
     if (b) {
         std::vector<float> bb(b->data.begin() + r0, b->data.begin() + r1);
         if (int rc = m->upload(&c.bias, bb)) return rc;
@@ -169,9 +188,10 @@ int pack_ln(odam_detr* m, LN& ln, const std::string& prefix) {
     return m->upload(&ln.b, b->data);
 }
 
-int run_conv(const Conv& c, const float* x, int B, int H, int W, const float* res, bool relu, float* y, int ldc,
-             hipStream_t st) {
+int run_conv(const Conv& c, const void* x, int B, int H, int W, const void* res, bool relu, void* y, int ldc,
+             hipStream_t st, int dtype = 0, int out_f32 = 0) {
     ConvGemmArgs a{};
+    a.dtype = dtype; a.out_f32 = out_f32;
     a.A = x; a.Wt = c.w; a.scale = c.scale; a.bias = c.bias; a.res = res; a.C = y;
     a.B = B; a.H = H; a.W = W; a.Cin = c.Cin; a.log2Cin = ilog2(c.Cin);
     a.Ho = conv_out(H, c.KH, c.stride, c.pad); a.Wo = conv_out(W, c.KW, c.stride, c.pad);
@@ -181,14 +201,15 @@ int run_conv(const Conv& c, const float* x, int B, int H, int W, const float* re
 }
 
 // y[M, Cout] = x[M, K] W^T + b (+ res) (relu)
-int run_linear(const Conv& c, const float* x, int M, const float* res, bool relu, float* y, int ldc, hipStream_t st) {
-    return run_conv(c, x, 1, 1, M, res, relu, y, ldc, st);
+int run_linear(const Conv& c, const void* x, int M, const void* res, bool relu, void* y, int ldc, hipStream_t st,
+               int dtype = 0, int out_f32 = 0) {
+    return run_conv(c, x, 1, 1, M, res, relu, y, ldc, st, dtype, out_f32);
 }
 
 // timed variants used by the forward: identical launches, bracketed by events when profiling is on
-int conv_t(odam_detr* m, const Conv& c, const float* x, int B, int H, int W, const float* res, bool relu, float* y,
-           hipStream_t st) {
-    if (!m->profile) return run_conv(c, x, B, H, W, res, relu, y, 0, st);
+int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, const void* res, bool relu, void* y,
+           hipStream_t st, int out_f32 = 0) {
+    if (!m->profile) return run_conv(c, x, B, H, W, res, relu, y, 0, st, m->dt, out_f32);
     if (m->ev_used + 2 > m->ev.size()) {
         for (int k = 0; k < 2; k++) {
             hipEvent_t e;
@@ -201,17 +222,18 @@ int conv_t(odam_detr* m, const Conv& c, const float* x, int B, int H, int W, con
     const int Cin_true = (c.KH == 7) ? 3 : c.Cin;  // the stem's 4th input channel is zero padding
     m->ev_flops[m->ev_used / 2] = 2.0 * B * Ho * Wo * (double)c.Cout * c.KH * c.KW * Cin_true;
     ODAM_HIP(hipEventRecord(m->ev[m->ev_used], st));
-    int rc = run_conv(c, x, B, H, W, res, relu, y, 0, st);
+    int rc = run_conv(c, x, B, H, W, res, relu, y, 0, st, m->dt, out_f32);
     ODAM_HIP(hipEventRecord(m->ev[m->ev_used + 1], st));
     m->ev_used += 2;
     return rc;
 }
-int lin_t(odam_detr* m, const Conv& c, const float* x, int M, const float* res, bool relu, float* y, hipStream_t st) {
-    return conv_t(m, c, x, 1, 1, M, res, relu, y, st);
+int lin_t(odam_detr* m, const Conv& c, const void* x, int M, const void* res, bool relu, void* y, hipStream_t st,
+          int out_f32 = 0) {
+    return conv_t(m, c, x, 1, 1, M, res, relu, y, st, out_f32);
 }
-int att_t(odam_detr* m, const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+int att_t(odam_detr* m, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
           int B, int H, int Lq, int Lk, hipStream_t st) {
-    if (!m->profile) return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, st);
+    if (!m->profile) return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, m->dt, st);
     if (m->aev_used + 2 > m->aev.size()) {
         for (int k = 0; k < 2; k++) {
             hipEvent_t e;
@@ -222,7 +244,7 @@ int att_t(odam_detr* m, const float* Q, int ldq, const float* K, int ldk, const 
     }
     m->aev_flops[m->aev_used / 2] = 4.0 * B * H * (double)Lq * Lk * 32;   // QK^T + PV, 2 flop per MAC
     ODAM_HIP(hipEventRecord(m->aev[m->aev_used], st));
-    int rc = odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, st);
+    int rc = odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, m->dt, st);
     ODAM_HIP(hipEventRecord(m->aev[m->aev_used + 1], st));
     m->aev_used += 2;
     return rc;
@@ -241,8 +263,11 @@ extern "C" int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out) {
     if (cfg->hidden_dim != 256 || cfg->nheads != 8)
         return odam_fail(3, "odam_detr_create: kernels are built for hidden_dim 256, 8 heads (head dim 32)");
     if (cfg->max_batch < 1 || cfg->img_h < 32 || cfg->img_w < 32) return odam_fail(1, "odam_detr_create: bad sizes");
+    if (cfg->dtype != 0 && cfg->dtype != 1) return odam_fail(1, "odam_detr_create: dtype must be 0 (fp32) or 1 (bf16)");
     odam_detr* m = new odam_detr();
     m->cfg = *cfg;
+    m->dt = cfg->dtype;
+    m->es = cfg->dtype ? 2 : 4;
     m->H1 = conv_out(cfg->img_h, 7, 2, 3); m->W1 = conv_out(cfg->img_w, 7, 2, 3);
     m->H2 = conv_out(m->H1, 3, 2, 1); m->W2 = conv_out(m->W1, 3, 2, 1);
     int h = m->H2, w = m->W2;
@@ -376,22 +401,22 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
         if ((int)pe->shape[0] != m->L || (int)pe->shape[1] != E) return odam_fail(1, "pos_embed must be [h*w, hidden_dim]");
         RC(m->upload(&m->pos, pe->data));
     }
-    // workspace
-    const size_t B = c.max_batch;
-    const size_t big = B * m->H2 * m->W2 * 256;
-    RC(m->dev_alloc(&m->x4, B * c.img_h * c.img_w * 4));
-    RC(m->dev_alloc(&m->stem_out, B * m->H1 * m->W1 * 64));
+    // workspace (bytes = elements * es)
+    const size_t B = c.max_batch, es = m->es;
+    const size_t big = B * m->H2 * m->W2 * 256 * es;
+    RC(m->dev_alloc(&m->x4, B * c.img_h * c.img_w * (m->dt ? 8 : 4) * es));
+    RC(m->dev_alloc(&m->stem_out, B * m->H1 * m->W1 * 64 * es));
     RC(m->dev_alloc(&m->bufA, big)); RC(m->dev_alloc(&m->bufB, big)); RC(m->dev_alloc(&m->dsb, big));
     RC(m->dev_alloc(&m->t1, big / 2)); RC(m->dev_alloc(&m->t2, big / 2));
     const size_t M = B * m->L, Mq = B * c.num_queries, F = c.dim_feedforward;
-    RC(m->dev_alloc(&m->src, M * E)); RC(m->dev_alloc(&m->srcpos, M * E)); RC(m->dev_alloc(&m->qk, M * 2 * E));
-    RC(m->dev_alloc(&m->v, M * E)); RC(m->dev_alloc(&m->att, M * E)); RC(m->dev_alloc(&m->tmp, M * E));
-    RC(m->dev_alloc(&m->ffn, M * F));
-    RC(m->dev_alloc(&m->kc, M * c.dec_layers * E)); RC(m->dev_alloc(&m->vc, M * c.dec_layers * E));
-    RC(m->dev_alloc(&m->tgt, Mq * E)); RC(m->dev_alloc(&m->tgtpos, Mq * E)); RC(m->dev_alloc(&m->dqk, Mq * 2 * E));
-    RC(m->dev_alloc(&m->dv, Mq * E)); RC(m->dev_alloc(&m->datt, Mq * E)); RC(m->dev_alloc(&m->dq, Mq * E));
-    RC(m->dev_alloc(&m->dtmp, Mq * E)); RC(m->dev_alloc(&m->dffn, Mq * F)); RC(m->dev_alloc(&m->hs, Mq * E));
-    RC(m->dev_alloc(&m->h1, Mq * E)); RC(m->dev_alloc(&m->h2, Mq * E));
+    RC(m->dev_alloc(&m->src, M * E * es)); RC(m->dev_alloc(&m->srcpos, M * E * es)); RC(m->dev_alloc(&m->qk, M * 2 * E * es));
+    RC(m->dev_alloc(&m->v, M * E * es)); RC(m->dev_alloc(&m->att, M * E * es)); RC(m->dev_alloc(&m->tmp, M * E * es));
+    RC(m->dev_alloc(&m->ffn, M * F * es));
+    RC(m->dev_alloc(&m->kc, M * c.dec_layers * E * es)); RC(m->dev_alloc(&m->vc, M * c.dec_layers * E * es));
+    RC(m->dev_alloc(&m->tgt, Mq * E * es)); RC(m->dev_alloc(&m->tgtpos, Mq * E * es)); RC(m->dev_alloc(&m->dqk, Mq * 2 * E * es));
+    RC(m->dev_alloc(&m->dv, Mq * E * es)); RC(m->dev_alloc(&m->datt, Mq * E * es)); RC(m->dev_alloc(&m->dq, Mq * E * es));
+    RC(m->dev_alloc(&m->dtmp, Mq * E * es)); RC(m->dev_alloc(&m->dffn, Mq * F * es)); RC(m->dev_alloc(&m->hs, Mq * E * es));
+    RC(m->dev_alloc(&m->h1, Mq * E * es)); RC(m->dev_alloc(&m->h2, Mq * E * es));
     m->host.clear();
     m->finalized = true;
     return 0;
@@ -407,14 +432,16 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
     m->ev_used = 0;
     m->aev_used = 0;
     const odam_detr_cfg& c = m->cfg;
-    const int E = c.hidden_dim, Hh = c.nheads, Q = c.num_queries;
+    const int E = c.hidden_dim, Hh = c.nheads, Q = c.num_queries, dt = m->dt;
+    const size_t es = m->es;
+    auto off = [&](char* p, size_t n) { return p + n * es; };   // element offset in the activation type
 
     // ---- backbone (backbone.py:59-94) ----------------------------------------------------------
-    RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, st));
+    RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, dt, st));
     RC(conv_t(m, m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, st));
-    RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, st));
-    float* cur = m->bufA;
-    float* nxt = m->bufB;
+    RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, dt, st));
+    char* cur = m->bufA;
+    char* nxt = m->bufB;
     int H = m->H2, W = m->W2;
     for (size_t i = 0; i < m->blocks.size(); i++) {
         const Bottleneck& b = m->blocks[i];
@@ -422,13 +449,13 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
         const int Ho = conv_out(H, 3, s, 1), Wo = conv_out(W, 3, s, 1);
         RC(conv_t(m, b.c1, cur, B, H, W, nullptr, true, m->t1, st));
         RC(conv_t(m, b.c2, m->t1, B, H, W, nullptr, true, m->t2, st));
-        const float* res = cur;
+        const char* res = cur;
         if (b.has_ds) {
             RC(conv_t(m, b.ds, cur, B, H, W, nullptr, false, m->dsb, st));
             res = m->dsb;
         }
         RC(conv_t(m, b.c3, m->t2, B, Ho, Wo, res, true, nxt, st));
-        float* t = cur; cur = nxt; nxt = t;
+        char* t = cur; cur = nxt; nxt = t;
         H = Ho; W = Wo;
     }
     m->layer4 = cur;
@@ -436,51 +463,53 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
 
     // ---- input_proj + encoder (detr.py:70, transformer.py:154-167) -----------------------------
     RC(conv_t(m, m->input_proj, cur, B, H, W, nullptr, false, m->src, st));
-    RC(odam_dk::launch_add_pos(m->src, m->pos, L, m->srcpos, M, st));
+    RC(odam_dk::launch_add_pos(m->src, m->pos, L, m->srcpos, M, dt, st));
     for (size_t i = 0; i < m->enc.size(); i++) {
         const EncLayer& e = m->enc[i];
         RC(lin_t(m, e.qk, m->srcpos, M, nullptr, false, m->qk, st));
         RC(lin_t(m, e.v, m->src, M, nullptr, false, m->v, st));
-        RC(att_t(m, m->qk, 2 * E, m->qk + E, 2 * E, m->v, E, m->att, E, B, Hh, L, L, st));
+        RC(att_t(m, m->qk, 2 * E, off(m->qk, E), 2 * E, m->v, E, m->att, E, B, Hh, L, L, st));
         RC(lin_t(m, e.out, m->att, M, m->src, false, m->tmp, st));
-        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n1.g, e.n1.b, m->src, nullptr, L, nullptr, M, st));
+        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n1.g, e.n1.b, m->src, nullptr, L, nullptr, M, dt, st));
         RC(lin_t(m, e.l1, m->src, M, nullptr, true, m->ffn, st));
         RC(lin_t(m, e.l2, m->ffn, M, m->src, false, m->tmp, st));
-        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n2.g, e.n2.b, m->src, m->pos, L, m->srcpos, M, st));
+        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n2.g, e.n2.b, m->src, m->pos, L, m->srcpos, M, dt, st));
     }
     // memory = src, memory + pos = srcpos
     RC(lin_t(m, m->cross_k_all, m->srcpos, M, nullptr, false, m->kc, st));
     RC(lin_t(m, m->cross_v_all, m->src, M, nullptr, false, m->vc, st));
 
     // ---- decoder (transformer.py:217-238) --------------------------------------------------------
-    ODAM_HIP(hipMemsetAsync(m->tgt, 0, sizeof(float) * (size_t)Mq * E, st));
-    RC(odam_dk::launch_add_pos(nullptr, m->query_pos, Q, m->tgtpos, Mq, st));
+    ODAM_HIP(hipMemsetAsync(m->tgt, 0, es * (size_t)Mq * E, st));
+    RC(odam_dk::launch_add_pos(nullptr, m->query_pos, Q, m->tgtpos, Mq, dt, st));
     const int ldkv = c.dec_layers * E;
     for (size_t i = 0; i < m->dec.size(); i++) {
         const DecLayer& d = m->dec[i];
         RC(lin_t(m, d.qk, m->tgtpos, Mq, nullptr, false, m->dqk, st));
         RC(lin_t(m, d.v, m->tgt, Mq, nullptr, false, m->dv, st));
-        RC(att_t(m, m->dqk, 2 * E, m->dqk + E, 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
+        RC(att_t(m, m->dqk, 2 * E, off(m->dqk, E), 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
         RC(lin_t(m, d.out, m->datt, Mq, m->tgt, false, m->dtmp, st));
-        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n1.g, d.n1.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, st));
+        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n1.g, d.n1.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, dt, st));
         RC(lin_t(m, d.cq, m->tgtpos, Mq, nullptr, false, m->dq, st));
-        RC(att_t(m, m->dq, E, m->kc + i * E, ldkv, m->vc + i * E, ldkv, m->datt, E, B, Hh, Q, L, st));
+        RC(att_t(m, m->dq, E, off(m->kc, i * E), ldkv, off(m->vc, i * E), ldkv, m->datt, E, B, Hh, Q, L, st));
         RC(lin_t(m, d.cout, m->datt, Mq, m->tgt, false, m->dtmp, st));
-        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n2.g, d.n2.b, m->tgt, nullptr, Q, nullptr, Mq, st));
+        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n2.g, d.n2.b, m->tgt, nullptr, Q, nullptr, Mq, dt, st));
         RC(lin_t(m, d.l1, m->tgt, Mq, nullptr, true, m->dffn, st));
         RC(lin_t(m, d.l2, m->dffn, Mq, m->tgt, false, m->dtmp, st));
-        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n3.g, d.n3.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, st));
+        RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n3.g, d.n3.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, dt, st));
     }
-    float* hs = obj_features ? obj_features : m->hs;
-    RC(odam_dk::launch_add_layernorm(m->tgt, nullptr, m->dec_norm.g, m->dec_norm.b, hs, nullptr, Q, nullptr, Mq, st));
+    // fp32 mode: the final norm can write straight into the caller's obj_features buffer
+    void* hs = (obj_features && dt == 0) ? (void*)obj_features : (void*)m->hs;
+    RC(odam_dk::launch_add_layernorm(m->tgt, nullptr, m->dec_norm.g, m->dec_norm.b, hs, nullptr, Q, nullptr, Mq, dt, st));
+    if (obj_features && dt != 0) RC(odam_dk::launch_to_f32(m->hs, obj_features, (size_t)Mq * E, dt, st));
 
-    // ---- heads on the last decoder layer (detr.py:73-88) ----------------------------------------
-    RC(lin_t(m, m->class_embed, hs, Mq, nullptr, false, logits, st));
+    // ---- heads on the last decoder layer (detr.py:73-88); their outputs are fp32 in every mode ----
+    RC(lin_t(m, m->class_embed, hs, Mq, nullptr, false, logits, st, 1));
     float* outs[5] = {boxes, offset, angle, size, depth};
     for (int k = 0; k < 5; k++) {
         RC(lin_t(m, m->mlp[k][0], hs, Mq, nullptr, true, m->h1, st));
         RC(lin_t(m, m->mlp[k][1], m->h1, Mq, nullptr, true, m->h2, st));
-        RC(lin_t(m, m->mlp[k][2], m->h2, Mq, nullptr, false, outs[k], st));
+        RC(lin_t(m, m->mlp[k][2], m->h2, Mq, nullptr, false, outs[k], st, 1));
     }
     RC(odam_dk::launch_sigmoid(boxes, Mq * 4, st));
     return 0;
@@ -489,10 +518,8 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
 extern "C" int odam_detr_debug_read(odam_detr* m, int B, float* layer4_nchw, float* memory, void* stream) {
     if (!m || !m->finalized || !m->layer4) return odam_fail(1, "odam_detr_debug_read: no forward has run");
     hipStream_t st = (hipStream_t)stream;
-    if (layer4_nchw) RC(odam_dk::launch_nhwc_to_nchw(m->layer4, layer4_nchw, B, m->fh, m->fw, 2048, st));
-    if (memory)
-        ODAM_HIP(hipMemcpyAsync(memory, m->src, sizeof(float) * (size_t)B * m->L * m->cfg.hidden_dim,
-                                hipMemcpyDeviceToDevice, st));
+    if (layer4_nchw) RC(odam_dk::launch_nhwc_to_nchw(m->layer4, layer4_nchw, B, m->fh, m->fw, 2048, m->dt, st));
+    if (memory) RC(odam_dk::launch_to_f32(m->src, memory, (size_t)B * m->L * m->cfg.hidden_dim, m->dt, st));
     return 0;
 }
 
@@ -517,21 +544,31 @@ extern "C" int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const 
     return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream);
 }
 
+extern "C" int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* scale, const float* bias,
+                                        const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH,
+                                        int KW, int stride, int pad, int Kpad, int relu, int out_f32, void* stream) {
+    if (!x || !w_packed || !y) return odam_fail(1, "odam_op_conv2d_nhwc_bf16: null pointer");
+    Conv c;
+    c.w = const_cast<void*>(w_packed); c.scale = const_cast<float*>(scale); c.bias = const_cast<float*>(bias);
+    c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
+    return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream, 1, out_f32);
+}
+
 extern "C" int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                                  int ldo, int B, int H, int Lq, int Lk, void* stream) {
     if (!Q || !K || !V || !O) return odam_fail(1, "odam_op_attention: null pointer");
-    return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, (hipStream_t)stream);
+    return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, 0, (hipStream_t)stream);
 }
 
 extern "C" int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y,
                                      int M, void* stream) {
     if (!x || !gamma || !beta || !y) return odam_fail(1, "odam_op_add_layernorm: null pointer");
-    return odam_dk::launch_add_layernorm(x, r, gamma, beta, y, nullptr, 1, nullptr, M, (hipStream_t)stream);
+    return odam_dk::launch_add_layernorm(x, r, gamma, beta, y, nullptr, 1, nullptr, M, 0, (hipStream_t)stream);
 }
 
 extern "C" int odam_op_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     if (!x || !y || C % 4) return odam_fail(1, "odam_op_maxpool3x3s2_nhwc: bad argument");
-    return odam_dk::launch_maxpool3x3s2(x, y, B, H, W, C, conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1),
+    return odam_dk::launch_maxpool3x3s2(x, y, B, H, W, C, conv_out(H, 3, 2, 1), conv_out(W, 3, 2, 1), 0,
                                         (hipStream_t)stream);
 }
 

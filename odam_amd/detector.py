@@ -19,7 +19,7 @@ class _Cfg(ctypes.Structure):
     _fields_ = [("resnet_blocks", ctypes.c_int * 4), ("hidden_dim", ctypes.c_int), ("nheads", ctypes.c_int),
                 ("dim_feedforward", ctypes.c_int), ("enc_layers", ctypes.c_int), ("dec_layers", ctypes.c_int),
                 ("num_queries", ctypes.c_int), ("num_classes1", ctypes.c_int), ("angle_bins", ctypes.c_int),
-                ("max_batch", ctypes.c_int), ("img_h", ctypes.c_int), ("img_w", ctypes.c_int)]
+                ("max_batch", ctypes.c_int), ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("dtype", ctypes.c_int)]
 
 
 def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000):
@@ -47,8 +47,11 @@ class Detector:
 
     def __init__(self, backbone="resnet50", hidden_dim=256, nheads=8, dim_feedforward=2048, enc_layers=6,
                  dec_layers=6, num_queries=100, num_classes=18, angle_bins=30, max_batch=8, device="cuda:0",
-                 n_streams=2):
+                 n_streams=2, dtype="fp32"):
         self.n_streams = max(1, int(n_streams))
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError("dtype must be 'fp32' (parity mode) or 'bf16' (BASELINE config 4)")
+        self.dtype = dtype
         self.arch = dict(backbone=backbone, hidden_dim=hidden_dim, nheads=nheads, dim_feedforward=dim_feedforward,
                          enc_layers=enc_layers, dec_layers=dec_layers, num_queries=num_queries,
                          num_classes1=num_classes + 1, angle_bins=angle_bins)
@@ -102,6 +105,7 @@ class Detector:
                   "angle_bins"):
             setattr(cfg, k, a[k])
         cfg.max_batch, cfg.img_h, cfg.img_w = self.max_batch, H, W
+        cfg.dtype = 1 if self.dtype == "bf16" else 0
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.odam_detr_create(ctypes.byref(cfg), ctypes.byref(h)), "odam_detr_create")

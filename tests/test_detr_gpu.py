@@ -228,3 +228,67 @@ def test_streamed_detection_equals_plain_forward(model):
     assert np.allclose(got, plain, rtol=0, atol=2e-6)
     assert np.array_equal(got[..., 1], plain[..., 1])          # class labels
     assert np.allclose(det.detect_resident(frames, (640, 480), K), plain, rtol=0, atol=2e-6)
+
+
+# ---- bf16 mode (BASELINE config 4): bf16 weights/activations, bf16 MFMA, fp32 accumulation ------------------------
+def _to_bf16_bits(t):
+    return t.to(torch.bfloat16).view(torch.int16)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p,relu,res", [
+    (2, 25, 34, 256, 512, 1, 1, 0, True, True),
+    (1, 40, 53, 64, 64, 3, 1, 1, True, False),
+    (2, 33, 41, 128, 128, 3, 2, 1, False, False),
+    (1, 64, 80, 3, 64, 7, 2, 3, True, False),       # stem: Cin 3 -> 8, K 392 -> 448
+])
+def test_conv_gemm_bf16_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
+    """bf16 operands are exact in fp32, so against a float conv on the bf16-rounded operands only the summation
+    order differs (fp32 output requested); the bf16-stored output then agrees to bf16 rounding."""
+    from odam_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(B * 100 + Cin + Cout + k)
+    x = torch.randn(B, Cin, H, W).to(torch.bfloat16).float(); w = (torch.randn(Cout, Cin, k, k) / (Cin * k * k) ** 0.5).to(torch.bfloat16).float()
+    sc = torch.rand(Cout) + 0.5; bi = torch.randn(Cout)
+    y = F.conv2d(x, w, None, s, p) * sc.view(1, -1, 1, 1) + bi.view(1, -1, 1, 1)
+    r = torch.randn_like(y).to(torch.bfloat16).float() if res else None
+    if res:
+        y = y + r
+    if relu:
+        y = F.relu(y)
+    CinP = (Cin + 7) // 8 * 8
+    wp = torch.zeros(Cout, k, k, CinP); wp[..., :Cin] = w.permute(0, 2, 3, 1)
+    Kk = k * k * CinP; Kpad = (Kk + 63) // 64 * 64
+    wpk = torch.zeros(Cout, Kpad); wpk[:, :Kk] = wp.reshape(Cout, Kk)
+    xh = torch.zeros(B, H, W, CinP); xh[..., :Cin] = x.permute(0, 2, 3, 1)
+    dx, dw = _to_bf16_bits(xh).to(DEV), _to_bf16_bits(wpk).to(DEV)
+    dsc, dbi = sc.to(DEV), bi.to(DEV)
+    dr = _to_bf16_bits(r.permute(0, 2, 3, 1).contiguous()).to(DEV) if res else None
+    for out_f32 in (1, 0):
+        dy = torch.empty(B, y.shape[2], y.shape[3], Cout, device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
+        _lib.check(L.odam_op_conv2d_nhwc_bf16(_lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dbi), _lib.ptr(dr), _lib.ptr(dy),
+                                              B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), out_f32, _st()), "conv bf16")
+        got = dy.float().cpu().permute(0, 3, 1, 2)
+        tol = 3e-6 if out_f32 else 8e-3     # bf16 has 8 significant bits
+        assert (got - y).abs().max().item() <= tol * max(y.abs().max().item(), 1.0), out_f32
+
+
+def test_bf16_forward_close_to_fp32_oracle():
+    """R101 at a reduced 800x600-like aspect (config 4): documented looser tolerance against the fp32 oracle"""
+    import detr_oracle as O
+    from odam_amd import detector, weights
+    sd = weights.make_state_dict(backbone="resnet101", seed=1)
+    det = detector.Detector(backbone="resnet101", max_batch=2, device=DEV, dtype="bf16", n_streams=1)
+    det.load_state_dict(sd)
+    torch.manual_seed(3)
+    img = torch.randn(2, 3, 192, 256)
+    ref = O.detr_forward(sd, img, blocks=(3, 4, 23, 3))
+    out = det(img.to(DEV))
+    for k in KEYS:
+        assert out[k].dtype == torch.float32
+        err = (out[k].cpu() - ref[k]).abs().max().item()
+        assert err <= 0.05 * max(1.0, ref[k].abs().max().item()), (k, err)
+    agree = (out["pred_logits"].cpu().argmax(-1) == ref["pred_logits"].argmax(-1)).float().mean().item()
+    assert agree >= 0.9, agree
+    feats = out["pred_obj_features"].cpu()
+    assert (feats - ref["pred_obj_features"]).abs().max().item() <= 0.15
+    det.close()
