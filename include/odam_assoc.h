@@ -1,0 +1,39 @@
+/*
+ * odam_assoc.h -- C ABI of the association network forward pass on MI355X.
+ *
+ * Replaces, for the inference call OdamProcess.process_frame makes (src/processor.py:327-337):
+ *   src/models/associator.py:202-254  Associator.forward up to and including log_optimal_transport
+ *   src/models/associator.py:283-312  log_optimal_transport / log_sinkhorn_iterations   -> odam_assoc_sinkhorn
+ * The Hungarian step (associator.py:19-35, scipy.optimize.linear_sum_assignment) stays on the host.
+ * Conventions as in odam_sq.h.
+ */
+#ifndef ODAM_ASSOC_H
+#define ODAM_ASSOC_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct odam_assoc odam_assoc;
+
+/* gnn_is_cross[n_gnn_layers]: 1 for a 'cross' layer, 0 for 'self' (cfg.GNN_layers); n_self_layers = len(cfg.self_GNN_layers) */
+int odam_assoc_create(int max_tracks, int n_self_layers, const int* gnn_is_cross, int n_gnn_layers, int sinkhorn_iters,
+                      odam_assoc** out);
+int odam_assoc_destroy(odam_assoc* m);
+/* state_dict entries under the reference's key names ("encoder.0.weight", "fuser.layers.0.attn.proj.1.bias",
+ * "gnn.layers.3.mlp.2.weight", "final_proj.weight", "bin_score", ...), float32 [host]; plus "pe_div_term" [128]
+ * = exp(arange(0, 256, 2) * (-ln(10000) / 256)) as PositionalEncoding computes it (associator.py:317-321). */
+int odam_assoc_set_weight(odam_assoc* m, const char* name, const float* data, const long long* shape, int ndim);
+int odam_assoc_finalize(odam_assoc* m);
+
+/* tracks [dev][T,79,100] and detections [dev][79,30] in the associator's input layout (channel 0 = frame index,
+ * -1 padding; processor.py:49-68, 155-179); Z_out [dev][(T+1),(n_det+1)] = log assignment incl. dustbins. */
+int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, float* Z_out,
+                       void* stream);
+
+/* log_optimal_transport alone: scores [dev][m, n] with row stride lds, alpha = bin_score */
+int odam_assoc_sinkhorn(const float* scores, int lds, int m, int n, float alpha, int iters, float* Z_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

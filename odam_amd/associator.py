@@ -1,0 +1,120 @@
+"""Host side of the association network: drop-in for the reference's Associator object as OdamProcess calls it
+(likojack/ODAM src/models/associator.py:163-268, src/processor.py:327-341):
+    out = associator(data, match_threshold, eval_only=True)
+    out["matches"][0]  -> track id per detection (-1 = new track)      (hungarian_matching, :19-35)
+    out["pred"][0][0]  -> log assignment [(T+1), (n_det+1)] tensor      (log_optimal_transport, :283-298)
+The network forward and the 100 Sinkhorn iterations run in the gfx950 library (include/odam_assoc.h); the
+Hungarian assignment stays on the host with scipy, exactly as the reference does."""
+import ctypes
+import math
+
+import numpy as np
+import torch
+from scipy.optimize import linear_sum_assignment
+
+from . import _lib
+
+
+def hungarian_matching(scores, matching_threshold):  # associator.py:19-35
+    scores = scores.detach().cpu().numpy()
+    match = np.zeros(scores.shape[1]) - 1
+    rows, cols = linear_sum_assignment(1 - scores)
+    for r, c in zip(rows, cols):
+        if scores[r, c] > matching_threshold:
+            match[c] = r
+    return match
+
+
+class Associator:
+    def __init__(self, config=None, max_tracks=256, device="cuda:0"):
+        cfg = config or {"GNN_layers": ["self", "cross"] * 6, "self_GNN_layers": ["self"] * 4, "sinkhorn_iterations": 100}
+        self.gnn_layers = list(cfg["GNN_layers"])
+        self.n_self = len(cfg["self_GNN_layers"])
+        self.iters = int(cfg["sinkhorn_iterations"])
+        self.max_tracks = max_tracks
+        self.device = torch.device(device)
+        self._h = None
+        self._sd = None
+
+    def to(self, device):
+        self.device = torch.device("cuda:0" if str(device) == "cuda" else device)
+        return self
+
+    def cuda(self):
+        return self.to("cuda:0")
+
+    def eval(self):
+        return self
+
+    def load_state_dict(self, sd, strict=True):
+        self._sd = {k: v.detach().to("cpu", torch.float32).contiguous() for k, v in sd.items() if torch.is_tensor(v)}
+        self.close()
+        return self
+
+    def close(self):
+        if self._h:
+            _lib.lib().odam_assoc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _handle(self):
+        if self._h:
+            return self._h
+        if self._sd is None:
+            raise _lib.OdamError("Associator: load_state_dict() first")
+        L = _lib.lib()
+        h = ctypes.c_void_p()
+        cross = (ctypes.c_int * len(self.gnn_layers))(*[1 if n == "cross" else 0 for n in self.gnn_layers])
+        with torch.cuda.device(self.device):
+            _lib.check(L.odam_assoc_create(self.max_tracks, self.n_self, cross, len(self.gnn_layers), self.iters,
+                                           ctypes.byref(h)), "odam_assoc_create")
+            tensors = dict(self._sd)
+            # PositionalEncoding.div_term (associator.py:320), torch CPU float32 ops
+            tensors["pe_div_term"] = torch.exp(torch.arange(0, 256, 2).float() * (-math.log(10000.0) / 256))
+            for name, t in tensors.items():
+                t = t.reshape(t.shape[0], t.shape[1]) if t.dim() == 3 else t     # Conv1d weight [N, K, 1]
+                t = t.contiguous()
+                shape = (ctypes.c_longlong * max(t.dim(), 1))(*t.shape)
+                _lib.check(L.odam_assoc_set_weight(h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
+                           f"odam_assoc_set_weight({name})")
+            _lib.check(L.odam_assoc_finalize(h), "odam_assoc_finalize")
+        self._h = h
+        return h
+
+    def assignment(self, tracks, detections, n_tracks, n_det):
+        """tracks [T,79,100], detections [1,79,30] or [79,30] (any device) -> Z [(T+1),(n_det+1)] device tensor"""
+        dev = self.device
+        tr = tracks.to(dev, torch.float32).contiguous()
+        de = detections.to(dev, torch.float32).reshape(79, 30).contiguous()
+        Z = torch.empty(n_tracks + 1, n_det + 1, device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().odam_assoc_forward(self._handle(), _lib.ptr(tr), ctypes.c_int(n_tracks), _lib.ptr(de),
+                                                     ctypes.c_int(n_det), _lib.ptr(Z),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "odam_assoc_forward")
+        return Z
+
+    def __call__(self, in_data, threshold, eval_only=False, device="cuda"):
+        """Associator.forward for the batch-of-one call of OdamProcess (associator.py:202-268, eval_only=True)"""
+        valid = in_data["valid_list"]
+        if len(valid) != 1:
+            raise _lib.OdamError("batch size 1 only (what OdamProcess.process_frame passes)")
+        n_tracks, n_det = valid[0]
+        Z = self.assignment(in_data["tracks"], in_data["detections"][0], n_tracks, n_det)
+        pred = [Z[None]]
+        match = [hungarian_matching(Z[:-1, :-1].exp(), threshold)]
+        return {"pred": pred, "loss": 0, "matches": match}
+
+    forward = __call__
+
+
+def build(args):
+    """src/models/associator.py:330-340"""
+    g = (lambda k: args[k]) if isinstance(args, dict) else (lambda k: getattr(args, k))
+    return Associator({"GNN_layers": g("GNN_layers"), "self_GNN_layers": g("self_GNN_layers"),
+                       "sinkhorn_iterations": g("sinkhorn_iterations")})

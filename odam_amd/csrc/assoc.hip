@@ -1,0 +1,371 @@
+// assoc.hip -- the association network's forward pass on gfx950.
+//
+// Reference (likojack/ODAM src/models/associator.py:163-312): keypoint encoder MLP, sine frame-index encoding,
+// 2 self-attention GNN layers over each track's time steps, average pooling over time, 8 alternating self/cross
+// GNN layers between tracks and detections (4 heads of 64), final projection, score matrix / 16, 100 Sinkhorn
+// iterations in log space.  The reference runs ~300 tiny PyTorch kernels per frame for this; here every Conv1d(k=1)
+// is a conv_gemm launch (fp32 MFMA), attention is the fused kernel with head dimension 64, and the whole Sinkhorn
+// loop is ONE single-workgroup kernel.  The Hungarian step stays on the host (scipy, as the reference).
+//
+// Layout: token-major rows.  A token set lives in a [N, 512] buffer "cat": columns 0..255 hold x, columns
+// 256..511 receive the attention message, so cat([x, message]) (associator.py:97) needs no copy.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/odam_assoc.h"
+#include "conv_gemm.h"
+#include "detr_kernels.h"
+#include "odam_err.h"
+
+using odam_cg::ConvGemmArgs;
+
+namespace {
+
+constexpr int D = 256, NF = 79, NT = 100, ND = 30, FPAD = 128;
+
+struct Lin { float* w = nullptr; float* b = nullptr; int K = 0, N = 0; };
+struct Prop { Lin q, kv, merge, m0, m2; };   // AttentionalPropagation (associator.py:85-97)
+
+struct HostT { std::vector<long long> shape; std::vector<float> data; };
+
+// ---- kernels ------------------------------------------------------------------------------------------------------
+// in [n_seq, 79, L] channel-first (row 0 = frame index, rows 1..78 features) ->
+// feat [n_seq*L, 128] (features, zero padded) and cat[:, 0:256] = sine encoding of the frame index
+__global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ in, int L, int n_tok,
+                                                      const float* __restrict__ div_term, float* __restrict__ feat,
+                                                      float* __restrict__ cat) {
+    const int tok = blockIdx.x;
+    if (tok >= n_tok) return;
+    const int s = tok / L, l = tok - s * L;
+    const float* src = in + (size_t)s * NF * L + l;
+    const int c = threadIdx.x;
+    if (c < FPAD) feat[(size_t)tok * FPAD + c] = (c < NF - 1) ? src[(size_t)(c + 1) * L] : 0.0f;
+    const float pos = src[0];
+    const float a = pos * div_term[c >> 1];                    // associator.py:325-326
+    cat[(size_t)tok * 512 + c] = (c & 1) ? cosf(a) : sinf(a);
+}
+
+// F.avg_pool1d over the L time steps of each track: out[s, c] = mean_l cat[(s*L + l), c]   (associator.py:231-232)
+__global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ cat, int L, float* __restrict__ out) {
+    const int s = blockIdx.x, c = threadIdx.x;
+    float acc = 0.0f;
+    for (int l = 0; l < L; l++) acc += cat[((size_t)s * L + l) * 512 + c];
+    out[(size_t)s * 512 + c] = acc / (float)L;
+}
+
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, int ldx, const float* __restrict__ d,
+                                                       int ldd, int M) {
+    const int i = blockIdx.x * 256 + threadIdx.x;   // over M * 64 float4
+    if (i >= M * 64) return;
+    const int r = i >> 6, c4 = (i & 63) * 4;
+    float4 a = *reinterpret_cast<float4*>(x + (size_t)r * ldx + c4);
+    const float4 b = *reinterpret_cast<const float4*>(d + (size_t)r * ldd + c4);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    *reinterpret_cast<float4*>(x + (size_t)r * ldx + c4) = a;
+}
+
+// log_optimal_transport + log_sinkhorn_iterations (associator.py:283-312), one workgroup:
+//   couplings Z[(m+1) x (n+1)] = [[scores, alpha], [alpha, alpha]] in LDS; u, v in LDS;
+//   iters x { u = log_mu - logsumexp_j(Z + v);  v = log_nu - logsumexp_i(Z + u) };  out = Z + u + v - norm
+__global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__ scores, int lds, int m, int n,
+                                                       float alpha, int iters, float* __restrict__ out) {
+    extern __shared__ float sm[];
+    const int M1 = m + 1, N1 = n + 1;
+    float* Z = sm;                 // [M1][N1]
+    float* u = Z + M1 * N1;        // [M1]
+    float* v = u + M1;             // [N1]
+    const int tid = threadIdx.x;
+    for (int i = tid; i < M1 * N1; i += 256) {
+        const int r = i / N1, c = i - r * N1;
+        Z[i] = (r < m && c < n) ? scores[(size_t)r * lds + c] : alpha;
+    }
+    for (int i = tid; i < M1; i += 256) u[i] = 0.0f;
+    for (int i = tid; i < N1; i += 256) v[i] = 0.0f;
+    const float norm = -logf((float)m + (float)n);
+    const float log_mu_last = logf((float)n) + norm, log_nu_last = logf((float)m) + norm;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int it = 0; it < iters; ++it) {
+        for (int r = tid; r < M1; r += 256) {          // rows: <= 31 entries, one lane each
+            float mx = -INFINITY;
+            for (int c = 0; c < N1; c++) mx = fmaxf(mx, Z[r * N1 + c] + v[c]);
+            float sum = 0.0f;
+            for (int c = 0; c < N1; c++) sum += expf(Z[r * N1 + c] + v[c] - mx);
+            u[r] = ((r < m) ? norm : log_mu_last) - (logf(sum) + mx);
+        }
+        __syncthreads();
+        for (int c = wave; c < N1; c += 4) {           // columns: one wavefront each, lanes stride the rows
+            float mx = -INFINITY;
+            for (int r = lane; r < M1; r += 64) mx = fmaxf(mx, Z[r * N1 + c] + u[r]);
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+            float sum = 0.0f;
+            for (int r = lane; r < M1; r += 64) sum += expf(Z[r * N1 + c] + u[r] - mx);
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
+            if (lane == 0) v[c] = ((c < n) ? norm : log_nu_last) - (logf(sum) + mx);
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < M1 * N1; i += 256) {
+        const int r = i / N1, c = i - r * N1;
+        out[i] = Z[i] + u[r] + v[c] - norm;
+    }
+}
+
+int lin(const Lin& L, const float* x, int lda, int M, const float* res, bool relu, float* y, int ldc, const float* scale,
+        hipStream_t st) {
+    ConvGemmArgs a{};
+    a.A = x; a.Wt = L.w; a.scale = scale; a.bias = L.b; a.res = res; a.C = y;
+    a.B = 1; a.H = 1; a.W = M; a.Cin = L.K; a.lda = lda;
+    int lg = 0; while ((1 << lg) < L.K) lg++;
+    a.log2Cin = lg;
+    a.Ho = 1; a.Wo = M; a.Cout = L.N; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Kpad = L.K;
+    a.relu = relu ? 1 : 0; a.M = M; a.ldc = ldc;
+    return odam_cg::launch_conv_gemm(a, st);
+}
+
+#define RC(call) do { int rc_ = (call); if (rc_) return rc_; } while (0)
+
+}  // namespace
+
+struct odam_assoc {
+    int max_tracks = 0, n_self = 0, n_gnn = 0, iters = 100;
+    std::vector<int> gnn_cross;          // per GNN layer: 1 = cross
+    std::map<std::string, HostT> host;
+    bool finalized = false;
+    std::vector<void*> allocs;
+    Lin enc0, enc2, final_proj;
+    std::vector<Prop> fuser, gnn;
+    float bin_score = 1.0f;
+    float *div_term = nullptr, *sc16 = nullptr;
+    // workspace
+    float *feat = nullptr, *h256 = nullptr, *catT = nullptr, *q = nullptr, *kv = nullptr, *att = nullptr, *h512 = nullptr;
+    float *catTr = nullptr, *catD = nullptr, *featD = nullptr, *qT = nullptr, *kvT = nullptr, *qD = nullptr, *kvD = nullptr,
+          *attT = nullptr, *attD = nullptr, *hT = nullptr, *hD = nullptr, *dT = nullptr, *mT = nullptr, *mD = nullptr,
+          *scores = nullptr;
+
+    int alloc(float** p, size_t n) {
+        ODAM_HIP(hipMalloc((void**)p, n * sizeof(float)));
+        ODAM_HIP(hipMemset(*p, 0, n * sizeof(float)));
+        allocs.push_back(*p);
+        return 0;
+    }
+    int upload(float** p, const std::vector<float>& v) {
+        if (int rc = alloc(p, v.size())) return rc;
+        ODAM_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        return 0;
+    }
+};
+
+namespace {
+
+const HostT* findw(odam_assoc* m, const std::string& n) {
+    auto it = m->host.find(n);
+    return it == m->host.end() ? nullptr : &it->second;
+}
+#define NEEDW(var, name)                                                                                  \
+    const HostT* var = findw(m, name);                                                                     \
+    if (!var) {                                                                                            \
+        std::snprintf(g_odam_err, sizeof(g_odam_err), "odam_assoc_finalize: missing weight %s", std::string(name).c_str()); \
+        return 1;                                                                                          \
+    }
+
+// Conv1d(k=1) weight [N, K(,1)] + bias -> Lin with K padded to Kp; optional row/column permutations
+int pack(odam_assoc* m, Lin& L, const HostT& w, const HostT* b, int Kp, const std::vector<int>* row_perm,
+         const std::vector<int>* col_perm) {
+    const int N = (int)w.shape[0], K = (int)w.shape[1];
+    std::vector<float> p((size_t)N * Kp, 0.0f), bb(N, 0.0f);
+    for (int r = 0; r < N; r++) {
+        const int sr = row_perm ? (*row_perm)[r] : r;
+        for (int c = 0; c < K; c++) {
+            const int sc = col_perm ? (*col_perm)[c] : c;
+            p[(size_t)r * Kp + c] = w.data[(size_t)sr * K + sc];
+        }
+        if (b) bb[r] = b->data[sr];
+    }
+    L.K = Kp; L.N = N;
+    if (int rc = m->upload(&L.w, p)) return rc;
+    return m->upload(&L.b, bb);
+}
+
+// the reference views the 256 projected channels as (dim 64, head 4): channel c = d*4 + h (associator.py:77-81);
+// the attention kernel wants head-major channels c' = h*64 + d: perm[c'] = d*4 + h
+std::vector<int> head_perm() {
+    std::vector<int> p(D);
+    for (int h = 0; h < 4; h++)
+        for (int d = 0; d < 64; d++) p[h * 64 + d] = d * 4 + h;
+    return p;
+}
+
+int pack_prop(odam_assoc* m, Prop& P, const std::string& pre) {
+    const std::vector<int> hp = head_perm();
+    NEEDW(w0, pre + "attn.proj.0.weight"); NEEDW(b0, pre + "attn.proj.0.bias");
+    NEEDW(w1, pre + "attn.proj.1.weight"); NEEDW(b1, pre + "attn.proj.1.bias");
+    NEEDW(w2, pre + "attn.proj.2.weight"); NEEDW(b2, pre + "attn.proj.2.bias");
+    RC(pack(m, P.q, *w0, b0, D, &hp, nullptr));
+    HostT wkv, bkv;          // key and value projections read the same source: one [512, 256] layer
+    wkv.shape = {2 * D, D};
+    for (const HostT* w : {w1, w2})
+        for (int r = 0; r < D; r++)
+            wkv.data.insert(wkv.data.end(), w->data.begin() + (size_t)hp[r] * D, w->data.begin() + (size_t)(hp[r] + 1) * D);
+    for (const HostT* b : {b1, b2})
+        for (int r = 0; r < D; r++) bkv.data.push_back(b->data[hp[r]]);
+    bkv.shape = {2 * D};
+    RC(pack(m, P.kv, wkv, &bkv, D, nullptr, nullptr));
+    NEEDW(wm, pre + "attn.merge.weight"); NEEDW(bm, pre + "attn.merge.bias");
+    RC(pack(m, P.merge, *wm, bm, D, nullptr, &hp));      // its input channels arrive head-major
+    NEEDW(m0w, pre + "mlp.0.weight"); NEEDW(m0b, pre + "mlp.0.bias");
+    NEEDW(m2w, pre + "mlp.2.weight"); NEEDW(m2b, pre + "mlp.2.bias");
+    RC(pack(m, P.m0, *m0w, m0b, 2 * D, nullptr, nullptr));
+    RC(pack(m, P.m2, *m2w, m2b, 2 * D, nullptr, nullptr));
+    return 0;
+}
+
+// delta = layer(x, source): message into cat_x[:, 256:], hidden in h, delta to `out` (ld_out) with optional residual
+int prop_forward(const Prop& P, float* cat_x, int Mx, const float* cat_s, int Ms, int Bt, int Lq, int Lk, float* qb,
+                 float* kvb, float* attb, float* hb, const float* res, float* out, int ld_out, hipStream_t st) {
+    RC(lin(P.q, cat_x, 512, Mx, nullptr, false, qb, D, nullptr, st));
+    RC(lin(P.kv, cat_s, 512, Ms, nullptr, false, kvb, 2 * D, nullptr, st));
+    RC(odam_dk::launch_attention_d64(qb, D, kvb, 2 * D, kvb + D, 2 * D, attb, D, Bt, 4, Lq, Lk, st));
+    RC(lin(P.merge, attb, D, Mx, nullptr, false, cat_x + D, 512, nullptr, st));
+    RC(lin(P.m0, cat_x, 512, Mx, nullptr, true, hb, 2 * D, nullptr, st));
+    RC(lin(P.m2, hb, 2 * D, Mx, res, false, out, ld_out, nullptr, st));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int odam_assoc_create(int max_tracks, int n_self_layers, const int* gnn_is_cross, int n_gnn_layers,
+                                 int sinkhorn_iters, odam_assoc** out) {
+    if (!out || max_tracks < 1 || max_tracks > 1024 || n_self_layers < 0 || n_gnn_layers < 0 || !gnn_is_cross)
+        return odam_fail(1, "odam_assoc_create: bad argument (1 <= max_tracks <= 1024)");
+    odam_assoc* m = new odam_assoc();
+    m->max_tracks = max_tracks; m->n_self = n_self_layers; m->n_gnn = n_gnn_layers; m->iters = sinkhorn_iters;
+    m->gnn_cross.assign(gnn_is_cross, gnn_is_cross + n_gnn_layers);
+    *out = m;
+    return 0;
+}
+
+extern "C" int odam_assoc_destroy(odam_assoc* m) {
+    if (!m) return 0;
+    for (void* p : m->allocs) (void)hipFree(p);
+    delete m;
+    return 0;
+}
+
+extern "C" int odam_assoc_set_weight(odam_assoc* m, const char* name, const float* data, const long long* shape, int ndim) {
+    if (!m || !name || !data || ndim < 0 || ndim > 3 || m->finalized) return odam_fail(1, "odam_assoc_set_weight: bad argument");
+    HostT t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; i++) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.data.assign(data, data + n);
+    m->host[name] = std::move(t);
+    return 0;
+}
+
+extern "C" int odam_assoc_finalize(odam_assoc* m) {
+    if (!m) return odam_fail(1, "odam_assoc_finalize: null model");
+    if (m->finalized) return 0;
+    {
+        NEEDW(w0, "encoder.0.weight"); NEEDW(b0, "encoder.0.bias");
+        NEEDW(w2, "encoder.2.weight"); NEEDW(b2, "encoder.2.bias");
+        RC(pack(m, m->enc0, *w0, b0, FPAD, nullptr, nullptr));
+        RC(pack(m, m->enc2, *w2, b2, D, nullptr, nullptr));
+        NEEDW(fw, "final_proj.weight"); NEEDW(fb, "final_proj.bias");
+        RC(pack(m, m->final_proj, *fw, fb, D, nullptr, nullptr));
+        NEEDW(bs, "bin_score");
+        m->bin_score = bs->data[0];
+        NEEDW(dv, "pe_div_term");
+        if (dv->data.size() != D / 2) return odam_fail(1, "pe_div_term must have 128 entries");
+        RC(m->upload(&m->div_term, dv->data));
+        RC(m->upload(&m->sc16, std::vector<float>(ND, 1.0f / 16.0f)));   // scores / descriptor_dim ** 0.5
+    }
+    for (int i = 0; i < m->n_self; i++) {
+        Prop P;
+        RC(pack_prop(m, P, "fuser.layers." + std::to_string(i) + "."));
+        m->fuser.push_back(P);
+    }
+    for (int i = 0; i < m->n_gnn; i++) {
+        Prop P;
+        RC(pack_prop(m, P, "gnn.layers." + std::to_string(i) + "."));
+        m->gnn.push_back(P);
+    }
+    const size_t T = m->max_tracks, N = T * NT;
+    RC(m->alloc(&m->feat, N * FPAD)); RC(m->alloc(&m->h256, N * D)); RC(m->alloc(&m->catT, N * 512));
+    RC(m->alloc(&m->q, N * D)); RC(m->alloc(&m->kv, N * 512)); RC(m->alloc(&m->att, N * D)); RC(m->alloc(&m->h512, N * 512));
+    RC(m->alloc(&m->catTr, T * 512)); RC(m->alloc(&m->catD, ND * 512)); RC(m->alloc(&m->featD, ND * FPAD));
+    const size_t TX = T > (size_t)ND ? T : (size_t)ND;   // key/value rows come from the OTHER set in cross layers
+    RC(m->alloc(&m->qT, T * D)); RC(m->alloc(&m->kvT, TX * 512)); RC(m->alloc(&m->qD, ND * D)); RC(m->alloc(&m->kvD, TX * 512));
+    RC(m->alloc(&m->attT, T * D)); RC(m->alloc(&m->attD, ND * D)); RC(m->alloc(&m->hT, T * 512)); RC(m->alloc(&m->hD, ND * 512));
+    RC(m->alloc(&m->dT, T * D)); RC(m->alloc(&m->mT, T * D)); RC(m->alloc(&m->mD, ND * D)); RC(m->alloc(&m->scores, T * 32));
+    ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    m->host.clear();
+    m->finalized = true;
+    return 0;
+}
+
+extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det,
+                                  float* Z_out, void* stream) {
+    if (!m || !tracks || !detections || !Z_out) return odam_fail(1, "odam_assoc_forward: null pointer");
+    if (!m->finalized) return odam_fail(1, "odam_assoc_forward: call odam_assoc_finalize first");
+    if (T < 1 || T > m->max_tracks || n_det < 1 || n_det > ND) return odam_fail(3, "odam_assoc_forward: T / n_det out of range");
+    hipStream_t st = (hipStream_t)stream;
+    const int N = T * NT;
+    // encoder + frame-index encoding (associator.py:222-229)
+    hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
+    hipLaunchKernelGGL(prepare_kernel, dim3(ND), dim3(256), 0, st, detections, ND, ND, m->div_term, m->featD, m->catD);
+    ODAM_HIP(hipGetLastError());
+    RC(lin(m->enc0, m->feat, FPAD, N, nullptr, true, m->h256, D, nullptr, st));
+    RC(lin(m->enc2, m->h256, D, N, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
+    RC(lin(m->enc0, m->featD, FPAD, ND, nullptr, true, m->h256, D, nullptr, st));
+    RC(lin(m->enc2, m->h256, D, ND, m->catD, false, m->catD, 512, nullptr, st));
+    // fuser: self-attention over each track's 100 time steps (associator.py:143-160, 230)
+    for (const Prop& P : m->fuser)
+        RC(prop_forward(P, m->catT, N, m->catT, N, T, NT, NT, m->q, m->kv, m->att, m->h512, m->catT, m->catT, 512, st));
+    hipLaunchKernelGGL(time_mean_kernel, dim3(T), dim3(256), 0, st, m->catT, NT, m->catTr);
+    ODAM_HIP(hipGetLastError());
+    // matching GNN between the fused tracks [T] and all 30 detection slots (associator.py:111-139, 240)
+    for (size_t i = 0; i < m->gnn.size(); i++) {
+        const Prop& P = m->gnn[i];
+        const bool cross = m->gnn_cross[i] != 0;
+        const float* srcT = cross ? m->catD : m->catTr;
+        const int nT = cross ? ND : T;
+        const float* srcD = cross ? m->catTr : m->catD;
+        const int nD = cross ? T : ND;
+        // both deltas come from the layer's inputs: the tracks' delta is parked in dT and added afterwards
+        RC(prop_forward(P, m->catTr, T, srcT, nT, 1, T, nT, m->qT, m->kvT, m->attT, m->hT, nullptr, m->dT, D, st));
+        RC(prop_forward(P, m->catD, ND, srcD, nD, 1, ND, nD, m->qD, m->kvD, m->attD, m->hD, m->catD, m->catD, 512, st));
+        hipLaunchKernelGGL(add_rows_kernel, dim3((T * 64 + 255) / 256), dim3(256), 0, st, m->catTr, 512, m->dT, D, T);
+        ODAM_HIP(hipGetLastError());
+    }
+    // descriptors, scores, optimal transport (associator.py:242-254)
+    RC(lin(m->final_proj, m->catTr, 512, T, nullptr, false, m->mT, D, nullptr, st));
+    RC(lin(m->final_proj, m->catD, 512, ND, nullptr, false, m->mD, D, nullptr, st));
+    Lin sc; sc.w = m->mD; sc.b = nullptr; sc.K = D; sc.N = ND;
+    RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
+    const size_t lds = ((size_t)(T + 1) * (n_det + 1) + (T + 1) + (n_det + 1)) * sizeof(float);
+    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(256), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odam_assoc_sinkhorn(const float* scores, int lds_, int m_, int n_, float alpha, int iters, float* Z_out,
+                                   void* stream) {
+    if (!scores || !Z_out || m_ < 1 || n_ < 1 || (size_t)(m_ + 1) * (n_ + 1) > 36000)
+        return odam_fail(1, "odam_assoc_sinkhorn: bad argument");
+    static bool attr = false;
+    if (!attr) {
+        ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+        attr = true;
+    }
+    const size_t lds = ((size_t)(m_ + 1) * (n_ + 1) + (m_ + 1) + (n_ + 1)) * sizeof(float);
+    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, scores, lds_, m_, n_, alpha, iters, Z_out);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}

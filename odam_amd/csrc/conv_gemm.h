@@ -41,6 +41,7 @@ struct ConvGemmArgs {
     int ldc;             // row stride of C / res in elements (>= Cout)
     int dtype;           // ODAM_CG_F32 / ODAM_CG_BF16: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, fp32 accumulate
     int out_f32;         // bf16 mode only: write C as fp32
+    int lda;             // elements between consecutive input pixels (0 = Cin): reads a column block of a wider buffer
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);

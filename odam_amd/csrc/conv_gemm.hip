@@ -60,6 +60,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
     bool a_ok[A_LD];
     const int hw = a.Ho * a.Wo;
+    const int lda = a.lda > 0 ? a.lda : a.Cin;   // elements between consecutive input pixels
 #pragma unroll
     for (int i = 0; i < A_LD; i++) {
         const int m = m0 + r0 + RPP * i;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         const int ox = rem - oy * a.Wo;
         a_iy0[i] = oy * a.stride - a.pad;
         a_ix0[i] = ox * a.stride - a.pad;
-        a_base[i] = ((b * a.H + a_iy0[i]) * a.W + a_ix0[i]) * a.Cin;
+        a_base[i] = ((b * a.H + a_iy0[i]) * a.W + a_ix0[i]) * lda;
     }
     const T* w_ptr[B_LD];
     bool b_ok[B_LD];
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         const int ky = (tap * kw_inv) >> 16;
         const int kx = tap - ky * a.KW;
         const bool tap_ok = tap < ntaps;
-        const int koff = (ky * a.W + kx) * a.Cin + ci;
+        const int koff = (ky * a.W + kx) * lda + ci;
 #pragma unroll
         for (int i = 0; i < A_LD; i++) {
             const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;

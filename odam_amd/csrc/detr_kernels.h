@@ -12,6 +12,10 @@ namespace odam_dk {
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                      int B, int H, int Lq, int Lk, int dtype, hipStream_t stream);
 
+// same kernel with head dimension 64, fp32 (associator GNN, 4 heads of 64; scores scaled by 1/8)
+int launch_attention_d64(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                         int B, int H, int Lq, int Lk, hipStream_t stream);
+
 // y = LayerNorm(x + r) * gamma + beta over C = 256 (eps 1e-5); r may be null.
 // If y_pos != null also writes y_pos = y + pos[row % L]  (the next layer's q/k input).
 int launch_add_layernorm(const void* x, const void* r, const float* gamma, const float* beta, void* y,

@@ -39,63 +39,78 @@ __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
 // src/models/transformer.py:154-167, 217-238 (q scaled by sqrt(1/32) before the product, softmax
 // over keys, no dropout at inference, padding mask all-false for same-size frames).
 // =================================================================================================
-constexpr int ATT_D = 32;
 constexpr int ATT_KT = 32;          // keys per tile
-constexpr int ATT_LD = ATT_D + 4;   // LDS row stride (floats)
 
 __device__ __forceinline__ int acc_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <typename T>
+// D = head dimension: 32 (detector, 8 heads) or 64 (associator GNN, 4 heads)
+template <typename T, int D>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q, int ldq,
                                                         const T* __restrict__ K, int ldk,
                                                         const T* __restrict__ V, int ldv,
-                                                        T* __restrict__ O, int ldo, int Lq, int Lk) {
-    __shared__ __align__(16) float Ks[2][ATT_KT][ATT_LD];
-    __shared__ __align__(16) float Vs[2][ATT_KT][ATT_LD];
+                                                        T* __restrict__ O, int ldo, int Lq, int Lk, float scale) {
+    constexpr int LD = D + 4;        // LDS row stride (floats)
+    constexpr int HD = D / 2;        // channels of the QK^T reduction held by one lane half
+    constexpr int NO = D / 32;       // 32-channel output tiles
+    constexpr int CPR = D / 4;       // 16-byte... 4-channel chunks per K/V row
+    constexpr int RPP = 256 / CPR;   // K/V rows staged per pass
+    __shared__ __align__(16) float Ks[2][ATT_KT][LD];
+    __shared__ __align__(16) float Vs[2][ATT_KT][LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const T* Qb = Q + (size_t)b * Lq * ldq + h * ATT_D;
-    const T* Kb = K + (size_t)b * Lk * ldk + h * ATT_D;
-    const T* Vb = V + (size_t)b * Lk * ldv + h * ATT_D;
+    const T* Qb = Q + (size_t)b * Lq * ldq + h * D;
+    const T* Kb = K + (size_t)b * Lk * ldk + h * D;
+    const T* Vb = V + (size_t)b * Lk * ldv + h * D;
 
-    // this lane's 16 query channels d = 16*half + s, pre-scaled by sqrt(1/32)
-    float qreg[16];
+    // this lane's HD query channels d = HD*half + s, pre-scaled (a power-of-two scale commutes with the product)
+    float qreg[HD];
     {
         const int q = q0 + col;
-        const float scale = (float)0.1767766952966369;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float4 v = (q < Lq) ? ld4(Qb + (size_t)q * ldq + 16 * half + 4 * g) : float4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < HD / 4; g++) {
+            float4 v = (q < Lq) ? ld4(Qb + (size_t)q * ldq + HD * half + 4 * g) : float4{0.f, 0.f, 0.f, 0.f};
             qreg[4 * g + 0] = v.x * scale; qreg[4 * g + 1] = v.y * scale;
             qreg[4 * g + 2] = v.z * scale; qreg[4 * g + 3] = v.w * scale;
         }
     }
 
-    const int lr = tid >> 3, lc = (tid & 7) * 4;  // tile loader: row 0..31, float4 column
-    auto load_kv = [&](int kt, float4& kv, float4& vv) {
-        const int key = kt * ATT_KT + lr;
-        if (key < Lk) {
-            kv = ld4(Kb + (size_t)key * ldk + lc);
-            vv = ld4(Vb + (size_t)key * ldv + lc);
-        } else {
-            kv = float4{0.f, 0.f, 0.f, 0.f};
-            vv = float4{0.f, 0.f, 0.f, 0.f};
+    const int lr = tid / CPR, lc = (tid % CPR) * 4;  // tile loader: row, 4-channel column
+    constexpr int NLD = ATT_KT / RPP;                // passes to stage one 32-key tile (1 for D = 32, 2 for D = 64)
+    auto load_kv = [&](int kt, float4* kv, float4* vv) {
+#pragma unroll
+        for (int pss = 0; pss < NLD; pss++) {
+            const int key = kt * ATT_KT + lr + pss * RPP;
+            if (key < Lk) {
+                kv[pss] = ld4(Kb + (size_t)key * ldk + lc);
+                vv[pss] = ld4(Vb + (size_t)key * ldv + lc);
+            } else {
+                kv[pss] = float4{0.f, 0.f, 0.f, 0.f};
+                vv[pss] = float4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_kv = [&](int buf, const float4* kv, const float4* vv) {
+#pragma unroll
+        for (int pss = 0; pss < NLD; pss++) {
+            *reinterpret_cast<float4*>(&Ks[buf][lr + pss * RPP][lc]) = kv[pss];
+            *reinterpret_cast<float4*>(&Vs[buf][lr + pss * RPP][lc]) = vv[pss];
         }
     };
 
-    floatx16 oacc;
+    floatx16 oacc[NO];
 #pragma unroll
-    for (int r = 0; r < 16; r++) oacc[r] = 0.0f;
+    for (int o = 0; o < NO; o++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[o][r] = 0.0f;
     float m_run = -1e30f, l_run = 0.0f;
 
     const int ntiles = (Lk + ATT_KT - 1) / ATT_KT;
-    float4 kv, vv;
+    float4 kv[NLD], vv[NLD];
     load_kv(0, kv, vv);
-    *reinterpret_cast<float4*>(&Ks[0][lr][lc]) = kv;
-    *reinterpret_cast<float4*>(&Vs[0][lr][lc]) = vv;
+    store_kv(0, kv, vv);
     __syncthreads();
 
     for (int kt = 0; kt < ntiles; ++kt) {
@@ -107,8 +122,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q,
 #pragma unroll
         for (int r = 0; r < 16; r++) s[r] = 0.0f;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const float4 kf = *reinterpret_cast<const float4*>(&Ks[cur][col][16 * half + 4 * g]);
+        for (int g = 0; g < HD / 4; g++) {
+            const float4 kf = *reinterpret_cast<const float4*>(&Ks[cur][col][HD * half + 4 * g]);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.x, qreg[4 * g + 0], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.y, qreg[4 * g + 1], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[4 * g + 2], s, 0, 0, 0);
@@ -138,29 +153,34 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q,
         l_run = l_run * alpha + psum;
         m_run = m_new;
 #pragma unroll
-        for (int r = 0; r < 16; r++) oacc[r] *= alpha;
+        for (int o = 0; o < NO; o++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) oacc[o][r] *= alpha;
         // O^T += V^T . P^T : k-slot (step r, lane half) <-> key acc_row(r, half) on both operands
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const float vf = Vs[cur][acc_row(r, half)][col];
-            oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], oacc, 0, 0, 0);
+#pragma unroll
+            for (int o = 0; o < NO; o++) {
+                const float vf = Vs[cur][acc_row(r, half)][o * 32 + col];
+                oacc[o] = __builtin_amdgcn_mfma_f32_32x32x2f32(vf, s[r], oacc[o], 0, 0, 0);
+            }
         }
-        if (kt + 1 < ntiles) {
-            *reinterpret_cast<float4*>(&Ks[cur ^ 1][lr][lc]) = kv;
-            *reinterpret_cast<float4*>(&Vs[cur ^ 1][lr][lc]) = vv;
-        }
+        if (kt + 1 < ntiles) store_kv(cur ^ 1, kv, vv);
         __syncthreads();
     }
 
     const int q = q0 + col;
     if (q < Lq) {
         const float inv = 1.0f / l_run;
-        T* Ob = O + ((size_t)b * Lq + q) * ldo + h * ATT_D;
+        T* Ob = O + ((size_t)b * Lq + q) * ldo + h * D;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            float4 v = {oacc[4 * g + 0] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv};
-            st4(Ob + 8 * g + 4 * half, v);  // channels acc_row(4g..4g+3, half)
-        }
+        for (int o = 0; o < NO; o++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float4 v = {oacc[o][4 * g + 0] * inv, oacc[o][4 * g + 1] * inv, oacc[o][4 * g + 2] * inv,
+                            oacc[o][4 * g + 3] * inv};
+                st4(Ob + o * 32 + 8 * g + 4 * half, v);  // channels o*32 + acc_row(4g..4g+3, half)
+            }
     }
 }
 
@@ -168,9 +188,21 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
                      int B, int H, int Lq, int Lk, int dtype, hipStream_t stream) {
     if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
     dim3 grid((Lq + 127) / 128, H, B);
-#define ODAM_K(T, ...) hipLaunchKernelGGL(attention_kernel<T>, grid, dim3(256), 0, stream, (const T*)Q, ldq, (const T*)K, ldk, (const T*)V, ldv, (T*)O, ldo, Lq, Lk)
+    const float scale = (float)0.1767766952966369;   // sqrt(1/32) as torch computes it in float64, then float32
+#define ODAM_K(T, ...) hipLaunchKernelGGL((attention_kernel<T, 32>), grid, dim3(256), 0, stream, (const T*)Q, ldq, (const T*)K, ldk, (const T*)V, ldv, (T*)O, ldo, Lq, Lk, scale)
     ODAM_DISPATCH(dtype, ODAM_K, 0);
 #undef ODAM_K
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+// head dimension 64, fp32 (associator GNN: scores / 64**0.5, src/models/associator.py:47-56)
+int launch_attention_d64(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
+                         int B, int H, int Lq, int Lk, hipStream_t stream) {
+    if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
+    dim3 grid((Lq + 127) / 128, H, B);
+    hipLaunchKernelGGL((attention_kernel<float, 64>), grid, dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk,
+                       0.125f);
     ODAM_HIP(hipGetLastError());
     return 0;
 }

@@ -82,3 +82,29 @@ def make_state_dict(backbone="resnet50", hidden=256, ffn=2048, enc_layers=6, dec
         _linear(sd, name + ".layers.1", g, hidden, hidden)
         _linear(sd, name + ".layers.2", g, nout, hidden, wscale=0.5, bias=bias)
     return sd
+
+
+def make_associator_state_dict(n_self=2, n_gnn=8, seed=0):
+    """Deterministic synthetic weights under the reference Associator's key names (src/models/associator.py:163-200;
+    configs/detr_scan_net.yaml: keypoint_encoder [78,256,256], 8 GNN layers, 2 self layers)."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    sd = {}
+
+    def conv1d(p, nout, nin, wscale=1.0):
+        sd[p + ".weight"] = _u(g, (nout, nin, 1), wscale * math.sqrt(3.0 / nin))
+        sd[p + ".bias"] = 0.02 * _u(g, (nout,), 1.0)
+
+    conv1d("encoder.0", 256, 78, 0.3)
+    conv1d("encoder.2", 256, 256)
+    for grp, n in (("fuser", n_self), ("gnn", n_gnn)):
+        for i in range(n):
+            p = f"{grp}.layers.{i}."
+            conv1d(p + "attn.merge", 256, 256)
+            for k in range(3):
+                conv1d(p + f"attn.proj.{k}", 256, 256, 1.5)
+            conv1d(p + "mlp.0", 512, 512)
+            conv1d(p + "mlp.2", 256, 512, 0.5)
+            sd[p + "mlp.2.bias"] = torch.zeros(256)
+    conv1d("final_proj", 256, 256, 2.0)
+    sd["bin_score"] = torch.tensor(1.0)
+    return sd
