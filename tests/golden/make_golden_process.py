@@ -82,6 +82,29 @@ def main():
     np.savez_compressed(os.path.join(HERE, "process_tracks.npz"), **d)
     print("process golden:", len(proc.tracks), "tracks, lengths", [len(t) for t in proc.tracks])
 
+    # the same sequence with the reference's REAL Associator (CPU, synthetic weights): pins the association network
+    # inside the plugin surface (tests/test_assoc_gpu.py::test_process_sequence_with_network)
+    torch.Tensor.to = lambda self, *a, **k: self if (a and a[0] == "cuda") else orig_to(self, *a, **k)
+    from src.models.associator import Associator
+    from make_golden_assoc import CFG
+    from odam_amd import weights
+    net = Associator(CFG)
+    net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0), strict=True)
+    net.eval()
+    fwd = net.forward
+    net.forward = lambda data, thr, eval_only=False: fwd(data, thr, eval_only=eval_only, device="cpu")
+    proc = OdamProcess(None, net, None, None, score_threshold=0.2)
+    proc.init_sequence(sc["K"], 480, 640)
+    proc.run_detector = lambda rgb, fid, T: [list(r) for r in per[fid]]
+    for i, fid in enumerate(sc["img_names"]):
+        proc.process_frame(None, fid, sc["T_wcs"][i])
+    torch.Tensor.to = orig_to
+    d2 = dict(n_tracks=np.int32(len(proc.tracks)))
+    for i, t in enumerate(proc.tracks):
+        d2[f"track{i}"] = t
+    np.savez_compressed(os.path.join(HERE, "process_tracks_net.npz"), **d2)
+    print("process golden with the reference associator:", len(proc.tracks), "tracks, lengths", [len(t) for t in proc.tracks])
+
 
 if __name__ == "__main__":
     main()
