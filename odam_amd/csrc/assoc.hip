@@ -69,50 +69,65 @@ __global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, in
     *reinterpret_cast<float4*>(x + (size_t)r * ldx + c4) = a;
 }
 
-// log_optimal_transport + log_sinkhorn_iterations (associator.py:283-312), one workgroup:
+// log_optimal_transport + log_sinkhorn_iterations (associator.py:283-312), one 1024-thread workgroup:
 //   couplings Z[(m+1) x (n+1)] = [[scores, alpha], [alpha, alpha]] in LDS; u, v in LDS;
 //   iters x { u = log_mu - logsumexp_j(Z + v);  v = log_nu - logsumexp_i(Z + u) };  out = Z + u + v - norm
-__global__ __launch_bounds__(256) void sinkhorn_kernel(const float* __restrict__ scores, int lds, int m, int n,
-                                                       float alpha, int iters, float* __restrict__ out) {
+// A row (or column) is reduced by a group of 8 lanes (xor butterflies inside the group), 128 groups at a time.
+constexpr int SK_NT = 1024, SK_G = 8;
+
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1)); v = fmaxf(v, __shfl_xor(v, 2)); v = fmaxf(v, __shfl_xor(v, 4));
+    return v;
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+    return v;
+}
+
+__global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict__ scores, int lds, int m, int n,
+                                                         float alpha, int iters, float* __restrict__ out) {
     extern __shared__ float sm[];
     const int M1 = m + 1, N1 = n + 1;
     float* Z = sm;                 // [M1][N1]
     float* u = Z + M1 * N1;        // [M1]
     float* v = u + M1;             // [N1]
     const int tid = threadIdx.x;
-    for (int i = tid; i < M1 * N1; i += 256) {
+    for (int i = tid; i < M1 * N1; i += SK_NT) {
         const int r = i / N1, c = i - r * N1;
         Z[i] = (r < m && c < n) ? scores[(size_t)r * lds + c] : alpha;
     }
-    for (int i = tid; i < M1; i += 256) u[i] = 0.0f;
-    for (int i = tid; i < N1; i += 256) v[i] = 0.0f;
+    for (int i = tid; i < M1; i += SK_NT) u[i] = 0.0f;
+    for (int i = tid; i < N1; i += SK_NT) v[i] = 0.0f;
     const float norm = -logf((float)m + (float)n);
     const float log_mu_last = logf((float)n) + norm, log_nu_last = logf((float)m) + norm;
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+    const int grp = tid / SK_G, gl = tid % SK_G;
+    constexpr int NG = SK_NT / SK_G;
     for (int it = 0; it < iters; ++it) {
-        for (int r = tid; r < M1; r += 256) {          // rows: <= 31 entries, one lane each
+        for (int r0 = 0; r0 < M1; r0 += NG) {            // u: one group per row
+            const int r = r0 + grp;
             float mx = -INFINITY;
-            for (int c = 0; c < N1; c++) mx = fmaxf(mx, Z[r * N1 + c] + v[c]);
+            if (r < M1) for (int c = gl; c < N1; c += SK_G) mx = fmaxf(mx, Z[r * N1 + c] + v[c]);
+            mx = group_max(mx);
             float sum = 0.0f;
-            for (int c = 0; c < N1; c++) sum += expf(Z[r * N1 + c] + v[c] - mx);
-            u[r] = ((r < m) ? norm : log_mu_last) - (logf(sum) + mx);
+            if (r < M1) for (int c = gl; c < N1; c += SK_G) sum += expf(Z[r * N1 + c] + v[c] - mx);
+            sum = group_sum(sum);
+            if (r < M1 && gl == 0) u[r] = ((r < m) ? norm : log_mu_last) - (logf(sum) + mx);
         }
         __syncthreads();
-        for (int c = wave; c < N1; c += 4) {           // columns: one wavefront each, lanes stride the rows
+        for (int c0 = 0; c0 < N1; c0 += NG) {            // v: one group per column
+            const int c = c0 + grp;
             float mx = -INFINITY;
-            for (int r = lane; r < M1; r += 64) mx = fmaxf(mx, Z[r * N1 + c] + u[r]);
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) mx = fmaxf(mx, __shfl_xor(mx, s));
+            if (c < N1) for (int r = gl; r < M1; r += SK_G) mx = fmaxf(mx, Z[r * N1 + c] + u[r]);
+            mx = group_max(mx);
             float sum = 0.0f;
-            for (int r = lane; r < M1; r += 64) sum += expf(Z[r * N1 + c] + u[r] - mx);
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) sum += __shfl_xor(sum, s);
-            if (lane == 0) v[c] = ((c < n) ? norm : log_nu_last) - (logf(sum) + mx);
+            if (c < N1) for (int r = gl; r < M1; r += SK_G) sum += expf(Z[r * N1 + c] + u[r] - mx);
+            sum = group_sum(sum);
+            if (c < N1 && gl == 0) v[c] = ((c < n) ? norm : log_nu_last) - (logf(sum) + mx);
         }
         __syncthreads();
     }
-    for (int i = tid; i < M1 * N1; i += 256) {
+    for (int i = tid; i < M1 * N1; i += SK_NT) {
         const int r = i / N1, c = i - r * N1;
         out[i] = Z[i] + u[r] + v[c] - norm;
     }
@@ -350,7 +365,7 @@ extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, con
     Lin sc; sc.w = m->mD; sc.b = nullptr; sc.K = D; sc.N = ND;
     RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
     const size_t lds = ((size_t)(T + 1) * (n_det + 1) + (T + 1) + (n_det + 1)) * sizeof(float);
-    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(256), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out);
+    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -365,7 +380,7 @@ extern "C" int odam_assoc_sinkhorn(const float* scores, int lds_, int m_, int n_
         attr = true;
     }
     const size_t lds = ((size_t)(m_ + 1) * (n_ + 1) + (m_ + 1) + (n_ + 1)) * sizeof(float);
-    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, scores, lds_, m_, n_, alpha, iters, Z_out);
+    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, (hipStream_t)stream, scores, lds_, m_, n_, alpha, iters, Z_out);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
