@@ -13,11 +13,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // One k-tile is 8 chunks of 16 bytes per row in both precisions: 32 fp32 or 64 bf16 values; LDS rows are
 // padded by one chunk (144-byte rows: 16-byte aligned, conflict-free for ds_read_b128).
 constexpr int LDS_STRIDE = 36;  // floats per LDS row
+#ifndef CG_ABLATE
+#define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier
+#endif
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 
-template <int BM, int BN, int WM, int WN, bool BF16>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_VOFF = 0x80000000u;   // >= num_records of every buffer descriptor below: the load returns zeros
+
+// UT ("uniform tap"): Cin is a multiple of the k-tile, so a whole k-tile lies inside one filter tap and the tap,
+// its input offset and the channel offset are wave-uniform (SGPRs).  The gather then costs three VALU
+// instructions per 16-byte load: per-row tap-validity bit -> select the row's byte offset or an out-of-range one ->
+// buffer_load_dwordx4 (hardware returns zeros for the padding halo and the ragged last tile; no branches).
+template <int BM, int BN, int WM, int WN, bool BF16, bool UT>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a) {
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;   // elements per 16-byte chunk
@@ -30,9 +40,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     constexpr int B_LD = BN / RPP;
     static_assert(BM % RPP == 0 && BN % RPP == 0, "tile rows divide over the loader threads");
 
-    __shared__ __align__(16) float smem[2 * (BM + BN) * LDS_STRIDE];   // 36 / 54 / 72 KiB, static
-    float* As = smem;                         // [2][BM][LDS_STRIDE]
-    float* Bs = smem + 2 * BM * LDS_STRIDE;   // [2][BN][LDS_STRIDE]
+    // LDS tile image.  Register-staged path: rows padded to 36 floats.  UT path: the tiles are written by LDS-DMA
+    // (buffer_load ... lds: one wave-instruction fills 8 rows x 128 B, lane-linear), so rows are unpadded and the
+    // 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7) -- the DMA's *source* address carries the
+    // permutation, ds_read_b128 applies it again; every 16-lane read group then covers 16 distinct slots.
+    constexpr int LDS_LD = UT ? 32 : LDS_STRIDE;
+    __shared__ __align__(16) float smem[2 * (BM + BN) * LDS_LD];   // static: 32 / 48 / 64 KiB (UT)
+    float* As = smem;                      // [2][BM][LDS_LD]
+    float* Bs = smem + 2 * BM * LDS_LD;    // [2][BN][LDS_LD]
 
     const T* __restrict__ Ag = reinterpret_cast<const T*>(a.A);
     const T* __restrict__ Wg = reinterpret_cast<const T*>(a.Wt);
@@ -85,8 +100,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     const int ntaps = a.KH * a.KW;
     const int kw_inv = (65536 + a.KW - 1) / a.KW;  // tap / KW for tap < 64, KW <= 7
 
+    // UT bookkeeping: descriptors over the input (rebased to the first image this tile touches, minus the padding
+    // margin so every row offset is non-negative) and the filters; per row a byte offset and a bit per filter tap.
+    __amdgpu_buffer_rsrc_t a_rs, w_rs;
+    unsigned a_voff[A_LD], a_mask[A_LD], w_voff[B_LD];
+    if constexpr (UT) {
+        const int b0 = m0 / hw;
+        const int csrc = c4 ^ ((r0 >> 1) & 7);   // RPP % 16 == 0: the permutation key is the same for every i
+        const int margin = (a.pad * a.W + a.pad) * lda;
+        a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Ag + (size_t)b0 * a.H * a.W * lda - margin), 0, (int)OOB_VOFF, 0x00020000);
+        w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)OOB_VOFF, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < A_LD; i++) {
+            a_voff[i] = (unsigned)(a_base[i] - b0 * a.H * a.W * lda + margin + csrc * EPC) * (unsigned)sizeof(T);
+            unsigned mk = 0;
+            for (int t = 0; t < ntaps; t++) {
+                const int ky = (t * kw_inv) >> 16, kx = t - ky * a.KW;
+                if ((unsigned)(a_iy0[i] + ky) < (unsigned)a.H && (unsigned)(a_ix0[i] + kx) < (unsigned)a.W) mk |= 1u << t;
+            }
+            a_mask[i] = a_ok[i] ? mk : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; i++)
+            w_voff[i] = b_ok[i] ? (unsigned)((n0 + r0 + RPP * i) * a.Kpad + csrc * EPC) * (unsigned)sizeof(T) : OOB_VOFF;
+    }
+
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     float4 ra[A_LD], rb[B_LD];
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, int buf) {
+        if constexpr (UT) {
+            const int kb = kt * BKE;
+            const int tap = kb >> a.log2Cin;
+            const int ky = (tap * kw_inv) >> 16;
+            const int kx = tap - ky * a.KW;
+            const int soff = ((ky * a.W + kx) * lda + (kb & (a.Cin - 1))) * (int)sizeof(T);
+#pragma unroll
+            for (int i = 0; i < A_LD; i++) {
+                const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB_VOFF;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(As + (buf * BM + wave_u * 8 + RPP * i) * LDS_LD),
+                                                         16, (int)vo, soff, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < B_LD; i++)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(Bs + (buf * BN + wave_u * 8 + RPP * i) * LDS_LD),
+                                                         16, (int)w_voff[i], kb * (int)sizeof(T), 0, 0);
+            return;
+        }
         const int k0 = kt * BKE + c4 * EPC;
         const int tap = k0 >> a.log2Cin;
         const int ci = k0 & (a.Cin - 1);
@@ -105,6 +165,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             rb[i] = b_ok[i] ? *reinterpret_cast<const float4*>(w_ptr[i] + kt * BKE) : float4{0.f, 0.f, 0.f, 0.f};
     };
     auto store_tile = [&](int buf) {
+        if constexpr (UT) return;
 #pragma unroll
         for (int i = 0; i < A_LD; i++)
             *reinterpret_cast<float4*>(&As[(buf * BM + r0 + RPP * i) * LDS_STRIDE + c4 * 4]) = ra[i];
@@ -122,8 +183,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
     const int nk = a.Kpad / BKE;
-    load_tile(0);
+    load_tile(0, 0);
     store_tile(0);
+    if constexpr (UT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     // Operand fragments: lane (row = lane & 31, half = lane >> 5) reads the 16-byte chunk 2 g + half of its row for
@@ -131,29 +193,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     // (step, half) -> k map, so the k order inside a group is free).  bf16: 8 values = exactly the operand of one
     // v_mfma_f32_32x32x16_bf16 (lane half h holds k = 8 h + j).
     const int frag_row = lane & 31;
-    const int frag_k = (lane >> 5) * 4;
+    const int frag_k = UT ? 0 : (lane >> 5) * 4;
+    int frag_q[4];   // float offset of k-group q's chunk inside the row
+#pragma unroll
+    for (int q = 0; q < 4; q++) frag_q[q] = UT ? ((2 * q + (lane >> 5)) ^ ((frag_row >> 1) & 7)) * 4 : q * 8;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const float* Ab = &As[(cur * BM + wm * (BM / WM) + frag_row) * LDS_STRIDE + frag_k];
-        const float* Bb = &Bs[(cur * BN + wn * (BN / WN) + frag_row) * LDS_STRIDE + frag_k];
+        const float* Ab = &As[(cur * BM + wm * (BM / WM) + frag_row) * LDS_LD + frag_k];
+        const float* Bb = &Bs[(cur * BN + wn * (BN / WN) + frag_row) * LDS_LD + frag_k];
         // fragments of k-group 0 first, then the next tile's global loads are issued under that LDS latency;
         // every k-group's fragments are fetched one group ahead of the MFMAs that consume them
         float4 af[2][TM], bf[2][TN];
 #pragma unroll
-        for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE);
+        for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + frag_q[0]);
 #pragma unroll
-        for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE);
-        if (kt + 1 < nk) load_tile(kt + 1);
+        for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + frag_q[0]);
+        if (!(CG_ABLATE & 1) && kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int pb = q & 1;
             if (q + 1 < 4) {
 #pragma unroll
                 for (int i = 0; i < TM; i++)
-                    af[pb ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_STRIDE + (q + 1) * 8);
+                    af[pb ^ 1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + frag_q[(q + 1) & 3]);
 #pragma unroll
                 for (int j = 0; j < TN; j++)
-                    bf[pb ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_STRIDE + (q + 1) * 8);
+                    bf[pb ^ 1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + frag_q[(q + 1) & 3]);
             }
 #pragma unroll
             for (int i = 0; i < TM; i++)
@@ -171,8 +236,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
                     }
                 }
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
-        __syncthreads();
+        if (!(CG_ABLATE & 2) && kt + 1 < nk) store_tile(cur ^ 1);
+        if constexpr (UT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile kt + 1 has landed
+        if (!(CG_ABLATE & 4)) __syncthreads();
     }
 
     // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
@@ -193,8 +259,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         // Wide path: the accumulator layout (one column per lane) would give 4-byte accesses; the sub-tile is
         // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
         // 16-byte (fp32) / 8-byte (bf16) residual loads and stores, 256 / 128 contiguous bytes per 16 lanes.
-        constexpr int EP_LD = WCOLS + 4;
-        static_assert(WM * WN * 32 * EP_LD <= 2 * (BM + BN) * LDS_STRIDE, "epilogue staging fits the tile buffers");
+        // Unpadded rows: a wave writes 32 consecutive floats of one row per half (ds_write_b32: conflict-free), and
+        // the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) land on 16 distinct 16-byte slots for both
+        // 128-byte and 256-byte rows.
+        constexpr int EP_LD = WCOLS;
+        static_assert(WM * WN * 32 * EP_LD <= 2 * (BM + BN) * LDS_LD, "epilogue staging fits the tile buffers");
         float* Ep = smem + wave * (32 * EP_LD);     // one 32-row slab per wave, reused for each of its TM row tiles
         constexpr int LPR = WCOLS / 4;              // lanes per row
         constexpr int RPI = 64 / LPR;               // rows per wave-instruction
@@ -286,10 +355,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 template <int BM, int BN, int WM, int WN>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
-    if (a.dtype == ODAM_CG_BF16)
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
-    else
-        hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false>), dim3(tiles), dim3(64 * WM * WN), 0, stream, a);
+    const bool bf = a.dtype == ODAM_CG_BF16;
+    // uniform-tap gather: whole k-tiles inside one tap, a 32-bit tap mask, and 31-bit byte offsets from the
+    // first image a tile touches (a tile spans at most BM / (Ho*Wo) + 2 images)
+    const long esz = bf ? 2 : 4, lda = a.lda > 0 ? a.lda : a.Cin;
+    const long span = ((long)BM / ((long)a.Ho * a.Wo) + 2) * a.H * a.W * lda + (long)(a.pad * a.W + a.pad) * lda + a.Cin;
+    static const bool no_ut = getenv("ODAM_CG_NO_UT") != nullptr;
+    const bool ut = !no_ut && a.Cin % (bf ? 64 : 32) == 0 && a.KH * a.KW <= 32 && span * esz < 0x7fffffffL &&
+                    (long)a.Cout * a.Kpad * esz < 0x7fffffffL;
+    const dim3 g(tiles), b(64 * WM * WN);
+    if (bf) {
+        if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, false>), g, b, 0, stream, a);
+    } else {
+        if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, true>), g, b, 0, stream, a);
+        else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, false>), g, b, 0, stream, a);
+    }
     ODAM_HIP(hipGetLastError());
     return 0;
 }
