@@ -60,16 +60,17 @@ def compute_oriented_bbox(pts):
     edges = (contour[1:] - contour[:-1]).astype(np.float64)
     angles = np.array([abs(math.atan2(e[1], e[0]) % (math.pi / 2)) for e in edges])
     angles = np.unique(angles)
+    # all candidate rotations at once (the reference loops; np.matmul runs the same 2x2 @ 2xV product per angle)
+    ca = np.array([[math.cos(a), math.cos(a - (math.pi / 2)), math.cos(a + (math.pi / 2))] for a in angles]).reshape(-1, 3)
+    Rs = np.stack([ca[:, [0, 1]], ca[:, [2, 0]]], axis=1)                 # [A, 2, 2]
+    rot = np.matmul(Rs, np.transpose(contour))                            # [A, 2, V]
+    mins, maxs = np.nanmin(rot, axis=2), np.nanmax(rot, axis=2)           # [A, 2]
+    areas = (maxs[:, 0] - mins[:, 0]) * (maxs[:, 1] - mins[:, 1])
     best = (0, 10000000000, 0, 0, 0, 0)
-    for a in angles:
-        R = np.array([[math.cos(a), math.cos(a - (math.pi / 2))],
-                      [math.cos(a + (math.pi / 2)), math.cos(a)]])
-        rot = np.dot(R, np.transpose(contour))
-        min_x, max_x = np.nanmin(rot[0], axis=0), np.nanmax(rot[0], axis=0)
-        min_y, max_y = np.nanmin(rot[1], axis=0), np.nanmax(rot[1], axis=0)
-        area = (max_x - min_x) * (max_y - min_y)
-        if area < best[1]:
-            best = (a, area, min_x, max_x, min_y, max_y)
+    ok = areas < best[1]                                                  # NaN areas never win
+    if ok.any():
+        i = int(np.flatnonzero(areas == areas[ok].min())[0])              # the first smallest area wins
+        best = (angles[i], areas[i], mins[i, 0], maxs[i, 0], mins[i, 1], maxs[i, 1])
     a, _, min_x, max_x, min_y, max_y = best
     R = np.array([[math.cos(a), math.cos(a - (math.pi / 2))], [math.cos(a + (math.pi / 2)), math.cos(a)]])
     c2 = np.zeros((4, 2))
