@@ -206,7 +206,9 @@ class Detector:
         return out
 
     def detect_resident_chunks(self, frames, img_size, intr_mat, chunk=128):
-        """Forward + per-query post-processing over resident frames, where (1) batches alternate between `n_streams` HIP streams, each with its own
+        """Forward + per-query post-processing over frames resident in HBM -- or, when `frames` is a (pinned) host
+        tensor, uploaded batch by batch on a copy stream into two staging buffers per compute stream, so the
+        PCIe transfer of batch n+1 runs under the kernels of batch n -- where (1) batches alternate between `n_streams` HIP streams, each with its own
         native handle/workspace, so the tile-quantisation tails, launch gaps and HBM-bound layers of one batch
         are filled by kernels of another (frames are independent); (2) the rows come back in chunks while the
         GPU keeps working: everything is enqueued first (forward + post-processing per batch, then per chunk an
@@ -239,6 +241,12 @@ class Detector:
             st.wait_event(start)          # inputs produced on the caller's stream are visible
         events = []
         nb = 0
+        on_host = not frames.is_cuda
+        if on_host:
+            if getattr(self, "_stage", None) is None or self._stage[0][0].shape[2:] != (H, W) or len(self._stage) != ns:
+                self._stage = [[torch.empty(mb, 3, H, W, device=dev, dtype=torch.float32) for _ in range(2)] for _ in range(ns)]
+                self._copy_stream = torch.cuda.Stream(device=dev)
+            stage_free = [[None, None] for _ in range(ns)]   # event: the forward that last read this buffer is done
         with torch.cuda.device(dev):
             for c0 in range(0, N, chunk):
                 c1 = min(N, c0 + chunk)
@@ -250,7 +258,19 @@ class Detector:
                     used.add(k)
                     lg, bx, an, of, sz, dp = self._mscratch[k]
                     sp = ctypes.c_void_p(self._streams[k].cuda_stream)
-                    _lib.check(L.odam_detr_forward(handles[k], _lib.ptr(frames[b0:b0 + B]), ctypes.c_int(B), _lib.ptr(lg),
+                    src = frames[b0:b0 + B]
+                    if on_host:
+                        j = ((nb - 1) // ns) & 1
+                        buf = self._stage[k][j][:B]
+                        if stage_free[k][j] is not None:
+                            self._copy_stream.wait_event(stage_free[k][j])
+                        with torch.cuda.stream(self._copy_stream):
+                            buf.copy_(src, non_blocking=True)
+                            up = torch.cuda.Event()
+                            up.record(self._copy_stream)
+                        self._streams[k].wait_event(up)
+                        src = buf
+                    _lib.check(L.odam_detr_forward(handles[k], _lib.ptr(src), ctypes.c_int(B), _lib.ptr(lg),
                                                    _lib.ptr(bx), _lib.ptr(an), _lib.ptr(of), _lib.ptr(sz), _lib.ptr(dp),
                                                    ctypes.c_void_p(0), sp), "odam_detr_forward")
                     _lib.check(L.odam_detr_postprocess(handles[k], _lib.ptr(lg), _lib.ptr(bx), _lib.ptr(an), _lib.ptr(of),
@@ -258,6 +278,9 @@ class Detector:
                                                        K9.ctypes.data_as(_lib.c_float_p), ctypes.c_float(img_w),
                                                        ctypes.c_float(img_h), _lib.ptr(rows[b0:b0 + B]), sp),
                                "odam_detr_postprocess")
+                    if on_host:
+                        stage_free[k][j] = torch.cuda.Event()
+                        stage_free[k][j].record(self._streams[k])
                 for k in used:               # the chunk's copy waits for every stream that produced part of it
                     e = torch.cuda.Event()
                     e.record(self._streams[k])
