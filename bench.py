@@ -53,6 +53,7 @@ def main():
     ap.add_argument("--objects", type=int, default=30)
     ap.add_argument("--batch", type=int, default=0, help="frames per forward; 0 = by shard size")
     ap.add_argument("--streams", type=int, default=0, help="concurrent HIP streams; 0 = by shard size")
+    ap.add_argument("--chunk", type=int, default=0, help="frames per device->host copy of detections; 0 = 4 batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo + "
                     "--one-device let several ranks share one GPU for a functional check of the N > 1 path")
@@ -81,9 +82,10 @@ def main():
 
     n_local = f1 - f0
     if args.batch <= 0:
-        args.batch = 32 if n_local >= 512 else (16 if n_local >= 192 else 8)
+        args.batch = 32   # best at every shard size measured (125 ... 1000 frames, tests/native/sweep_shard.sh)
     if args.streams <= 0:
         args.streams = 2 if args.batch >= 16 else 3
+    args.chunk = args.chunk or 4 * args.batch
     detector = det_mod.Detector(max_batch=args.batch, device=device, n_streams=args.streams)
     detector.load_state_dict(weights.make_state_dict(seed=0))
     fitter = sq.SqFitter(device, 200)
@@ -103,7 +105,7 @@ def main():
         per_frame = []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for c0, rows16 in detector.detect_resident_chunks(frames, img_size, K, chunk=16 * args.batch):
+        for c0, rows16 in detector.detect_resident_chunks(frames, img_size, K, chunk=args.chunk):
             for i in range(rows16.shape[0]):   # host: threshold + NMS + 79-column rows, overlapped with the GPU
                 sel = detector.select(rows16[i], 0.6, True, 30)
                 objs = {k: [v] for k, v in sel.items()}

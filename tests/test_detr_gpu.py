@@ -42,6 +42,11 @@ def _pack(w):
     (1, 1, 300, 256, 19, 1, 1, 0, False, False),    # class head: N = 19
     (3, 25, 34, 2048, 256, 1, 1, 0, False, False),  # input_proj, K = 2048
     (1, 1, 1, 256, 1, 1, 1, 0, False, False),       # depth head on one token
+    (5, 5, 5, 32, 48, 3, 1, 1, False, False),       # a 128-row tile spans six images; one k-tile per filter tap
+    (7, 6, 9, 64, 96, 5, 1, 2, True, False),        # 25 taps: the widest kernel the tap bitmask path takes
+    (2, 12, 12, 32, 32, 7, 1, 3, False, False),     # 49 taps: register-staged gather with Cin >= 32
+    (3, 9, 9, 16, 32, 3, 1, 1, True, False),        # Cin < k-tile: two taps inside one k-tile
+    (2, 31, 29, 64, 256, 3, 2, 1, False, True),     # stride 2 + residual, N = 256
 ])
 def test_conv_gemm_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
     from odam_amd import _lib
