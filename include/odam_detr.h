@@ -90,16 +90,18 @@ int odam_detr_profile_read(odam_detr* m, int* n_launches, double* total_ms, doub
 int odam_detr_profile_read_attention(odam_detr* m, int* n_launches, double* total_ms, double* total_flops);
 
 /* ---- single-operator entry points (the same kernels the forward uses; for parity tests and reuse) ---- */
-/* NHWC convolution / linear:  x [dev][B,H,W,Cin] (Cin power of two >= 4), w_packed [dev][Cout][Kpad]
- * (k = (ky*KW+kx)*Cin+ci, zero padded to a multiple of 32), scale/bias/residual nullable, y [dev][B,Ho,Wo,Cout] */
+/* NHWC convolution / linear:  x [dev][B,H,W,Cin] (Cin power of two >= 4), w_packed [dev][Cout][Kpad], zero padded
+ * to a multiple of the k-tile (32 fp32 / 64 bf16), scale/bias/residual nullable, y [dev][B,Ho,Wo,Cout].
+ * k_order 0: k = (ky*KW+kx)*Cin + ci.  k_order 1 (Cin % k-tile == 0, KH*KW <= 32; what the detector uses for its 3x3
+ * layers): k = ((ci / kt)*KH*KW + ky*KW+kx)*kt + ci % kt -- all taps of one channel chunk in consecutive k-tiles. */
 int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const float* scale, const float* bias,
                         const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                        int stride, int pad, int Kpad, int relu, void* stream);
+                        int stride, int pad, int Kpad, int relu, int k_order, void* stream);
 /* same kernel in bf16 mode: x, w_packed, residual, y are raw bfloat16 (Cin a power of two >= 8, Kpad % 64 == 0);
  * out_f32 != 0 writes y as fp32 */
 int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* scale, const float* bias,
                              const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
-                             int stride, int pad, int Kpad, int relu, int out_f32, void* stream);
+                             int stride, int pad, int Kpad, int relu, int out_f32, int k_order, void* stream);
 int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                       int B, int H, int Lq, int Lk, void* stream);
 int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y, int M,

@@ -2,7 +2,7 @@
 //
 //   C[m, n] = epilogue( sum_k A(m, k) * W[n, k] )
 //     m = output pixel (b, oy, ox) of an NHWC tensor, n = output channel,
-//     k = (ky * KW + kx) * Cin + ci  -- the input is gathered on the fly (no im2col buffer).
+//     k = (ky * KW + kx) * Cin + ci  -- the input is gathered on the fly (no im2col buffer); see k_order.
 //   epilogue: * scale[n] + bias[n] (FrozenBatchNorm folded to scale/bias, or a Linear bias),
 //             + residual[m, n], ReLU -- all optional.
 //
@@ -42,6 +42,9 @@ struct ConvGemmArgs {
     int dtype;           // ODAM_CG_F32 / ODAM_CG_BF16: v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16, fp32 accumulate
     int out_f32;         // bf16 mode only: write C as fp32
     int lda;             // elements between consecutive input pixels (0 = Cin): reads a column block of a wider buffer
+    int k_order;         // 0: k = (tap, ci).  1: k = (ci / kt, tap, ci % kt) with kt = the k-tile (32 fp32 / 64 bf16),
+                         //    Cin % kt == 0: the taps of one channel chunk are consecutive k-tiles, so a workgroup re-reads
+                         //    its input window from L2 while it is still there (tap-major revisits it 8+ k-tiles later)
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);

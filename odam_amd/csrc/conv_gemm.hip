@@ -99,6 +99,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     }
     const int ntaps = a.KH * a.KW;
     const int kw_inv = (65536 + a.KW - 1) / a.KW;  // tap / KW for tap < 64, KW <= 7
+    const int nt_inv = (65536 + ntaps - 1) / ntaps; // kt / ntaps for kt < 2048, ntaps <= 32 (checked at launch)
 
     // UT bookkeeping: descriptors over the input (rebased to the first image this tile touches, minus the padding
     // margin so every row offset is non-negative) and the filters; per row a byte offset and a bit per filter tap.
@@ -131,10 +132,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     auto load_tile = [&](int kt, int buf) {
         if constexpr (UT) {
             const int kb = kt * BKE;
-            const int tap = kb >> a.log2Cin;
+            int tap, cbase;
+            if (a.k_order) {   // chunk-major: kt = chunk * ntaps + tap
+                const int chunk = (kt * nt_inv) >> 16;
+                tap = kt - chunk * ntaps;
+                cbase = chunk * BKE;
+            } else {
+                tap = kb >> a.log2Cin;
+                cbase = kb & (a.Cin - 1);
+            }
             const int ky = (tap * kw_inv) >> 16;
             const int kx = tap - ky * a.KW;
-            const int soff = ((ky * a.W + kx) * lda + (kb & (a.Cin - 1))) * (int)sizeof(T);
+            const int soff = ((ky * a.W + kx) * lda + cbase) * (int)sizeof(T);
 #pragma unroll
             for (int i = 0; i < A_LD; i++) {
                 const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB_VOFF;
@@ -148,8 +157,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             return;
         }
         const int k0 = kt * BKE + c4 * EPC;
-        const int tap = k0 >> a.log2Cin;
-        const int ci = k0 & (a.Cin - 1);
+        int tap = k0 >> a.log2Cin;
+        int ci = k0 & (a.Cin - 1);
+        if (a.k_order) {
+            const int chunk = (kt * nt_inv) >> 16;
+            tap = kt - chunk * ntaps;
+            ci = chunk * BKE + c4 * EPC;
+        }
         const int ky = (tap * kw_inv) >> 16;
         const int kx = tap - ky * a.KW;
         const bool tap_ok = tap < ntaps;
@@ -379,6 +393,8 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const int epc = (a.dtype == ODAM_CG_BF16) ? 8 : 4;
     if (a.Kpad % (8 * epc) != 0 || a.Cin < epc || (a.Cin & (a.Cin - 1)) != 0 || a.KW > 7 || a.KH * a.KW > 64)
         return odam_fail(1, "conv_gemm: unsupported shape (Kpad % k-tile, Cin a power of two >= one 16-byte chunk, KW <= 7)");
+    if (a.k_order && (a.Cin % (8 * epc) != 0 || a.KH * a.KW > 32 || a.Kpad / (8 * epc) >= 2048))
+        return odam_fail(1, "conv_gemm: k_order 1 needs Cin % k-tile == 0, at most 32 taps, fewer than 2048 k-tiles");
     if (a.M <= 0 || a.Cout <= 0) return 0;
     static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 3;  // 8-wave tiles (+2-3 %)
     if (a.Cout <= 64) return (variant & 2) ? launch_cfg<128, 64, 4, 2>(a, stream) : launch_cfg<128, 64, 4, 1>(a, stream);

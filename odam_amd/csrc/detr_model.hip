@@ -33,6 +33,7 @@ struct Conv {          // packed convolution / linear layer on device
     float* scale = nullptr;  // [Cout] or null
     float* bias = nullptr;   // [Cout] or null
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
+    int k_order = 0;         // conv_gemm.h: 1 = channel-chunk-major K (multi-tap filters with Cin % k-tile == 0)
 };
 
 struct Bottleneck {
@@ -145,11 +146,17 @@ int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad) {
     const int K = KH * KW * CinP;
     const int Kpad = (K + 8 * epc - 1) / (8 * epc) * (8 * epc);
     std::vector<float> p((size_t)Cout * Kpad, 0.0f);
+    const int kt = 8 * epc, ntaps = KH * KW;
+    const int k_order = (ntaps > 1 && ntaps <= 32 && CinP % kt == 0) ? 1 : 0;
     for (int o = 0; o < Cout; o++)
         for (int ci = 0; ci < Cin; ci++)
             for (int ky = 0; ky < KH; ky++)
-                for (int kx = 0; kx < KW; kx++)
-                    p[(size_t)o * Kpad + (ky * KW + kx) * CinP + ci] = w.data[(((size_t)o * Cin + ci) * KH + ky) * KW + kx];
+                for (int kx = 0; kx < KW; kx++) {
+                    const int tap = ky * KW + kx;
+                    const int k = k_order ? ((ci / kt) * ntaps + tap) * kt + ci % kt : tap * CinP + ci;
+                    p[(size_t)o * Kpad + k] = w.data[(((size_t)o * Cin + ci) * KH + ky) * KW + kx];
+                }
+    c.k_order = k_order;
     c.Cin = CinP; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
     return m->upload_w(&c.w, p);
 }
@@ -197,6 +204,7 @@ int run_conv(const Conv& c, const void* x, int B, int H, int W, const void* res,
     a.Ho = conv_out(H, c.KH, c.stride, c.pad); a.Wo = conv_out(W, c.KW, c.stride, c.pad);
     a.Cout = c.Cout; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad; a.Kpad = c.Kpad;
     a.relu = relu ? 1 : 0; a.M = B * a.Ho * a.Wo; a.ldc = ldc > 0 ? ldc : c.Cout;
+    a.k_order = c.k_order;
     return odam_cg::launch_conv_gemm(a, st);
 }
 
@@ -536,21 +544,23 @@ extern "C" int odam_detr_postprocess(odam_detr* m, const float* logits, const fl
 // ---- single-operator entry points -------------------------------------------------------------------
 extern "C" int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const float* scale, const float* bias,
                                    const float* residual, float* y, int B, int H, int W, int Cin, int Cout, int KH,
-                                   int KW, int stride, int pad, int Kpad, int relu, void* stream) {
+                                   int KW, int stride, int pad, int Kpad, int relu, int k_order, void* stream) {
     if (!x || !w_packed || !y) return odam_fail(1, "odam_op_conv2d_nhwc: null pointer");
     Conv c;
     c.w = const_cast<float*>(w_packed); c.scale = const_cast<float*>(scale); c.bias = const_cast<float*>(bias);
     c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
+    c.k_order = k_order;
     return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream);
 }
 
 extern "C" int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* scale, const float* bias,
                                         const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH,
-                                        int KW, int stride, int pad, int Kpad, int relu, int out_f32, void* stream) {
+                                        int KW, int stride, int pad, int Kpad, int relu, int out_f32, int k_order, void* stream) {
     if (!x || !w_packed || !y) return odam_fail(1, "odam_op_conv2d_nhwc_bf16: null pointer");
     Conv c;
     c.w = const_cast<void*>(w_packed); c.scale = const_cast<float*>(scale); c.bias = const_cast<float*>(bias);
     c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
+    c.k_order = k_order;
     return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream, 1, out_f32);
 }
 

@@ -33,7 +33,7 @@ def conv_case(B, H, W, Cin, Cout, k, s, p, relu, res, bn):
     dr = d(r.permute(0, 2, 3, 1)) if res else None
     dy = torch.empty(B, Ho, Wo, Cout, device=dev)
     _lib.check(L.odam_op_conv2d_nhwc(_lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dbi), _lib.ptr(dr), _lib.ptr(dy),
-               B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), st()), "conv")
+               B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), 0, st()), "conv")
     got = dy.cpu().permute(0, 3, 1, 2)
     err = (got - y).abs().max().item() / max(y.abs().max().item(), 1e-6)
     print(f"conv B{B} {H}x{W} {Cin}->{Cout} k{k}s{s}p{p} relu={relu} res={res} bn={bn}: rel err {err:.2e}")

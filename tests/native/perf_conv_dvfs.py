@@ -6,11 +6,11 @@ L = _lib.lib(); dev = torch.device("cuda:0")
 st = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 def run(x, w, y, B, H, W, Cin, Cout, k, s, p, Kpad, n=20):
     for _ in range(3):
-        L.odam_op_conv2d_nhwc(_lib.ptr(x), _lib.ptr(w), None, None, None, _lib.ptr(y), B, H, W, Cin, Cout, k, k, s, p, Kpad, 0, st)
+        L.odam_op_conv2d_nhwc(_lib.ptr(x), _lib.ptr(w), None, None, None, _lib.ptr(y), B, H, W, Cin, Cout, k, k, s, p, Kpad, 0, 0, st)
     torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(n):
-        L.odam_op_conv2d_nhwc(_lib.ptr(x), _lib.ptr(w), None, None, None, _lib.ptr(y), B, H, W, Cin, Cout, k, k, s, p, Kpad, 0, st)
+        L.odam_op_conv2d_nhwc(_lib.ptr(x), _lib.ptr(w), None, None, None, _lib.ptr(y), B, H, W, Cin, Cout, k, k, s, p, Kpad, 0, 0, st)
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
 for (name, B, H, W, Cin, Cout, k, s, p) in [("l3.c2 3x3 256->256", 32, 50, 67, 256, 256, 3, 1, 1), ("l4.c2 3x3 512->512", 32, 25, 34, 512, 512, 3, 1, 1),

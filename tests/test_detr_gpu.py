@@ -23,11 +23,17 @@ def _st():
     return ctypes.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
 
 
-def _pack(w):
+def _pack(w, epc=4, k_order=0):
+    """[Cout,Cin,KH,KW] -> [Cout][Kpad] in the kernel's K order (include/odam_detr.h): 0 = (tap, ci),
+    1 = (ci // kt, tap, ci % kt) with kt = 8 chunks of `epc` elements"""
     Cout, Cin, KH, KW = w.shape
-    CinP = (Cin + 3) // 4 * 4
+    kt = 8 * epc
+    CinP = (Cin + epc - 1) // epc * epc
     wp = torch.zeros(Cout, KH, KW, CinP); wp[..., :Cin] = w.permute(0, 2, 3, 1)
-    Kk = KH * KW * CinP; Kpad = (Kk + 31) // 32 * 32
+    Kk = KH * KW * CinP; Kpad = (Kk + kt - 1) // kt * kt
+    if k_order:
+        assert CinP % kt == 0
+        wp = wp.reshape(Cout, KH * KW, CinP // kt, kt).permute(0, 2, 1, 3)
     out = torch.zeros(Cout, Kpad); out[:, :Kk] = wp.reshape(Cout, Kk)
     return out, CinP, Kpad
 
@@ -60,15 +66,16 @@ def test_conv_gemm_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
         y = y + r
     if relu:
         y = F.relu(y)
-    wp, CinP, Kpad = _pack(w)
-    xh = torch.zeros(B, H, W, CinP); xh[..., :Cin] = x.permute(0, 2, 3, 1)
-    dx, dw, dsc, dbi = xh.to(DEV), wp.to(DEV), sc.to(DEV), bi.to(DEV)
-    dr = r.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None
-    dy = torch.empty(B, y.shape[2], y.shape[3], Cout, device=DEV)
-    _lib.check(L.odam_op_conv2d_nhwc(_lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dbi), _lib.ptr(dr), _lib.ptr(dy),
-                                     B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), _st()), "conv")
-    got = dy.cpu().permute(0, 3, 1, 2)
-    assert (got - y).abs().max().item() <= 3e-6 * max(y.abs().max().item(), 1.0)   # fp32, different sum order
+    for k_order in ((0, 1) if Cin % 32 == 0 and k * k <= 32 else (0,)):
+        wp, CinP, Kpad = _pack(w, 4, k_order)
+        xh = torch.zeros(B, H, W, CinP); xh[..., :Cin] = x.permute(0, 2, 3, 1)
+        dx, dw, dsc, dbi = xh.to(DEV), wp.to(DEV), sc.to(DEV), bi.to(DEV)
+        dr = r.permute(0, 2, 3, 1).contiguous().to(DEV) if res else None
+        dy = torch.empty(B, y.shape[2], y.shape[3], Cout, device=DEV)
+        _lib.check(L.odam_op_conv2d_nhwc(_lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dbi), _lib.ptr(dr), _lib.ptr(dy),
+                                         B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), k_order, _st()), "conv")
+        got = dy.cpu().permute(0, 3, 1, 2)
+        assert (got - y).abs().max().item() <= 3e-6 * max(y.abs().max().item(), 1.0), k_order   # fp32, different sum order
 
 
 @pytest.mark.parametrize("B,Lq,Lk", [(2, 850, 850), (3, 100, 100), (2, 100, 850), (1, 33, 70), (1, 1, 1)])
@@ -260,10 +267,8 @@ def test_conv_gemm_bf16_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
         y = y + r
     if relu:
         y = F.relu(y)
-    CinP = (Cin + 7) // 8 * 8
-    wp = torch.zeros(Cout, k, k, CinP); wp[..., :Cin] = w.permute(0, 2, 3, 1)
-    Kk = k * k * CinP; Kpad = (Kk + 63) // 64 * 64
-    wpk = torch.zeros(Cout, Kpad); wpk[:, :Kk] = wp.reshape(Cout, Kk)
+    k_order = 1 if Cin % 64 == 0 and k > 1 else 0
+    wpk, CinP, Kpad = _pack(w, 8, k_order)
     xh = torch.zeros(B, H, W, CinP); xh[..., :Cin] = x.permute(0, 2, 3, 1)
     dx, dw = _to_bf16_bits(xh).to(DEV), _to_bf16_bits(wpk).to(DEV)
     dsc, dbi = sc.to(DEV), bi.to(DEV)
@@ -271,7 +276,7 @@ def test_conv_gemm_bf16_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
     for out_f32 in (1, 0):
         dy = torch.empty(B, y.shape[2], y.shape[3], Cout, device=DEV, dtype=torch.float32 if out_f32 else torch.bfloat16)
         _lib.check(L.odam_op_conv2d_nhwc_bf16(_lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dbi), _lib.ptr(dr), _lib.ptr(dy),
-                                              B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), out_f32, _st()), "conv bf16")
+                                              B, H, W, CinP, Cout, k, k, s, p, Kpad, int(relu), out_f32, k_order, _st()), "conv bf16")
         got = dy.float().cpu().permute(0, 3, 1, 2)
         tol = 3e-6 if out_f32 else 8e-3     # bf16 has 8 significant bits
         assert (got - y).abs().max().item() <= tol * max(y.abs().max().item(), 1.0), out_f32
