@@ -27,8 +27,24 @@ constexpr unsigned OOB_VOFF = 0x80000000u;   // >= num_records of every buffer d
 // its input offset and the channel offset are wave-uniform (SGPRs).  The gather then costs three VALU
 // instructions per 16-byte load: per-row tap-validity bit -> select the row's byte offset or an out-of-range one ->
 // buffer_load_dwordx4 (hardware returns zeros for the padding halo and the ragged last tile; no branches).
-template <int BM, int BN, int WM, int WN, bool BF16, bool UT>
+// One LDS-DMA instruction written by hand: the compiler does not know it, so it neither counts it in its own
+// s_waitcnt bookkeeping nor drains vmcnt before every ds_read that might alias the DMA's destination (which it does
+// for the builtin) -- the deep pipeline below retires these loads itself with counted waits.  M0 (the LDS
+// destination base) is compiler-reserved: saved, set and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, unsigned voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_byte), "s"(soff)
+                 : "memory");
+}
+
+// NST: LDS stages.  2 = one tile in flight under the tile being multiplied (two workgroups per CU hide the rest).
+// 4 (UT only; small, latency-bound problems that leave most CUs with one workgroup): three tiles in flight, retired
+// with a counted s_waitcnt so the DMA queue stays full across the per-tile barrier.
+template <int BM, int BN, int WM, int WN, bool BF16, bool UT, int NST = 2>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a) {
+    static_assert(NST == 2 || (UT && (NST & (NST - 1)) == 0), "deep pipelines are LDS-DMA only");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;   // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;        // elements per k-tile (32 fp32 / 64 bf16)
@@ -45,10 +61,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     // 16-byte chunk c of row r sits at position c ^ ((r >> 1) & 7) -- the DMA's *source* address carries the
     // permutation, ds_read_b128 applies it again; every 16-lane read group then covers 16 distinct slots.
     constexpr int LDS_LD = UT ? 32 : LDS_STRIDE;
-    __shared__ __align__(16) float smem[2 * (BM + BN) * LDS_LD];   // static: 32 / 48 / 64 KiB (UT)
-    float* As = smem;                      // [2][BM][LDS_LD]
-    float* Bs = smem + 2 * BM * LDS_LD;    // [2][BN][LDS_LD]
+    __shared__ __align__(16) float smem[NST * (BM + BN) * LDS_LD];   // static: 32 / 48 / 64 KiB (UT)
+    float* As = smem;                        // [NST][BM][LDS_LD]
+    float* Bs = smem + NST * BM * LDS_LD;    // [NST][BN][LDS_LD]
 
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const T* __restrict__ Ag = reinterpret_cast<const T*>(a.A);
     const T* __restrict__ Wg = reinterpret_cast<const T*>(a.Wt);
 
@@ -104,6 +121,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     // UT bookkeeping: descriptors over the input (rebased to the first image this tile touches, minus the padding
     // margin so every row offset is non-negative) and the filters; per row a byte offset and a bit per filter tap.
     __amdgpu_buffer_rsrc_t a_rs, w_rs;
+    u32x4 a_rs4, w_rs4;   // the same descriptors as four SGPR words, for the hand-written DMA
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
     unsigned a_voff[A_LD], a_mask[A_LD], w_voff[B_LD];
     if constexpr (UT) {
         const int b0 = m0 / hw;
@@ -111,6 +130,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         const int margin = (a.pad * a.W + a.pad) * lda;
         a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(Ag + (size_t)b0 * a.H * a.W * lda - margin), 0, (int)OOB_VOFF, 0x00020000);
         w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)Wg, 0, (int)OOB_VOFF, 0x00020000);
+        const unsigned long long pa = (unsigned long long)(Ag + (size_t)b0 * a.H * a.W * lda - margin), pw = (unsigned long long)Wg;
+        a_rs4 = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+        w_rs4 = u32x4{(unsigned)pw, (unsigned)(pw >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
 #pragma unroll
         for (int i = 0; i < A_LD; i++) {
             a_voff[i] = (unsigned)(a_base[i] - b0 * a.H * a.W * lda + margin + csrc * EPC) * (unsigned)sizeof(T);
@@ -126,7 +148,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             w_voff[i] = b_ok[i] ? (unsigned)((n0 + r0 + RPP * i) * a.Kpad + csrc * EPC) * (unsigned)sizeof(T) : OOB_VOFF;
     }
 
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     float4 ra[A_LD], rb[B_LD];
     auto load_tile = [&](int kt, int buf) {
@@ -147,13 +168,21 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 #pragma unroll
             for (int i = 0; i < A_LD; i++) {
                 const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB_VOFF;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(As + (buf * BM + wave_u * 8 + RPP * i) * LDS_LD),
-                                                         16, (int)vo, soff, 0, 0);
+                if constexpr (NST > 2)
+                    lds_dma16(a_rs4, lds_base + (unsigned)((buf * BM + wave_u * 8 + RPP * i) * LDS_LD * 4), vo, soff);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (lds_ptr_t)(As + (buf * BM + wave_u * 8 + RPP * i) * LDS_LD),
+                                                             16, (int)vo, soff, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < B_LD; i++)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(Bs + (buf * BN + wave_u * 8 + RPP * i) * LDS_LD),
-                                                         16, (int)w_voff[i], kb * (int)sizeof(T), 0, 0);
+            for (int i = 0; i < B_LD; i++) {
+                if constexpr (NST > 2)
+                    lds_dma16(w_rs4, lds_base + (unsigned)((NST * BM + buf * BN + wave_u * 8 + RPP * i) * LDS_LD * 4), w_voff[i],
+                              kb * (int)sizeof(T));
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(w_rs, (lds_ptr_t)(Bs + (buf * BN + wave_u * 8 + RPP * i) * LDS_LD),
+                                                             16, (int)w_voff[i], kb * (int)sizeof(T), 0, 0);
+            }
             return;
         }
         const int k0 = kt * BKE + c4 * EPC;
@@ -197,10 +226,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
     const int nk = a.Kpad / BKE;
-    load_tile(0, 0);
-    store_tile(0);
-    if constexpr (UT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     // Operand fragments: lane (row = lane & 31, half = lane >> 5) reads the 16-byte chunk 2 g + half of its row for
     // k-group g = 0..3.  fp32: 4 values = the k slots of four v_mfma_f32_32x32x2_f32 steps (A and B use the same
@@ -211,18 +236,18 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     int frag_q[4];   // float offset of k-group q's chunk inside the row
 #pragma unroll
     for (int q = 0; q < 4; q++) frag_q[q] = UT ? ((2 * q + (lane >> 5)) ^ ((frag_row >> 1) & 7)) * 4 : q * 8;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+
+    // one k-tile of MFMAs out of LDS stage `cur`; `issue_next` (the next tile's global loads) runs right after the
+    // first fragment reads, under their LDS latency; every k-group's fragments are fetched one group ahead
+    auto mma_tile = [&](int cur, auto&& issue_next) {
         const float* Ab = &As[(cur * BM + wm * (BM / WM) + frag_row) * LDS_LD + frag_k];
         const float* Bb = &Bs[(cur * BN + wn * (BN / WN) + frag_row) * LDS_LD + frag_k];
-        // fragments of k-group 0 first, then the next tile's global loads are issued under that LDS latency;
-        // every k-group's fragments are fetched one group ahead of the MFMAs that consume them
         float4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + frag_q[0]);
 #pragma unroll
         for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + frag_q[0]);
-        if (!(CG_ABLATE & 1) && kt + 1 < nk) load_tile(kt + 1, cur ^ 1);
+        issue_next();
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int pb = q & 1;
@@ -250,9 +275,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
                     }
                 }
         }
-        if (!(CG_ABLATE & 2) && kt + 1 < nk) store_tile(cur ^ 1);
-        if constexpr (UT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile kt + 1 has landed
-        if (!(CG_ABLATE & 4)) __syncthreads();
+    };
+
+    if constexpr (NST == 2) {
+        load_tile(0, 0);
+        store_tile(0);
+        if constexpr (UT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            mma_tile(cur, [&] { if (!(CG_ABLATE & 1) && kt + 1 < nk) load_tile(kt + 1, cur ^ 1); });
+            if (!(CG_ABLATE & 2) && kt + 1 < nk) store_tile(cur ^ 1);
+            if constexpr (UT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA of tile kt + 1 has landed
+            if (!(CG_ABLATE & 4)) __syncthreads();
+        }
+    } else {
+        // Tiles kt .. kt + NST - 2 are in flight when tile kt is awaited: each thread's DMAs retire in order, so
+        // "at most (NST - 2) tiles' worth of my loads outstanding" means my part of tile kt has landed; the barrier
+        // extends that to every wave and also says stage (kt - 1) % NST has been read by all, so it can be refilled.
+        constexpr int LPT = A_LD + B_LD;   // DMA instructions per thread per tile
+#pragma unroll
+        for (int s0 = 0; s0 < NST - 1; s0++)
+            if (s0 < nk) load_tile(s0, s0);
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + NST - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            mma_tile(kt & (NST - 1), [&] { if (kt + NST - 1 < nk) load_tile(kt + NST - 1, (kt + NST - 1) & (NST - 1)); });
+        }
+        __syncthreads();   // the last stage is fully read before the epilogue reuses the tile buffers
     }
 
     // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
@@ -277,7 +329,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         // the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) land on 16 distinct 16-byte slots for both
         // 128-byte and 256-byte rows.
         constexpr int EP_LD = WCOLS;
-        static_assert(WM * WN * 32 * EP_LD <= 2 * (BM + BN) * LDS_LD, "epilogue staging fits the tile buffers");
+        static_assert(WM * WN * 32 * EP_LD <= NST * (BM + BN) * LDS_LD, "epilogue staging fits the tile buffers");
         float* Ep = smem + wave * (32 * EP_LD);     // one 32-row slab per wave, reused for each of its TM row tiles
         constexpr int LPR = WCOLS / 4;              // lanes per row
         constexpr int RPI = 64 / LPR;               // rows per wave-instruction
@@ -366,7 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     }
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int NST_UT = 2>
 static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.Cout + BN - 1) / BN);
     const bool bf = a.dtype == ODAM_CG_BF16;
@@ -379,10 +431,10 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
                     (long)a.Cout * a.Kpad * esz < 0x7fffffffL;
     const dim3 g(tiles), b(64 * WM * WN);
     if (bf) {
-        if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, true>), g, b, 0, stream, a);
+        if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, true, NST_UT>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, false>), g, b, 0, stream, a);
     } else {
-        if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, true>), g, b, 0, stream, a);
+        if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, true, NST_UT>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, false>), g, b, 0, stream, a);
     }
     ODAM_HIP(hipGetLastError());
@@ -396,10 +448,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (a.k_order && (a.Cin % (8 * epc) != 0 || a.KH * a.KW > 32 || a.Kpad / (8 * epc) >= 2048))
         return odam_fail(1, "conv_gemm: k_order 1 needs Cin % k-tile == 0, at most 32 taps, fewer than 2048 k-tiles");
     if (a.M <= 0 || a.Cout <= 0) return 0;
-    static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 3;  // 8-wave tiles (+2-3 %)
+    static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 7;  // 8-wave tiles (+2-3 %)
     if (a.Cout <= 64) return (variant & 2) ? launch_cfg<128, 64, 4, 2>(a, stream) : launch_cfg<128, 64, 4, 1>(a, stream);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
-    if (tiles128 < 128) return launch_cfg<64, 64, 2, 2>(a, stream);
+    if (tiles128 < 128) return (variant & 4) ? launch_cfg<64, 64, 2, 2, 4>(a, stream) : launch_cfg<64, 64, 2, 2>(a, stream);
     if (variant & 1) return launch_cfg<128, 128, 4, 2>(a, stream);
     return launch_cfg<128, 128, 2, 2>(a, stream);
 }

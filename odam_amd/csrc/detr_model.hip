@@ -208,12 +208,6 @@ int run_conv(const Conv& c, const void* x, int B, int H, int W, const void* res,
     return odam_cg::launch_conv_gemm(a, st);
 }
 
-// y[M, Cout] = x[M, K] W^T + b (+ res) (relu)
-int run_linear(const Conv& c, const void* x, int M, const void* res, bool relu, void* y, int ldc, hipStream_t st,
-               int dtype = 0, int out_f32 = 0) {
-    return run_conv(c, x, 1, 1, M, res, relu, y, ldc, st, dtype, out_f32);
-}
-
 // timed variants used by the forward: identical launches, bracketed by events when profiling is on
 int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, const void* res, bool relu, void* y,
            hipStream_t st, int out_f32 = 0) {

@@ -44,10 +44,8 @@ using namespace odam_sq;
 #define ODAM_SQ_NT 1024
 #endif
 constexpr int NT = ODAM_SQ_NT;  // threads per workgroup
-constexpr int NW = NT / 64;     // wavefronts per workgroup
 constexpr int BUFP = 208;       // padded theta-buffer length
 constexpr int QCAP = 200;       // pending arcs per curve per level (sum of n over a level <= 199)
-constexpr int PTS_PER_LANE = 16;  // ceil(1000 / 64)
 constexpr int NONE = 0x7fffffff;
 constexpr int TABN = 513;        // dyadic theta table: depth 9 of the parameter bisection
 

@@ -16,6 +16,8 @@ def run(L, x, w, y, B, H, W, Cin, Cout, k, s, p, Kpad, ko, n=20):
     return e0.elapsed_time(e1) / n
 layers = [("l1.c2 3x3 64->64", 32, 200, 267, 64, 64, 3, 1, 1), ("l2.c2 3x3 128->128", 32, 100, 134, 128, 128, 3, 1, 1),
           ("l3.c2 3x3 256->256", 32, 50, 67, 256, 256, 3, 1, 1), ("l4.c2 3x3 512->512", 32, 25, 34, 512, 512, 3, 1, 1), ("gemm 16384x2048x2048", 1, 1, 16384, 2048, 2048, 1, 1, 0),
+          ("small 64x512x512", 1, 1, 64, 512, 512, 1, 1, 0), ("small 40x256x256", 1, 1, 40, 256, 256, 1, 1, 0),
+          ("dec 3200x256x256", 1, 1, 3200, 256, 256, 1, 1, 0), ("dec 3200x2048x256", 1, 1, 3200, 2048, 256, 1, 1, 0),
           ("l1.c1 1x1 64->64", 32, 200, 267, 64, 64, 1, 1, 0), ("l1.c3 1x1 64->256", 32, 200, 267, 64, 256, 1, 1, 0)]
 for path in sys.argv[1:]:
     L = ctypes.CDLL(os.path.abspath(path))
