@@ -30,7 +30,8 @@ from odam_amd.processor import detection_rows  # noqa: E402
 
 FLOPS_PER_FRAME_R50 = 163.1e9   # SURVEY.md section 2.2 / BASELINE.md (2 x MAC, 800x1066 input)
 PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
-TRAFFIC_BYTES_PER_FRAME_PMC = (2 * 10860962.0 + 6627384.5) * 1024 / 8   # profiles/r1_detr_forward_B8_pmc_*.csv
+PEAK_HBM = 8.0e12                # MI355X_MICROARCH.md, HBM3E
+TRAFFIC_BYTES_PER_FRAME_PMC = (2 * 44250691.0 + 53019075.0) * 1024 / 64   # profiles/r1_detr_forward_B32_pmc_*.csv (2 forwards of 32)
 
 
 def build_frames(n_local, device, seed):
@@ -157,7 +158,7 @@ def main():
 
     # stage split (informational): one more untimed scene with explicit timers
     torch.cuda.synchronize(); s0 = time.perf_counter()
-    for _ in detector.detect_resident_chunks(frames, img_size, K, chunk=16 * args.batch):
+    for _ in detector.detect_resident_chunks(frames, img_size, K, chunk=args.chunk):
         pass
     torch.cuda.synchronize(); t_det = time.perf_counter() - s0
 
@@ -192,8 +193,8 @@ def main():
         iso = conv_flops / (conv_ms * 1e-3)
         result["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
                               "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA,
-                              # HBM-side bytes of this kernel per frame from rocprofv3 PMC passes of a B=8 forward
-                              # (profiles/r1_detr_forward_B8_pmc_*.csv): (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / 8;
+                              # HBM-side bytes of this kernel per frame from rocprofv3 PMC passes of B=32 forwards
+                              # (profiles/r1_detr_forward_B32_pmc_*.csv): (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / 64;
                               # counters cannot be read from inside this process, so the figure is the recorded one
                               "traffic": TRAFFIC_BYTES_PER_FRAME_PMC, "traffic_unit": "bytes per frame (all launches)",
                               "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv / linear, v_mfma_f32_32x32x2_f32)",
@@ -212,6 +213,36 @@ def main():
                                       "launches_per_forward": att_n, "ms_per_forward": att_ms, "batch": args.batch,
                                       "measured": "QK^T + PV flops of the fused attention kernel / its launch durations "
                                                   "(HIP events, one forward alone on one stream)"}
+    if mine:
+        # the fit kernel alone: one more pass over this rank's objects with an event pair around the launch
+        rec = {}
+        orig_fit = fitter.fit
+
+        def timed_fit(*a, **k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_fit(*a, **k)
+            e1.record()
+            rec["ev"], rec["views"] = (e0, e1), [int(v) for v in a[2]]
+            return out
+
+        fitter.fit = timed_fit
+        multi_view.optim_process([tracks[i] for i in mine], frame_ids, scene["T_wcs"], scene["P_cws"], synth.IMG_H,
+                                 synth.IMG_W, K, "super_quadric", True, 200, 10, fitter=fitter)
+        fitter.fit = orig_fit
+        torch.cuda.synchronize()
+        if "ev" in rec:
+            sq_ms = rec["ev"][0].elapsed_time(rec["ev"][1])
+            views = rec["views"]
+            alg = sum(12000 + 80 * v + 40 for v in views) * 200.0   # streaming-formulation bytes per object-step
+            result["sq_fit_kernel"] = {
+                "bound": "hbm", "achieved": alg / (sq_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                "frac": alg / (sq_ms * 1e-3) / PEAK_HBM, "objects": len(views), "max_views": max(views),
+                "ms_per_launch": sq_ms, "us_per_adam_step": 1e3 * sq_ms / 200,
+                "measured": "streaming-formulation bytes (12000 + 80 F + 40 per object-step) x 200 steps / launch duration "
+                            "(HIP events); one workgroup per object keeps points, sampler state and gradients in LDS for "
+                            "all 200 steps, so HBM sees each view's 80 bytes through L2 only -- the kernel is bound by "
+                            "per-step latency (VALU + LDS + barriers), not by this figure (DESIGN.md section 4)"}
     if rank == 0 and ws == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(scene, tracks, N)
     if rank == 0:
