@@ -142,8 +142,10 @@ class OdamProcess:
         return [t for t in tracks]
 
     def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100):
+        """processor.py:139-170.  Built in numpy and wrapped once: on a many-core host every torch CPU op above the
+        intra-op grain size forks the whole OpenMP pool, which costs milliseconds per frame in this loop."""
         T_cw = np.linalg.inv(T_wc)
-        in_ = torch.ones((len(tracks), n_times, 79)) * -1
+        in_ = np.full((len(tracks), n_times, 79), -1.0, np.float32)
         for idx, track in enumerate(tracks):
             n_steps = len(track)
             tmp = np.zeros((n_steps, 79)) - 1
@@ -162,7 +164,7 @@ class OdamProcess:
             tmp[:, 13] = np.cos(angle)
             tmp[:, 14] = track[:, 13]
             tmp[:, 15:79] = track[:, 14:78]
-            tmp = torch.tensor(tmp, dtype=torch.float32)
+            tmp = tmp.astype(np.float32)           # torch.tensor(tmp, dtype=float32): round to nearest
             if n_steps > n_times:
                 in_[idx, :, :] = tmp[-100:, :]
             else:
@@ -188,26 +190,27 @@ class OdamProcess:
             x_max, y_max, _ = np.max(pixels, axis=0)
             track[:, -4:] = np.array([[x_min, y_min, x_max, y_max]])
             tracks[idx] = track
-        tracks = self._preprocess_tracks(tracks, T_wc, cam_azi, n_times)
-        return tracks.permute(0, 2, 1)
+        in_ = self._preprocess_tracks(tracks, T_wc, cam_azi, n_times)
+        return torch.from_numpy(np.ascontiguousarray(in_.transpose(0, 2, 1)))   # [T, 79, n_times], as .permute(0, 2, 1)
 
     def _collater(self, data_list):
         max_dets = 30
         n_features = data_list[0]['detections'].shape[0]
-        detections = torch.ones((len(data_list), n_features, max_dets), dtype=torch.float) * -1
+        detections = np.full((len(data_list), n_features, max_dets), -1.0, np.float32)
         tracks, poses, tsplit, dsplit, valid = [], [], [], [], []
         for b_id, data in enumerate(data_list):
             tracks.append(data['tracks'])
             poses.append(data['pose'])
             nt, nd = data['tracks'].shape[0], data['detections'].shape[1]
             tsplit.append(nt); dsplit.append(nd); valid.append((nt, nd))
-            detections[b_id, :, :nd] = data['detections']
-        gt_masks = torch.zeros((sum(tsplit), sum(dsplit)), dtype=torch.float)
+            detections[b_id, :, :nd] = np.asarray(data['detections'], np.float32)
+        gt_masks = np.zeros((sum(tsplit), sum(dsplit)), np.float32)
         t0 = d0 = 0
         for nt, nd in zip(tsplit, dsplit):
             gt_masks[t0:t0 + nt, d0:d0 + nd] = 1
             t0 += nt; d0 += nd
-        return {"tracks": torch.cat(tracks, dim=0), "detections": detections, "gt_masks": gt_masks,
+        return {"tracks": tracks[0] if len(tracks) == 1 else torch.cat(tracks, dim=0),
+                "detections": torch.from_numpy(detections), "gt_masks": torch.from_numpy(gt_masks),
                 "track_batch_split": tsplit, "detection_batch_split": dsplit, "poses": poses, "valid_list": valid}
 
     def _attach_to_tracks(self, pred_match, detections, T_wc, score_mat):
@@ -252,8 +255,7 @@ class OdamProcess:
             return None
         dev = getattr(self.detector, "device", "cuda")
         track_tensors = self._prepare_tracks(T_wc)
-        data = self._collater([{"detections": torch.from_numpy(detections).float().to(dev).T,
-                                "tracks": track_tensors, "pose": T_wc}])
+        data = self._collater([{"detections": detections.astype(np.float32).T, "tracks": track_tensors, "pose": T_wc}])
         n_tracks, n_detections = data['valid_list'][0]
         with torch.no_grad():
             predictions = self.associator(data, self.match_threshold, eval_only=True)
