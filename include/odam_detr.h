@@ -83,6 +83,14 @@ int odam_detr_postprocess(odam_detr* m, const float* logits, const float* boxes,
  * odam_detr_postprocess; keep_idx [host][Q] receives the kept query indices in descending-score order. */
 int odam_detr_select(const float* rows, int Q, float threshold, int nms_2d, int* keep_idx, int* n_keep);
 
+/* The detector's input transform on the device (reference: src/datasets/transforms.py:281-290 = resize :75-105 via
+ * torchvision F.resize -> PIL Image.resize(BILINEAR), ToTensor :222-224, Normalize :236-243; called per frame from
+ * src/processor.py:263): rgb [dev][B,h,w,3] uint8 -> out [dev][B,3,img_h,img_w] float32 at the handle's size,
+ * bit-identical to the host transform (Pillow's two-pass 22-bit fixed-point resampling, then float32 /255, -mean, /std).
+ * mean, std: host float[3].  The resampling tables of each (h, w) are built and uploaded at first use (synchronous). */
+int odam_detr_preprocess_u8(odam_detr* m, const unsigned char* rgb, int B, int h, int w, const float* mean,
+                            const float* std_dev, float* out, void* stream);
+
 /* Per-launch timing of the contraction kernel (all conv / linear launches of a forward are bracketed by
  * event pairs while enabled); read returns the totals of the most recent forward. */
 int odam_detr_profile_enable(odam_detr* m, int on);

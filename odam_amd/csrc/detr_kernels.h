@@ -45,4 +45,11 @@ int launch_postprocess(const float* logits, const float* boxes, const float* ang
                        const float* size, const float* depth, int B, int Q, int n_cls1, int n_bins, float img_w,
                        float img_h, float fx, float fy, float cx, float cy, float* rows, hipStream_t stream);
 
+// Input transform on the device: uint8 [B,h,w,3] -> float32 [B,3,H,W] = Normalize(ToTensor(PIL-bilinear resize)),
+// bit-identical to the host transform (resampling tables: detr_model.hip resample_table, 22-bit fixed point)
+int launch_preprocess_u8(const unsigned char* rgb, int B, int h, int w, const int* tx_xmin, const int* tx_cnt,
+                         const int* tx_K, int tx_ksize, const int* ty_xmin, const int* ty_cnt, const int* ty_K,
+                         int ty_ksize, float* out, int H, int W, const float mean[3], const float stdv[3],
+                         hipStream_t stream);
+
 }  // namespace odam_dk

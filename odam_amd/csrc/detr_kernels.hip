@@ -450,4 +450,77 @@ int launch_postprocess(const float* logits, const float* boxes, const float* ang
     return 0;
 }
 
+// ---- input transform: PIL bilinear resize of the uint8 frame + ToTensor + Normalize ------------
+// Pillow's 8-bit resampling is two passes of integer arithmetic (src/libImaging/Resample.c): each pass rounds to a
+// byte, clip8((2^21 + sum_k px[k] * K[k]) >> 22).  One thread owns one output pixel: it recomputes the (<= ksize)
+// horizontally resampled bytes of the rows its vertical taps need, so no intermediate image exists.
+struct ResampleTable {   // device pointers
+    const int* xmin;     // [out] first source index
+    const int* cnt;      // [out] taps
+    const int* K;        // [out][ksize] fixed-point weights (22 fractional bits)
+    int ksize;
+};
+
+__device__ __forceinline__ int clip8_22(int v) {
+    v >>= 22;
+    return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ __launch_bounds__(256) void preprocess_u8_kernel(const unsigned char* __restrict__ rgb, int h, int w,
+                                                            ResampleTable tx, ResampleTable ty, int need_x, int need_y,
+                                                            float* __restrict__ out, int H, int W, float3 mean,
+                                                            float3 stdv) {
+    const int X = blockIdx.x * 256 + threadIdx.x;
+    const int Y = blockIdx.y;
+    const size_t b = blockIdx.z;
+    if (X >= W) return;
+    const unsigned char* img = rgb + b * (size_t)h * w * 3;
+    const int x0 = need_x ? tx.xmin[X] : X, nx = need_x ? tx.cnt[X] : 1;
+    const int y0 = need_y ? ty.xmin[Y] : Y, ny = need_y ? ty.cnt[Y] : 1;
+    const int* kx = tx.K + (size_t)X * tx.ksize;
+    const int* ky = ty.K + (size_t)Y * ty.ksize;
+    int acc[3] = {1 << 21, 1 << 21, 1 << 21};
+    int last[3] = {0, 0, 0};
+    for (int j = 0; j < ny; j++) {
+        const unsigned char* row = img + ((size_t)(y0 + j) * w + x0) * 3;
+        int hv[3];
+        if (need_x) {
+            int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+            for (int k = 0; k < nx; k++) {
+                const int kk = kx[k];
+                a0 += row[k * 3 + 0] * kk; a1 += row[k * 3 + 1] * kk; a2 += row[k * 3 + 2] * kk;
+            }
+            hv[0] = clip8_22(a0); hv[1] = clip8_22(a1); hv[2] = clip8_22(a2);
+        } else {
+            hv[0] = row[0]; hv[1] = row[1]; hv[2] = row[2];
+        }
+        if (need_y) {
+            const int kk = ky[j];
+            acc[0] += hv[0] * kk; acc[1] += hv[1] * kk; acc[2] += hv[2] * kk;
+        }
+        last[0] = hv[0]; last[1] = hv[1]; last[2] = hv[2];
+    }
+    const int u0 = need_y ? clip8_22(acc[0]) : last[0];
+    const int u1 = need_y ? clip8_22(acc[1]) : last[1];
+    const int u2 = need_y ? clip8_22(acc[2]) : last[2];
+    // ToTensor: float32(u8) / 255; Normalize: (x - mean) / std, float32 (transforms.py:222-243)
+    const size_t plane = (size_t)H * W, o = (b * 3 * H + Y) * (size_t)W + X;
+    out[o] = ((float)u0 / 255.0f - mean.x) / stdv.x;
+    out[o + plane] = ((float)u1 / 255.0f - mean.y) / stdv.y;
+    out[o + 2 * plane] = ((float)u2 / 255.0f - mean.z) / stdv.z;
+}
+
+int launch_preprocess_u8(const unsigned char* rgb, int B, int h, int w, const int* tx_xmin, const int* tx_cnt,
+                         const int* tx_K, int tx_ksize, const int* ty_xmin, const int* ty_cnt, const int* ty_K,
+                         int ty_ksize, float* out, int H, int W, const float mean[3], const float stdv[3],
+                         hipStream_t stream) {
+    if (B <= 0) return 0;
+    ResampleTable tx{tx_xmin, tx_cnt, tx_K, tx_ksize}, ty{ty_xmin, ty_cnt, ty_K, ty_ksize};
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3((W + 255) / 256, H, B), dim3(256), 0, stream, rgb, h, w, tx, ty,
+                       (int)(W != w), (int)(H != h), out, H, W, float3{mean[0], mean[1], mean[2]},
+                       float3{stdv[0], stdv[1], stdv[2]});
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
 }  // namespace odam_dk

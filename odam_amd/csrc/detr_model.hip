@@ -90,6 +90,10 @@ struct odam_detr {
     std::vector<hipEvent_t> ev;
     std::vector<double> ev_flops;
     size_t ev_used = 0;
+    // input-transform resampling tables per (source length, output length): device [xmin | cnt | K]
+    struct Resample { int* xmin; int* cnt; int* K; int ksize; };
+    std::map<std::pair<int, int>, Resample> resample;
+
     std::vector<hipEvent_t> aev;      // same for the fused attention kernel
     std::vector<double> aev_flops;
     size_t aev_used = 0;
@@ -617,6 +621,65 @@ extern "C" int odam_detr_profile_read_attention(odam_detr* m, int* n_launches, d
 }
 
 // ---- threshold + greedy 3D/2D NMS on one frame's post-processed rows (host, float32 as the reference's numpy) --
+// Pillow src/libImaging/Resample.c precompute_coeffs + normalize_coeffs_8bpc for the bilinear (triangle, support 1)
+// filter over the whole image: what PIL's Image.resize(BILINEAR) -- torchvision F.resize on a PIL image, the
+// reference's transforms.py:105 -- builds before its two integer passes.  Double arithmetic, C truncating casts.
+static int resample_table(odam_detr* m, int in_size, int out_size, odam_detr::Resample* r) {
+    auto it = m->resample.find({in_size, out_size});
+    if (it != m->resample.end()) { *r = it->second; return 0; }
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    const int ksize = (int)std::ceil(support) * 2 + 1;
+    std::vector<int> xmin(out_size), cnt(out_size), K((size_t)out_size * ksize, 0);
+    std::vector<double> w(ksize);
+    const double ss = 1.0 / filterscale;
+    for (int xx = 0; xx < out_size; xx++) {
+        const double center = (xx + 0.5) * scale;
+        int lo = (int)(center - support + 0.5);
+        if (lo < 0) lo = 0;
+        int hi = (int)(center + support + 0.5);
+        if (hi > in_size) hi = in_size;
+        const int n = hi - lo;
+        double ww = 0.0;
+        for (int x = 0; x < ksize; x++) w[x] = 0.0;
+        for (int x = 0; x < n; x++) {
+            double t = (x + lo - center + 0.5) * ss;
+            if (t < 0.0) t = -t;
+            w[x] = t < 1.0 ? 1.0 - t : 0.0;
+            ww += w[x];
+        }
+        for (int x = 0; x < n; x++)
+            if (ww != 0.0) w[x] /= ww;
+        for (int x = 0; x < ksize; x++)
+            K[(size_t)xx * ksize + x] = w[x] < 0 ? (int)(-0.5 + w[x] * (1 << 22)) : (int)(0.5 + w[x] * (1 << 22));
+        xmin[xx] = lo; cnt[xx] = n;
+    }
+    odam_detr::Resample t{};
+    t.ksize = ksize;
+    if (int rc = m->dev_alloc(&t.xmin, xmin.size())) return rc;
+    if (int rc = m->dev_alloc(&t.cnt, cnt.size())) return rc;
+    if (int rc = m->dev_alloc(&t.K, K.size())) return rc;
+    ODAM_HIP(hipMemcpy(t.xmin, xmin.data(), xmin.size() * sizeof(int), hipMemcpyHostToDevice));
+    ODAM_HIP(hipMemcpy(t.cnt, cnt.data(), cnt.size() * sizeof(int), hipMemcpyHostToDevice));
+    ODAM_HIP(hipMemcpy(t.K, K.data(), K.size() * sizeof(int), hipMemcpyHostToDevice));
+    m->resample[{in_size, out_size}] = t;
+    *r = t;
+    return 0;
+}
+
+// transforms.py:281-290 on the device: resize to the model's (img_h, img_w) + ToTensor + Normalize
+extern "C" int odam_detr_preprocess_u8(odam_detr* m, const unsigned char* rgb, int B, int h, int w, const float* mean,
+                                       const float* stdv, float* out, void* stream) {
+    if (!m || !rgb || !mean || !stdv || !out) return odam_fail(1, "odam_detr_preprocess_u8: null pointer");
+    if (B < 0 || h < 1 || w < 1) return odam_fail(1, "odam_detr_preprocess_u8: bad size");
+    odam_detr::Resample tx{}, ty{};
+    RC(resample_table(m, w, m->cfg.img_w, &tx));
+    RC(resample_table(m, h, m->cfg.img_h, &ty));
+    return odam_dk::launch_preprocess_u8(rgb, B, h, w, tx.xmin, tx.cnt, tx.K, tx.ksize, ty.xmin, ty.cnt, ty.K, ty.ksize,
+                                         out, m->cfg.img_h, m->cfg.img_w, mean, stdv, (hipStream_t)stream);
+}
+
 // detr.py:124-125 (keep = score > threshold, in query order) and :161-205 (nms_3d):
 // candidates sorted by descending score; a later candidate is suppressed by a kept one when
 // (same class and 3D-AABB IoU > 0.25) or (nms_2d and 2D IoU > 0.5).  keep_idx receives query indices in kept order.

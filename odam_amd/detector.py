@@ -49,6 +49,7 @@ class Detector:
                  dec_layers=6, num_queries=100, num_classes=18, angle_bins=30, max_batch=8, device="cuda:0",
                  n_streams=2, dtype="fp32"):
         self.n_streams = max(1, int(n_streams))
+        self.resize = (800, 1333)   # get_transforms(): shortest side, longest-side cap (transforms.py:281-290)
         if dtype not in ("fp32", "bf16"):
             raise ValueError("dtype must be 'fp32' (parity mode) or 'bf16' (BASELINE config 4)")
         self.dtype = dtype
@@ -151,6 +152,33 @@ class Detector:
 
     forward = __call__
 
+    # ---- transforms.py:281-290 on the device + DETR.forward ------------------------------------------
+    def preprocess_u8(self, rgb, out=None, idx=0, stream=None):
+        """uint8 [B,h,w,3] device frames -> float32 [B,3,H,W] (resize shortest side to `size`, /255, normalise):
+        the reference's get_transforms() evaluated by the library, bit-identical to the PIL/torch host path."""
+        from .transforms import MEAN, STD, target_size
+        B, h, w, c = rgb.shape
+        assert c == 3 and rgb.dtype == torch.uint8 and rgb.is_cuda and rgb.is_contiguous()
+        H, W = target_size(w, h, *self.resize)
+        if out is None:
+            out = torch.empty(B, 3, H, W, device=self.device, dtype=torch.float32)
+        st = stream if stream is not None else torch.cuda.current_stream(self.device).cuda_stream
+        mean, std = (ctypes.c_float * 3)(*MEAN), (ctypes.c_float * 3)(*STD)
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().odam_detr_preprocess_u8(self._handle(H, W, idx), _lib.ptr(rgb), ctypes.c_int(B),
+                                                          ctypes.c_int(h), ctypes.c_int(w), mean, std, _lib.ptr(out),
+                                                          ctypes.c_void_p(st)), "odam_detr_preprocess_u8")
+        return out
+
+    def forward_u8(self, rgb):
+        """raw uint8 [B,h,w,3] frames (device) -> the DETR output dict; B <= max_batch per preprocessing call"""
+        outs = [self(self.preprocess_u8(rgb[b0:b0 + self.max_batch])) for b0 in range(0, rgb.shape[0], self.max_batch)]
+        if len(outs) == 1:
+            return outs[0]
+        res = {k: torch.cat([o[k] for o in outs]) for k in outs[0] if k != "_hw"}
+        res["_hw"] = outs[0]["_hw"]
+        return res
+
     def debug_taps(self, B, H, W):
         """layer4 feature map [B,2048,h,w] and encoder memory [B,h*w,256] of the last forward (tests)."""
         hd = self._handle(H, W)
@@ -215,7 +243,12 @@ class Detector:
         asynchronous copy into pinned host memory + an event), and the generator yields
         (first_frame, rows[n,Q,16]) as each chunk's event completes -- host-side thresholding / NMS of chunk i
         overlaps the kernels of chunks i+1.. ."""
-        N, _, H, W = frames.shape
+        raw = frames.dtype == torch.uint8     # [N,h,w,3] frames as decoded: the input transform runs on the device
+        if raw:
+            from .transforms import target_size
+            N, H, W = frames.shape[0], *target_size(frames.shape[2], frames.shape[1], *self.resize)
+        else:
+            N, _, H, W = frames.shape
         a = self.arch
         Q = a["num_queries"]
         dev = self.device
@@ -242,9 +275,14 @@ class Detector:
         events = []
         nb = 0
         on_host = not frames.is_cuda
+        if raw:
+            if getattr(self, "_xform", None) is None or self._xform[0].shape[2:] != (H, W) or len(self._xform) != ns:
+                self._xform = [torch.empty(mb, 3, H, W, device=dev, dtype=torch.float32) for _ in range(ns)]
         if on_host:
-            if getattr(self, "_stage", None) is None or self._stage[0][0].shape[2:] != (H, W) or len(self._stage) != ns:
-                self._stage = [[torch.empty(mb, 3, H, W, device=dev, dtype=torch.float32) for _ in range(2)] for _ in range(ns)]
+            st0 = getattr(self, "_stage", None)
+            if st0 is None or st0[0][0].shape[1:] != frames.shape[1:] or st0[0][0].dtype != frames.dtype or len(st0) != ns:
+                self._stage = [[torch.empty((mb,) + tuple(frames.shape[1:]), device=dev, dtype=frames.dtype)
+                                for _ in range(2)] for _ in range(ns)]
                 self._copy_stream = torch.cuda.Stream(device=dev)
             stage_free = [[None, None] for _ in range(ns)]   # event: the forward that last read this buffer is done
         with torch.cuda.device(dev):
@@ -270,6 +308,8 @@ class Detector:
                             up.record(self._copy_stream)
                         self._streams[k].wait_event(up)
                         src = buf
+                    if raw:    # same stream as the forward that reads it: the buffer is free again when that is done
+                        src = self.preprocess_u8(src, self._xform[k][:B], k, self._streams[k].cuda_stream)
                     _lib.check(L.odam_detr_forward(handles[k], _lib.ptr(src), ctypes.c_int(B), _lib.ptr(lg),
                                                    _lib.ptr(bx), _lib.ptr(an), _lib.ptr(of), _lib.ptr(sz), _lib.ptr(dp),
                                                    ctypes.c_void_p(0), sp), "odam_detr_forward")

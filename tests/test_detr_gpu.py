@@ -242,6 +242,45 @@ def test_streamed_detection_equals_plain_forward(model):
     assert np.allclose(det.detect_resident(frames, (640, 480), K), plain, rtol=0, atol=2e-6)
 
 
+@pytest.mark.parametrize("w,h,resize", [(640, 480, (800, 1333)), (800, 600, (800, 1333)), (96, 72, (240, 400)),
+                                        (57, 131, (120, 200)), (400, 300, (150, 1333)), (321, 240, (240, 1333))])
+def test_device_transform_equals_host_transform(model, w, h, resize):
+    """A1 on the device (PIL bilinear resize in 22-bit fixed point, /255, normalise) is bit-identical to the PIL +
+    torch host transform, for up-scaling, down-scaling and a pass-through axis"""
+    from odam_amd import transforms
+    det, _ = model
+    rng = np.random.default_rng(w * 1000 + h)
+    imgs = rng.integers(0, 256, (3, h, w, 3), dtype=np.uint8)
+    imgs[1] = (np.add.outer(np.arange(h), np.arange(w))[..., None] * np.array([1, 2, 3])) % 256   # ramps
+    imgs[2, ::2] = 255; imgs[2, 1::2] = 0                                                          # extremes
+    host = torch.stack([transforms.Transforms(*resize)(im)[0] for im in imgs])
+    det.resize = resize
+    try:
+        got = det.preprocess_u8(torch.from_numpy(imgs).to(DEV)).cpu()
+    finally:
+        det.resize = (800, 1333)
+    assert got.shape == host.shape
+    assert torch.equal(got, host)
+
+
+def test_streamed_detection_from_raw_frames(model):
+    """uint8 frames (resident, or pinned on the host and uploaded under the kernels) through the device transform
+    give exactly the rows of the host-transformed float frames"""
+    from odam_amd import transforms
+    det, _ = model
+    rng = np.random.default_rng(5)
+    raw = rng.integers(0, 256, (6, 72, 96, 3), dtype=np.uint8)
+    det.resize = (240, 400)
+    try:
+        host = torch.stack([transforms.Transforms(240, 400)(im)[0] for im in raw]).to(DEV)
+        want = det.detect_resident(host, (96, 72), K)
+        got_dev = det.detect_resident(torch.from_numpy(raw).to(DEV), (96, 72), K)
+        got_pin = det.detect_resident(torch.from_numpy(raw).pin_memory(), (96, 72), K)
+    finally:
+        det.resize = (800, 1333)
+    assert np.array_equal(got_dev, want) and np.array_equal(got_pin, want)
+
+
 # ---- bf16 mode (BASELINE config 4): bf16 weights/activations, bf16 MFMA, fp32 accumulation ------------------------
 def _to_bf16_bits(t):
     return t.to(torch.bfloat16).view(torch.int16)
