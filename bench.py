@@ -35,14 +35,14 @@ TRAFFIC_BYTES_PER_FRAME_PMC = (2 * 44250691.0 + 53019075.0) * 1024 / 64   # prof
 
 
 def build_frames(n_local, device, seed):
-    """resident detector inputs: 32 distinct synthetic 640x480 RGB frames through the reference's transform
-    (PIL resize to 800x1066, /255, ImageNet normalisation), tiled to n_local with a per-frame intensity offset"""
-    t = transforms.get_transforms()
-    base = torch.stack([t(f)[0] for f in synth.make_frames(min(32, n_local), seed=seed)]).to(device)
-    out = torch.empty(n_local, 3, base.shape[2], base.shape[3], device=device, dtype=torch.float32)
+    """resident raw frames: 32 distinct synthetic 640x480 uint8 RGB frames tiled to n_local with a per-frame intensity
+    offset, [n_local,480,640,3] in HBM.  The reference's transform (PIL-bilinear resize to 800x1066, /255, ImageNet
+    normalisation; transforms.py:281-290) runs on the device inside the timed step."""
+    base = np.stack(list(synth.make_frames(min(32, n_local), seed=seed)))
+    out = np.empty((n_local,) + base.shape[1:], np.uint8)
     for i in range(n_local):
-        out[i] = base[i % len(base)] + 0.01 * ((i // len(base)) % 7)
-    return out
+        out[i] = np.clip(base[i % len(base)].astype(np.int16) + (i // len(base)) % 7, 0, 255).astype(np.uint8)
+    return torch.from_numpy(out).to(device)
 
 
 def main():
@@ -91,7 +91,7 @@ def main():
     detector.load_state_dict(weights.make_state_dict(seed=0))
     fitter = sq.SqFitter(device, 200)
     frames = build_frames(f1 - f0, device, seed=rank)
-    H, W = frames.shape[2], frames.shape[3]
+    H, W = transforms.target_size(frames.shape[2], frames.shape[1])   # 800 x 1066
 
     # SQ problems decoupled from the (random-weight) detector output so the fit runs at the stated sizes
     scene = synth.make_scene(N, args.objects, seed=1, min_views=10, max_views=min(300, N))
@@ -146,7 +146,7 @@ def main():
     # the contraction kernel alone on the device: one more forward on one stream with an event pair around
     # every launch (flop count per launch comes from the library)
     detector.profile(H, W, True)
-    detector(frames[:args.batch])
+    detector(detector.preprocess_u8(frames[:args.batch]))
     torch.cuda.synchronize()
     n_launch, conv_ms, conv_flops = detector.profile_read(H, W)
     att_n, att_ms, att_flops = detector.profile_read_attention(H, W)
@@ -174,8 +174,9 @@ def main():
         "scaling": "strong",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic (seeded 640x480 RGB stream through the reference transform; deterministic random-init "
-                "DETR-R50 weights; synthetic 82-column object tracks for the SQ fit)",
+        "data": "synthetic (seeded 640x480 uint8 RGB stream resident in HBM, put through the reference transform on the "
+                "device inside the step; deterministic random-init DETR-R50 weights; synthetic 82-column object tracks "
+                "for the SQ fit)",
         "config": {"workload": f"one scene: {N} frames 640x480 -> 800x1066, DETR-R50 detect + 2 passes of "
                                f"200-step SQ fit over {len(tracks)} objects (10-300 views), fp32",
                    "frames": N, "objects": len(tracks), "detector_batch": args.batch, "detector_streams": args.streams,
@@ -259,11 +260,11 @@ def cpu_baseline(scene, tracks, N):
     from conftest import Oracle
     sd = weights.make_state_dict(seed=0)
     t = transforms.get_transforms()
-    imgs = [t(f)[0][None] for f in synth.make_frames(3, seed=0)]
-    detr_oracle.detr_forward(sd, imgs[0])  # warm-up
+    imgs = list(synth.make_frames(3, seed=0))
+    detr_oracle.detr_forward(sd, t(imgs[0])[0][None])  # warm-up
     s = time.perf_counter()
-    for im in imgs[1:]:
-        out = detr_oracle.detr_forward(sd, im)
+    for f in imgs[1:]:
+        out = detr_oracle.detr_forward(sd, t(f)[0][None])   # host transform (PIL + torch) + forward
         detr_oracle.postprocess(out, (synth.IMG_W, synth.IMG_H), 0.6, synth.K_SCANNET)
     det_fps = (len(imgs) - 1) / (time.perf_counter() - s)
     o = Oracle()

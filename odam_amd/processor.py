@@ -103,17 +103,26 @@ class OdamProcess:
     # ---- detection (processor.py:259-289) ----------------------------------------------------------
     def detect_frames(self, rgbs, frame_ids):
         """Batched, stateless run_detector over several frames: list (per frame) of lists of 79-float rows."""
-        tensors = [self.transforms(rgb, None)[0] for rgb in rgbs]
-        sizes = {tuple(rgb.size) for rgb in rgbs}
+        sizes = {tuple(rgb.size) if hasattr(rgb, "size") and not isinstance(rgb, np.ndarray) else rgb.shape[1::-1]
+                 for rgb in rgbs}
         assert len(sizes) == 1, "frames of one batch must have one size"
         img_size = sizes.pop()
         out = []
         mb = getattr(self.detector, "max_batch", 1)
-        for b0 in range(0, len(tensors), mb):
-            x = torch.stack(tensors[b0:b0 + mb])
-            pred = self.detector(x)
+        on_device = getattr(self.transforms, "on_device", False)
+        if on_device:
+            self.detector.resize = (self.transforms.size, self.transforms.max_size)
+        for b0 in range(0, len(rgbs), mb):
+            if on_device:   # raw uint8 frames up, transform + forward on the GPU
+                raw = np.stack([np.asarray(rgb, np.uint8) for rgb in rgbs[b0:b0 + mb]])
+                pred = self.detector.forward_u8(torch.from_numpy(raw).to(self.detector.device))
+                nb = raw.shape[0]
+            else:
+                x = torch.stack([self.transforms(rgb, None)[0] for rgb in rgbs[b0:b0 + mb]])
+                pred = self.detector(x)
+                nb = x.shape[0]
             objs = self.detector.postprocess(pred, img_size, float(self.detect_threshold), self.sequence_meta.K)
-            for b in range(x.shape[0]):
+            for b in range(nb):
                 out.append(detection_rows(objs, b, frame_ids[b0 + b], self.sequence_meta.img_w,
                                           self.sequence_meta.img_h))
         return out

@@ -1,7 +1,8 @@
 """Image transforms of the detector input: the reference's `get_transforms()` (likojack/ODAM
 src/datasets/transforms.py:281-290): shortest side -> 800 (max 1333) with PIL bilinear on the uint8 image,
-ToTensor (/255), Normalize(ImageNet mean/std).  Host side, caller-supplied object as in the reference
-(`transforms(rgb, None) -> (tensor[3,H,W], None)`); torchvision is not required."""
+ToTensor (/255), Normalize(ImageNet mean/std).  Caller-supplied object as in the reference
+(`transforms(rgb, None) -> (tensor[3,H,W], None)`), on the host with PIL + torch (torchvision is not required), or --
+`get_device_transforms()` -- on the device through `odam_detr_preprocess_u8`."""
 import numpy as np
 import torch
 from PIL import Image
@@ -40,3 +41,14 @@ class Transforms:
 
 def get_transforms():
     return Transforms()
+
+
+class DeviceTransforms(Transforms):
+    """Same transform, evaluated by the library on the device (`Detector.preprocess_u8`, bit-identical results):
+    pass it to OdamProcess instead of get_transforms() and `detect_frames` uploads the raw uint8 frames (11x fewer
+    PCIe bytes) and resizes / normalises them on the GPU.  Called directly it is the host transform."""
+    on_device = True
+
+
+def get_device_transforms():
+    return DeviceTransforms()

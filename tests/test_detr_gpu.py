@@ -281,6 +281,25 @@ def test_streamed_detection_from_raw_frames(model):
     assert np.array_equal(got_dev, want) and np.array_equal(got_pin, want)
 
 
+def test_detect_frames_with_device_transforms(model):
+    """OdamProcess.detect_frames: raw frames + DeviceTransforms give the rows of the host-transform path"""
+    from PIL import Image
+    from odam_amd import synth, transforms
+    from odam_amd.processor import OdamProcess
+    det, _ = model
+    frames = [Image.fromarray(f) for f in synth.make_frames(3, h=96, w=128, seed=2)]
+    rows = []
+    for t in (transforms.Transforms(192, 320), transforms.DeviceTransforms(192, 320)):
+        proc = OdamProcess(det, None, t, None, detect_threshold=0.02)
+        proc.init_sequence(K, 96, 128)
+        rows.append(proc.detect_frames(frames, [7, 8, 9]))
+    det.resize = (800, 1333)
+    assert sum(len(r) for r in rows[0]) > 0
+    assert [len(r) for r in rows[0]] == [len(r) for r in rows[1]]
+    for a, b in zip(rows[0], rows[1]):
+        assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 # ---- bf16 mode (BASELINE config 4): bf16 weights/activations, bf16 MFMA, fp32 accumulation ------------------------
 def _to_bf16_bits(t):
     return t.to(torch.bfloat16).view(torch.int16)
