@@ -26,6 +26,10 @@ def lib():
             raise OdamError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch ships its own HIP runtime; it must be the first one mapped into the process.  Loading this library
+        # before torch binds it to the system libamdhip64 instead, and the two runtimes then disagree about the
+        # devices ("no ROCm-capable device is detected" at the first hipMalloc).
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.odam_last_error.restype = ctypes.c_char_p
         _lib = L

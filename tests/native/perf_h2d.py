@@ -17,8 +17,12 @@ def run(fr):
     return np.concatenate(out)
 a = run(dev); b = run(host)
 print("host-upload path equals resident path:", np.array_equal(a, b), flush=True)
-for name, fr in (("resident", dev), ("pinned host + upload", host)):
+raw = torch.randint(0, 256, (N, 480, 640, 3), dtype=torch.uint8)
+raw_pin, raw_dev = raw.pin_memory(), raw.to("cuda:0")
+print("raw uint8: pinned-upload path equals resident path:", np.array_equal(run(raw_dev), run(raw_pin)), flush=True)
+for name, fr in (("resident", dev), ("pinned host + upload", host), ("raw uint8 resident + device transform", raw_dev),
+                 ("raw uint8 pinned + upload + device transform", raw_pin)):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(2): run(fr)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
-    print(f"{name:22s}: {N/dt:7.1f} frames/s  ({N*3*800*1066*4/dt/1e9:.1f} GB/s of input)", flush=True)
+    print(f"{name:44s}: {N/dt:7.1f} frames/s  ({fr[0].numel()*fr.element_size()*N/dt/1e9:.2f} GB/s of input)", flush=True)
