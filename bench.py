@@ -69,6 +69,7 @@ def main():
     torch.cuda.set_device(local_rank)
     if ws > 1:
         import torch.distributed as dist
+        torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // ws)))   # ranks share the host cores
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device(f"cuda:{local_rank}"))
         else:
