@@ -9,8 +9,10 @@
  *
  * Conventions: plain pointers and sizes, no exceptions across the boundary, int return code
  * (0 = OK, otherwise an ODAM_E_* value; odam_last_error() returns a static message), caller-owned
- * buffers, work is enqueued on the caller's hipStream_t (passed as void*), no synchronisation and
- * no allocation inside the *_batch calls (all scratch lives in the handle).
+ * buffers, work is enqueued on the caller's hipStream_t (passed as void*).  All scratch lives in the handle: the
+ * *_batch calls neither synchronise nor allocate, except that odam_sq_fit_batch grows the handle's exchange
+ * buffer (hipMalloc) the first time a larger problem is seen.  A handle serves one launch at a time (use one
+ * per stream / thread).
  * Pointers marked [dev] are device pointers, [host] host pointers.
  */
 #ifndef ODAM_SQ_H
@@ -43,7 +45,9 @@ int odam_sq_create(int max_iters, odam_sq_ctx** out);
 int odam_sq_destroy(odam_sq_ctx* ctx);
 
 /*
- * Fits n_obj super-quadrics, one workgroup per object, n_iters Adam steps each, entirely on device.
+ * Fits n_obj super-quadrics, n_iters Adam steps each, entirely on device: one 1024-thread workgroup per object,
+ * or -- when the grid would leave most CUs idle -- up to four per object that split the views of the per-view
+ * extent search and exchange the per-view gradient rows once per step (results are bit-identical either way).
  *   init_params  [dev] [n_obj][9]   translate[3], angle, scales[3] (= sqrt(dims/2)), shapes[2]
  *   class_id     [dev] [n_obj]      0..7 selects the scale prior row; < 0 = no prior (prior=False)
  *   view_offsets [dev] [n_obj+1]    object o owns views view_offsets[o] .. view_offsets[o+1]-1

@@ -48,6 +48,7 @@ constexpr int BUFP = 208;       // padded theta-buffer length
 constexpr int QCAP = 200;       // pending arcs per curve per level (sum of n over a level <= 199)
 constexpr int NONE = 0x7fffffff;
 constexpr int TABN = 513;        // dyadic theta table: depth 9 of the parameter bisection
+constexpr unsigned long long SPLIT_WAIT_TICKS = 3000;   // 30 us of the 100 MHz wall clock: longer than one slice of phase E
 
 struct QArc {                    // pending arc + its position in the dyadic table (-1: deeper than the table)
     Arc a;
@@ -72,6 +73,14 @@ struct FitArgs {
     float* out_points;
     float* loss_log;
     float* traj;
+    // view split (phase E of one object over `split` workgroups, see the kernel): exchange rows + progress flags
+    int n_obj;
+    int split;                        // workgroups per object (1 = off)
+    int split_min_views;              // objects with fewer views stay on one workgroup
+    int max_views;                    // row pitch of the exchange buffers
+    float* xgrad;                     // [n_iters][n_obj][max_views][9]
+    float* xloss;                     // [n_iters][n_obj][max_views][4] (only with loss_log)
+    unsigned* done;                   // [n_obj][split]: steps published by each workgroup, zeroed before launch
 };
 
 struct Lds {
@@ -83,6 +92,7 @@ struct Lds {
     float* shape;   // [12]  c, s, a0..2, e0..1, sig0..1
     float* misc;    // [8]   cdf sum, dirsum[4]
     int* cnt;       // [8]   3 x 2 level counters
+    int* xready;    // [16]  view split: partner rows arrived this step
     float* pwx;     // [1024] x3
     float* pwy;
     float* pwz;
@@ -101,7 +111,7 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_words(int pn) {
-    return 12 * 6 + 8 + 8 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
+    return 12 * 6 + 8 + 8 + 16 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
            (size_t)pn * 9 + (size_t)pn * 4;
 }
 
@@ -116,6 +126,7 @@ __device__ inline Lds carve(float* base, int pn) {
     L.shape = w; w += 12;
     L.misc = w; w += 8;
     L.cnt = (int*)w; w += 8;
+    L.xready = (int*)w; w += 16;
     L.pwx = w; w += 1024;
     L.pwy = w; w += 1024;
     L.pwz = w; w += 1024;
@@ -156,7 +167,21 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int obj = blockIdx.x;
+    // View split: the per-view extent search (phase E) is pure VALU work on one CU, ~0.3 us per view per step.  With
+    // few objects and many idle CUs an object is given `split` workgroups: each runs the whole (deterministic) step --
+    // sampler, points, tree, Adam -- redundantly and in lock step, but only its own slice of the views in phase E; the
+    // per-view gradient rows are exchanged through HBM once per step.  The exchange never blocks: rows of every step
+    // have their own slot (no reuse, so a published row is final), a workgroup that does not find a partner's rows
+    // after a bounded wait computes that slice itself (same arithmetic, same bits), so the result does not depend on
+    // which workgroups are resident or how far apart they run, and nothing can deadlock.
+    // Workgroup ids are dealt round-robin over the 8 XCDs: the workgroups of one object share an XCD (one L2).
+    int obj = blockIdx.x, wj = 0;
+    if (A.split > 1) {
+        const int g = blockIdx.x, xcd = g & 7, slot = g >> 3;
+        wj = slot % A.split;
+        obj = (slot / A.split) * 8 + xcd;
+        if (obj >= A.n_obj) return;
+    }
     Lds L = carve(smem, A.pn_views);
 
     int v0 = 0, F = 0;
@@ -171,6 +196,11 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
     const bool use_prior = (cls >= 0) && (A.prior_icov != nullptr);
     const int n_opt = (A.representation == ODAM_SQ_SUPER_QUADRIC) ? 9 : 7;
     const bool want_loss = (A.loss_log != nullptr);
+    const int keff = (A.split > 1 && F >= A.split_min_views) ? A.split : 1;
+    if (wj >= keff) return;
+    const int fs = (F + keff - 1) / keff;           // views per slice
+    const bool lead = (wj == 0);                    // writes the object's outputs
+    int absent = 0;                                 // bit jj: partner jj missed a deadline once -> no more waiting for it
 
     if (tid < 9) {
         L.p[tid] = A.init_params[(size_t)obj * 9 + tid];
@@ -189,7 +219,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
     {
         int best_cost = 0x7fffffff;
         for (int c = 1; c <= 64; c <<= 1) {
-            const int rounds = (F * c + NT - 1) / NT;
+            const int rounds = (fs * c + NT - 1) / NT;
             const int cost = rounds * ((N_PTS + c - 1) / c + 24);
             if (cost < best_cost) { best_cost = cost; S = c; }
         }
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         __syncthreads();
 
         if (it == A.n_iters) {
-            if (A.out_points) {
+            if (A.out_points && lead) {
                 for (int i = tid; i < N_PTS; i += NT) {
                     float* o = A.out_points + ((size_t)obj * N_PTS + i) * 3;
                     o[0] = L.pwx[i]; o[1] = L.pwy[i]; o[2] = L.pwz[i];
@@ -362,10 +392,11 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         // each walks every S-th surface point keeping its four running extremes (value, first index), an
         // S-lane xor butterfly merges them, then the closed-form gradient of the view's four edges runs on
         // those same lanes and is added in the order (d0 + d1) + (d2 + d3).
-        for (int v0 = 0; v0 < F; v0 += NT / S) {
+        auto views = [&](int f_lo, int f_hi) {
+        for (int v0 = f_lo; v0 < f_hi; v0 += NT / S) {
             const int f = v0 + tid / S;
             const int sub = tid & (S - 1);
-            const bool vf = f < F;
+            const bool vf = f < f_hi;
             float Mv[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) Mv[k] = vf ? Pm[(size_t)12 * f + k] : 0.0f;
@@ -457,6 +488,58 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                 for (int k = 0; k < 9; k++) L.vgrad[f * 9 + k] = g9[k];
             }
         }
+        };
+        {
+            const int lo = wj * fs < F ? wj * fs : F, hi = lo + fs < F ? lo + fs : F;
+            views(lo, hi);
+            if (keff > 1) {
+                // Publish my rows of this step and collect the other slices, one wavefront per partner: wavefront wj
+                // stores the rows and raises the flag (release), wavefront jj != wj waits for partner jj's flag
+                // (acquire, bounded) and copies its rows into LDS.  Slices that did not arrive are computed here.
+                __syncthreads();
+                const size_t row0 = ((size_t)it * A.n_obj + obj) * A.max_views;
+                float* xg = A.xgrad + row0 * 9;
+                float* xl = want_loss ? A.xloss + row0 * 4 : nullptr;
+                if (wid == wj) {
+                    for (int idx = lo * 9 + lane; idx < hi * 9; idx += 64) xg[idx] = L.vgrad[idx];
+                    if (want_loss)
+                        for (int idx = lo * 4 + lane; idx < hi * 4; idx += 64) xl[idx] = L.lterm[idx];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0)
+                        __hip_atomic_store(&A.done[obj * A.split + wj], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                } else if (wid < keff) {
+                    const int jj = wid;
+                    const int plo = jj * fs < F ? jj * fs : F, phi = plo + fs < F ? plo + fs : F;
+                    const unsigned* flag = &A.done[obj * A.split + jj];
+                    int ready = 0;
+                    if (lane == 0) {
+                        ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
+                        if (!ready && !((absent >> jj) & 1)) {
+                            const unsigned long long t0 = wall_clock64();   // 100 MHz
+                            while (!ready && wall_clock64() - t0 < SPLIT_WAIT_TICKS) {
+                                __builtin_amdgcn_s_sleep(4);
+                                ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
+                            }
+                        }
+                    }
+                    ready = __shfl(ready, 0);
+                    if (ready) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                        for (int idx = plo * 9 + lane; idx < phi * 9; idx += 64) L.vgrad[idx] = xg[idx];
+                        if (want_loss)
+                            for (int idx = plo * 4 + lane; idx < phi * 4; idx += 64) L.lterm[idx] = xl[idx];
+                    }
+                    if (lane == 0) L.xready[jj] = ready;
+                }
+                __syncthreads();
+                for (int jj = 0; jj < keff; jj++) {
+                    if (jj == wj || L.xready[jj]) continue;      // uniform: read from LDS after the barrier
+                    absent |= 1 << jj;                           // no more waiting for this partner
+                    const int plo = jj * fs < F ? jj * fs : F, phi = plo + fs < F ? plo + fs : F;
+                    views(plo, phi);
+                }
+            }
+        }
         for (int idx = tid; idx < (Pn - F) * 9; idx += NT) L.vgrad[F * 9 + idx] = 0.0f;
         __syncthreads();
 
@@ -486,16 +569,16 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                 adam_scalar(pp, mm, vv, g, (tid < 7) ? tab[0] : tab[1], tab[2]);
                 L.p[tid] = pp; L.m[tid] = mm; L.v[tid] = vv;
             }
-            if (A.traj) A.traj[((size_t)obj * A.n_iters + it) * 9 + tid] = L.p[tid];
+            if (A.traj && lead) A.traj[((size_t)obj * A.n_iters + it) * 9 + tid] = L.p[tid];
         }
-        if (want_loss && tid == 0) {
+        if (want_loss && tid == 0 && lead) {
             float l2d = 0.0f;
             for (int dd = 0; dd < 4; dd++) l2d += L.misc[1 + dd] * invF;
             A.loss_log[(size_t)obj * A.n_iters + it] = l2d;
         }
         __syncthreads();
     }
-    if (A.out_params && tid < 9) A.out_params[(size_t)obj * 9 + tid] = L.p[tid];
+    if (A.out_params && tid < 9 && lead) A.out_params[(size_t)obj * 9 + tid] = L.p[tid];
 }
 
 }  // namespace
@@ -509,6 +592,12 @@ struct odam_sq_ctx {
     unsigned short* d_omega_idx;
     float* d_adam;
     float* d_dummy_params;
+    // view-split exchange (grow-only; a context serves one launch at a time, like a stream)
+    float* d_xch = nullptr;
+    size_t xch_bytes = 0;
+    unsigned* d_done = nullptr;
+    size_t done_n = 0;
+    int n_cu = 256;
 };
 
 static std::vector<float> sampler_draws() {
@@ -547,6 +636,10 @@ extern "C" int odam_sq_create(int max_iters, odam_sq_ctx** out) {
     ODAM_HIP(hipMemcpy(c->d_adam, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
     ODAM_HIP(hipFuncSetAttribute((const void*)sq_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  160 * 1024));
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        c->n_cu = prop.multiProcessorCount;
     *out = c;
     return ODAM_OK;
 }
@@ -556,6 +649,8 @@ extern "C" int odam_sq_destroy(odam_sq_ctx* c) {
     (void)hipFree(c->d_draws);
     (void)hipFree(c->d_omega_idx);
     (void)hipFree(c->d_adam);
+    if (c->d_xch) (void)hipFree(c->d_xch);
+    if (c->d_done) (void)hipFree(c->d_done);
     delete c;
     return ODAM_OK;
 }
@@ -569,7 +664,37 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     A.adam_tab = ctx->d_adam;
     size_t bytes = lds_words(pn) * sizeof(float);
     if (bytes > 160 * 1024) return odam_fail(ODAM_E_LIMIT, "odam_sq: LDS budget exceeded");
-    hipLaunchKernelGGL(sq_fit_kernel, dim3(n_obj), dim3(NT), bytes, stream, A);
+    // View split: only when every workgroup of the grid can be resident at once (one 1024-thread workgroup per CU),
+    // the objects are large enough to gain, and the exchange history fits a modest buffer.
+    static const int split_env = getenv("ODAM_SQ_SPLIT") ? atoi(getenv("ODAM_SQ_SPLIT")) : 4;
+    A.n_obj = n_obj; A.split = 1; A.split_min_views = 64; A.max_views = max_views;
+    int grid = n_obj;
+    const int n_pad = (n_obj + 7) / 8 * 8;
+    int k = split_env < 1 ? 1 : (split_env > 8 ? 8 : split_env);   // measured: 4 is best from 1 to 60 objects
+    while (k > 1 && n_pad * k > ctx->n_cu) k >>= 1;
+    if (k > 1 && A.n_iters > 0 && max_views >= A.split_min_views) {
+        const size_t rows = (size_t)A.n_iters * n_obj * max_views;
+        const size_t need = rows * (A.loss_log ? 13 : 9) * sizeof(float);
+        if (need <= ((size_t)1 << 30)) {
+            if (need > ctx->xch_bytes) {
+                if (ctx->d_xch) { ODAM_HIP(hipStreamSynchronize(stream)); (void)hipFree(ctx->d_xch); ctx->d_xch = nullptr; ctx->xch_bytes = 0; }
+                ODAM_HIP(hipMalloc(&ctx->d_xch, need));
+                ctx->xch_bytes = need;
+            }
+            if ((size_t)n_obj * k > ctx->done_n) {
+                if (ctx->d_done) { ODAM_HIP(hipStreamSynchronize(stream)); (void)hipFree(ctx->d_done); ctx->d_done = nullptr; ctx->done_n = 0; }
+                ODAM_HIP(hipMalloc(&ctx->d_done, sizeof(unsigned) * n_obj * k));
+                ctx->done_n = (size_t)n_obj * k;
+            }
+            ODAM_HIP(hipMemsetAsync(ctx->d_done, 0, sizeof(unsigned) * n_obj * k, stream));
+            A.split = k;
+            A.xgrad = ctx->d_xch;
+            A.xloss = A.loss_log ? ctx->d_xch + rows * 9 : nullptr;
+            A.done = ctx->d_done;
+            grid = n_pad * k;
+        }
+    }
+    hipLaunchKernelGGL(sq_fit_kernel, dim3(grid), dim3(NT), bytes, stream, A);
     ODAM_HIP(hipGetLastError());
     return ODAM_OK;
 }
