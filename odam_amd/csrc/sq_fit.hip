@@ -48,7 +48,6 @@ constexpr int BUFP = 208;       // padded theta-buffer length
 constexpr int QCAP = 200;       // pending arcs per curve per level (sum of n over a level <= 199)
 constexpr int NONE = 0x7fffffff;
 constexpr int TABN = 513;        // dyadic theta table: depth 9 of the parameter bisection
-constexpr unsigned long long SPLIT_WAIT_TICKS = 3000;   // 30 us of the 100 MHz wall clock: longer than one slice of phase E
 
 struct QArc {                    // pending arc + its position in the dyadic table (-1: deeper than the table)
     Arc a;
@@ -81,6 +80,7 @@ struct FitArgs {
     float* xgrad;                     // [n_iters][n_obj][max_views][9]
     float* xloss;                     // [n_iters][n_obj][max_views][4] (only with loss_log)
     unsigned* done;                   // [n_obj][split]: steps published by each workgroup, zeroed before launch
+    unsigned split_wait_ticks;        // bounded wait for a partner's rows, 100 MHz wall clock (30 us: > one slice of phase E)
 };
 
 struct Lds {
@@ -516,7 +516,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                         ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
                         if (!ready && !((absent >> jj) & 1)) {
                             const unsigned long long t0 = wall_clock64();   // 100 MHz
-                            while (!ready && wall_clock64() - t0 < SPLIT_WAIT_TICKS) {
+                            while (!ready && wall_clock64() - t0 < A.split_wait_ticks) {
                                 __builtin_amdgcn_s_sleep(4);
                                 ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
                             }
@@ -667,7 +667,8 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     // View split: only when every workgroup of the grid can be resident at once (one 1024-thread workgroup per CU),
     // the objects are large enough to gain, and the exchange history fits a modest buffer.
     static const int split_env = getenv("ODAM_SQ_SPLIT") ? atoi(getenv("ODAM_SQ_SPLIT")) : 4;
-    A.n_obj = n_obj; A.split = 1; A.split_min_views = 64; A.max_views = max_views;
+    static const int wait_env = getenv("ODAM_SQ_SPLIT_WAIT") ? atoi(getenv("ODAM_SQ_SPLIT_WAIT")) : 3000;   // 0: never wait (tests)
+    A.n_obj = n_obj; A.split = 1; A.split_min_views = 64; A.max_views = max_views; A.split_wait_ticks = (unsigned)wait_env;
     int grid = n_obj;
     const int n_pad = (n_obj + 7) / 8 * 8;
     int k = split_env < 1 ? 1 : (split_env > 8 ? 8 : split_env);   // measured: 4 is best from 1 to 60 objects
