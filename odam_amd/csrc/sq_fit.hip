@@ -225,6 +225,12 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         }
     }
 
+#ifdef SQ_STAMPS   // timing experiments: accumulated 100 MHz ticks per phase, written over out_points of object 0
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = wall_clock64();
+#define STAMP(k) do { if (tid == 0) { const unsigned long long now_ = wall_clock64(); st_acc[k] += now_ - st_last; st_last = now_; } } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
     for (int it = 0; it <= A.n_iters; ++it) {
         // ---------------- A: shape scalars ------------------------------------------------------
         if (tid == 0) L.shape[0] = cosf_(L.p[3]);
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             L.shape[tid] = sg * 1.4f + 0.2f;                                      // e   -> [5], [6]
         }
         __syncthreads();
+        STAMP(0);
         const Shape S_ = load_shape(L.shape);
         float p[9];
 #pragma unroll
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             L.buf[tid * BUFP + BUF - 1] = -ta;
         }
         __syncthreads();
+        STAMP(1);
 #ifndef SQ_ABLATE_B
         // B2: one wavefront per curve walks its levels with wave-level synchronisation only (no workgroup barrier
         // per level: a level is ~200 nodes at most, 4 passes of 64 lanes); the other wavefronts wait at the
@@ -328,6 +336,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         }
         __syncthreads();
 #endif
+        STAMP(2);
 
         // ---------------- C: CDF and per-entry factors ----------------------------------------
         for (int w = tid; w < 768; w += NT) {
@@ -359,6 +368,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         if (tid < BUF) L.cdf[tid] = L.cdf[tid] / L.misc[0];
         __syncthreads();
 
+        STAMP(3);
         // ---------------- D: inverse-CDF lookup + surface points --------------------------------
         for (int i = tid; i < N_PTS; i += NT) {
             const float r = A.draws[i];
@@ -387,6 +397,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             break;
         }
 
+        STAMP(4);
         // ---------------- E: projected extents + per-view gradient rows -----------------------
         // A view is owned by S consecutive lanes (S = largest power of two <= NT / F, at most one wavefront):
         // each walks every S-th surface point keeping its four running extremes (value, first index), an
@@ -543,6 +554,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         for (int idx = tid; idx < (Pn - F) * 9; idx += NT) L.vgrad[F * 9 + idx] = 0.0f;
         __syncthreads();
 
+        STAMP(5);
         // ---------------- F: tree over views, prior, Adam ---------------------------------------
         if (want_loss) {
             if (tid >= 64 && tid < 68) {
@@ -577,7 +589,12 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             A.loss_log[(size_t)obj * A.n_iters + it] = l2d;
         }
         __syncthreads();
+        STAMP(6);
     }
+#ifdef SQ_STAMPS
+    if (tid == 0 && obj == 0 && lead && A.out_points)
+        for (int k = 0; k < 8; k++) A.out_points[k] = (float)st_acc[k];
+#endif
     if (A.out_params && tid < 9 && lead) A.out_params[(size_t)obj * 9 + tid] = L.p[tid];
 }
 
