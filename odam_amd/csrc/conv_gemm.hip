@@ -449,6 +449,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         return odam_fail(1, "conv_gemm: k_order 1 needs Cin % k-tile == 0, at most 32 taps, fewer than 2048 k-tiles");
     if (a.M <= 0 || a.Cout <= 0) return 0;
     static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 7;  // 8-wave tiles (+2-3 %)
+    static const int force = getenv("ODAM_CG_FORCE") ? atoi(getenv("ODAM_CG_FORCE")) : 0;   // experiments: pin one tile shape
+    if (force == 1) return launch_cfg<128, 64, 4, 2>(a, stream);
+    if (force == 2) return launch_cfg<64, 64, 2, 2, 4>(a, stream);
+    if (force == 3) return launch_cfg<128, 128, 2, 2>(a, stream);
     if (a.Cout <= 64) return (variant & 2) ? launch_cfg<128, 64, 4, 2>(a, stream) : launch_cfg<128, 64, 4, 1>(a, stream);
     const long tiles128 = (long)((a.M + 127) / 128) * ((a.Cout + 127) / 128);
     if (tiles128 < 128) return (variant & 4) ? launch_cfg<64, 64, 2, 2, 4>(a, stream) : launch_cfg<64, 64, 2, 2>(a, stream);
