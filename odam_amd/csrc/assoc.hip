@@ -58,17 +58,6 @@ __global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict_
     out[(size_t)s * 512 + c] = acc / (float)L;
 }
 
-__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, int ldx, const float* __restrict__ d,
-                                                       int ldd, int M) {
-    const int i = blockIdx.x * 256 + threadIdx.x;   // over M * 64 float4
-    if (i >= M * 64) return;
-    const int r = i >> 6, c4 = (i & 63) * 4;
-    float4 a = *reinterpret_cast<float4*>(x + (size_t)r * ldx + c4);
-    const float4 b = *reinterpret_cast<const float4*>(d + (size_t)r * ldd + c4);
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    *reinterpret_cast<float4*>(x + (size_t)r * ldx + c4) = a;
-}
-
 // log_optimal_transport + log_sinkhorn_iterations (associator.py:283-312), one 1024-thread workgroup:
 //   couplings Z[(m+1) x (n+1)] = [[scores, alpha], [alpha, alpha]] in LDS; u, v in LDS;
 //   iters x { u = log_mu - logsumexp_j(Z + v);  v = log_nu - logsumexp_i(Z + u) };  out = Z + u + v - norm
@@ -161,9 +150,8 @@ struct odam_assoc {
     float *div_term = nullptr, *sc16 = nullptr;
     // workspace
     float *feat = nullptr, *h256 = nullptr, *catT = nullptr, *q = nullptr, *kv = nullptr, *att = nullptr, *h512 = nullptr;
-    float *catTr = nullptr, *catD = nullptr, *featD = nullptr, *qT = nullptr, *kvT = nullptr, *qD = nullptr, *kvD = nullptr,
-          *attT = nullptr, *attD = nullptr, *hT = nullptr, *hD = nullptr, *dT = nullptr, *mT = nullptr, *mD = nullptr,
-          *scores = nullptr;
+    float *qX = nullptr, *kvX = nullptr, *attX = nullptr, *hX = nullptr;
+    float *catTr = nullptr, *featD = nullptr, *mT = nullptr, *scores = nullptr;
 
     int alloc(float** p, size_t n) {
         ODAM_HIP(hipMalloc((void**)p, n * sizeof(float)));
@@ -314,11 +302,12 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     const size_t T = m->max_tracks, N = T * NT;
     RC(m->alloc(&m->feat, N * FPAD)); RC(m->alloc(&m->h256, N * D)); RC(m->alloc(&m->catT, N * 512));
     RC(m->alloc(&m->q, N * D)); RC(m->alloc(&m->kv, N * 512)); RC(m->alloc(&m->att, N * D)); RC(m->alloc(&m->h512, N * 512));
-    RC(m->alloc(&m->catTr, T * 512)); RC(m->alloc(&m->catD, ND * 512)); RC(m->alloc(&m->featD, ND * FPAD));
-    const size_t TX = T > (size_t)ND ? T : (size_t)ND;   // key/value rows come from the OTHER set in cross layers
-    RC(m->alloc(&m->qT, T * D)); RC(m->alloc(&m->kvT, TX * 512)); RC(m->alloc(&m->qD, ND * D)); RC(m->alloc(&m->kvD, TX * 512));
-    RC(m->alloc(&m->attT, T * D)); RC(m->alloc(&m->attD, ND * D)); RC(m->alloc(&m->hT, T * 512)); RC(m->alloc(&m->hD, ND * 512));
-    RC(m->alloc(&m->dT, T * D)); RC(m->alloc(&m->mT, T * D)); RC(m->alloc(&m->mD, ND * D)); RC(m->alloc(&m->scores, T * 32));
+    // fused tracks [T] and the 30 detection slots share one row block (detections start at row T of the frame) so the
+    // shared-weight GNN layers see both sets as ONE matrix
+    RC(m->alloc(&m->catTr, (T + ND) * 512)); RC(m->alloc(&m->featD, ND * FPAD));
+    RC(m->alloc(&m->qX, (T + ND) * D)); RC(m->alloc(&m->kvX, (T + ND) * 512)); RC(m->alloc(&m->attX, (T + ND) * D));
+    RC(m->alloc(&m->hX, (T + ND) * 512));
+    RC(m->alloc(&m->mT, (T + ND) * D)); RC(m->alloc(&m->scores, T * 32));
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     m->host.clear();
     m->finalized = true;
@@ -334,35 +323,43 @@ extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, con
     const int N = T * NT;
     // encoder + frame-index encoding (associator.py:222-229)
     hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
-    hipLaunchKernelGGL(prepare_kernel, dim3(ND), dim3(256), 0, st, detections, ND, ND, m->div_term, m->featD, m->catD);
+    float* X = m->catTr;                      // [T + 30][512]: fused tracks, then the detection slots
+    float* XD = X + (size_t)T * 512;
+    const int MX = T + ND;
+    hipLaunchKernelGGL(prepare_kernel, dim3(ND), dim3(256), 0, st, detections, ND, ND, m->div_term, m->featD, XD);
     ODAM_HIP(hipGetLastError());
     RC(lin(m->enc0, m->feat, FPAD, N, nullptr, true, m->h256, D, nullptr, st));
     RC(lin(m->enc2, m->h256, D, N, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
     RC(lin(m->enc0, m->featD, FPAD, ND, nullptr, true, m->h256, D, nullptr, st));
-    RC(lin(m->enc2, m->h256, D, ND, m->catD, false, m->catD, 512, nullptr, st));
+    RC(lin(m->enc2, m->h256, D, ND, XD, false, XD, 512, nullptr, st));
     // fuser: self-attention over each track's 100 time steps (associator.py:143-160, 230)
     for (const Prop& P : m->fuser)
         RC(prop_forward(P, m->catT, N, m->catT, N, T, NT, NT, m->q, m->kv, m->att, m->h512, m->catT, m->catT, 512, st));
-    hipLaunchKernelGGL(time_mean_kernel, dim3(T), dim3(256), 0, st, m->catT, NT, m->catTr);
+    hipLaunchKernelGGL(time_mean_kernel, dim3(T), dim3(256), 0, st, m->catT, NT, X);
     ODAM_HIP(hipGetLastError());
-    // matching GNN between the fused tracks [T] and all 30 detection slots (associator.py:111-139, 240)
+    // matching GNN between the fused tracks [T] and all 30 detection slots (associator.py:111-139, 240).  Both sets
+    // go through the same weights, so every projection / MLP runs once on the [T + 30] row block; only the attention
+    // differs per side (self: own set, cross: the other set).  All deltas come from the layer's inputs: the query,
+    // key and value projections are taken before the residual update of either set.
     for (size_t i = 0; i < m->gnn.size(); i++) {
         const Prop& P = m->gnn[i];
         const bool cross = m->gnn_cross[i] != 0;
-        const float* srcT = cross ? m->catD : m->catTr;
-        const int nT = cross ? ND : T;
-        const float* srcD = cross ? m->catTr : m->catD;
-        const int nD = cross ? T : ND;
-        // both deltas come from the layer's inputs: the tracks' delta is parked in dT and added afterwards
-        RC(prop_forward(P, m->catTr, T, srcT, nT, 1, T, nT, m->qT, m->kvT, m->attT, m->hT, nullptr, m->dT, D, st));
-        RC(prop_forward(P, m->catD, ND, srcD, nD, 1, ND, nD, m->qD, m->kvD, m->attD, m->hD, m->catD, m->catD, 512, st));
-        hipLaunchKernelGGL(add_rows_kernel, dim3((T * 64 + 255) / 256), dim3(256), 0, st, m->catTr, 512, m->dT, D, T);
-        ODAM_HIP(hipGetLastError());
+        RC(lin(P.q, X, 512, MX, nullptr, false, m->qX, D, nullptr, st));
+        RC(lin(P.kv, X, 512, MX, nullptr, false, m->kvX, 2 * D, nullptr, st));
+        const float* kvT = cross ? m->kvX + (size_t)T * 2 * D : m->kvX;      // source rows of the track queries
+        const float* kvD = cross ? m->kvX : m->kvX + (size_t)T * 2 * D;      // ... of the detection queries
+        const int nT = cross ? ND : T, nD = cross ? T : ND;
+        RC(odam_dk::launch_attention_d64(m->qX, D, kvT, 2 * D, kvT + D, 2 * D, m->attX, D, 1, 4, T, nT, st));
+        RC(odam_dk::launch_attention_d64(m->qX + (size_t)T * D, D, kvD, 2 * D, kvD + D, 2 * D, m->attX + (size_t)T * D, D, 1, 4,
+                                         ND, nD, st));
+        RC(lin(P.merge, m->attX, D, MX, nullptr, false, X + D, 512, nullptr, st));
+        RC(lin(P.m0, X, 512, MX, nullptr, true, m->hX, 2 * D, nullptr, st));
+        RC(lin(P.m2, m->hX, 2 * D, MX, X, false, X, 512, nullptr, st));
     }
     // descriptors, scores, optimal transport (associator.py:242-254)
-    RC(lin(m->final_proj, m->catTr, 512, T, nullptr, false, m->mT, D, nullptr, st));
-    RC(lin(m->final_proj, m->catD, 512, ND, nullptr, false, m->mD, D, nullptr, st));
-    Lin sc; sc.w = m->mD; sc.b = nullptr; sc.K = D; sc.N = ND;
+    RC(lin(m->final_proj, X, 512, MX, nullptr, false, m->mT, D, nullptr, st));
+    const float* mD = m->mT + (size_t)T * D;
+    Lin sc; sc.w = const_cast<float*>(mD); sc.b = nullptr; sc.K = D; sc.N = ND;
     RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
     const size_t lds = ((size_t)(T + 1) * (n_det + 1) + (T + 1) + (n_det + 1)) * sizeof(float);
     hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out);
