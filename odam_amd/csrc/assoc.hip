@@ -29,7 +29,7 @@ namespace {
 constexpr int D = 256, NF = 79, NT = 100, ND = 30, FPAD = 128;
 
 struct Lin { float* w = nullptr; float* b = nullptr; int K = 0, N = 0; };
-struct Prop { Lin q, kv, merge, m0, m2; };   // AttentionalPropagation (associator.py:85-97)
+struct Prop { Lin qkv, merge, m0, m2; };   // AttentionalPropagation (associator.py:85-97); q, k, v stacked
 
 struct HostT { std::vector<long long> shape; std::vector<float> data; };
 
@@ -149,8 +149,8 @@ struct odam_assoc {
     float bin_score = 1.0f;
     float *div_term = nullptr, *sc16 = nullptr;
     // workspace
-    float *feat = nullptr, *h256 = nullptr, *catT = nullptr, *q = nullptr, *kv = nullptr, *att = nullptr, *h512 = nullptr;
-    float *qX = nullptr, *kvX = nullptr, *attX = nullptr, *hX = nullptr;
+    float *feat = nullptr, *h256 = nullptr, *catT = nullptr, *kv = nullptr, *att = nullptr, *h512 = nullptr;
+    float *kvX = nullptr, *attX = nullptr, *hX = nullptr;
     float *catTr = nullptr, *featD = nullptr, *mT = nullptr, *scores = nullptr;
 
     int alloc(float** p, size_t n) {
@@ -211,16 +211,15 @@ int pack_prop(odam_assoc* m, Prop& P, const std::string& pre) {
     NEEDW(w0, pre + "attn.proj.0.weight"); NEEDW(b0, pre + "attn.proj.0.bias");
     NEEDW(w1, pre + "attn.proj.1.weight"); NEEDW(b1, pre + "attn.proj.1.bias");
     NEEDW(w2, pre + "attn.proj.2.weight"); NEEDW(b2, pre + "attn.proj.2.bias");
-    RC(pack(m, P.q, *w0, b0, D, &hp, nullptr));
-    HostT wkv, bkv;          // key and value projections read the same source: one [512, 256] layer
-    wkv.shape = {2 * D, D};
-    for (const HostT* w : {w1, w2})
+    HostT wqkv, bqkv;        // query, key and value projections of one row block: one [768, 256] layer, rows head-major
+    wqkv.shape = {3 * D, D};
+    for (const HostT* w : {w0, w1, w2})
         for (int r = 0; r < D; r++)
-            wkv.data.insert(wkv.data.end(), w->data.begin() + (size_t)hp[r] * D, w->data.begin() + (size_t)(hp[r] + 1) * D);
-    for (const HostT* b : {b1, b2})
-        for (int r = 0; r < D; r++) bkv.data.push_back(b->data[hp[r]]);
-    bkv.shape = {2 * D};
-    RC(pack(m, P.kv, wkv, &bkv, D, nullptr, nullptr));
+            wqkv.data.insert(wqkv.data.end(), w->data.begin() + (size_t)hp[r] * D, w->data.begin() + (size_t)(hp[r] + 1) * D);
+    for (const HostT* b : {b0, b1, b2})
+        for (int r = 0; r < D; r++) bqkv.data.push_back(b->data[hp[r]]);
+    bqkv.shape = {3 * D};
+    RC(pack(m, P.qkv, wqkv, &bqkv, D, nullptr, nullptr));
     NEEDW(wm, pre + "attn.merge.weight"); NEEDW(bm, pre + "attn.merge.bias");
     RC(pack(m, P.merge, *wm, bm, D, nullptr, &hp));      // its input channels arrive head-major
     NEEDW(m0w, pre + "mlp.0.weight"); NEEDW(m0b, pre + "mlp.0.bias");
@@ -230,15 +229,13 @@ int pack_prop(odam_assoc* m, Prop& P, const std::string& pre) {
     return 0;
 }
 
-// delta = layer(x, source): message into cat_x[:, 256:], hidden in h, delta to `out` (ld_out) with optional residual
-int prop_forward(const Prop& P, float* cat_x, int Mx, const float* cat_s, int Ms, int Bt, int Lq, int Lk, float* qb,
-                 float* kvb, float* attb, float* hb, const float* res, float* out, int ld_out, hipStream_t st) {
-    RC(lin(P.q, cat_x, 512, Mx, nullptr, false, qb, D, nullptr, st));
-    RC(lin(P.kv, cat_s, 512, Ms, nullptr, false, kvb, 2 * D, nullptr, st));
-    RC(odam_dk::launch_attention_d64(qb, D, kvb, 2 * D, kvb + D, 2 * D, attb, D, Bt, 4, Lq, Lk, st));
+// self-attention layer over Bt sequences of L rows (the fuser): message into cat_x[:, 256:], delta added in place
+int prop_forward_self(const Prop& P, float* cat_x, int Mx, int Bt, int L, float* qkvb, float* attb, float* hb, hipStream_t st) {
+    RC(lin(P.qkv, cat_x, 512, Mx, nullptr, false, qkvb, 3 * D, nullptr, st));
+    RC(odam_dk::launch_attention_d64(qkvb, 3 * D, qkvb + D, 3 * D, qkvb + 2 * D, 3 * D, attb, D, Bt, 4, L, L, st));
     RC(lin(P.merge, attb, D, Mx, nullptr, false, cat_x + D, 512, nullptr, st));
     RC(lin(P.m0, cat_x, 512, Mx, nullptr, true, hb, 2 * D, nullptr, st));
-    RC(lin(P.m2, hb, 2 * D, Mx, res, false, out, ld_out, nullptr, st));
+    RC(lin(P.m2, hb, 2 * D, Mx, cat_x, false, cat_x, 512, nullptr, st));
     return 0;
 }
 
@@ -301,11 +298,11 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     }
     const size_t T = m->max_tracks, N = T * NT;
     RC(m->alloc(&m->feat, N * FPAD)); RC(m->alloc(&m->h256, N * D)); RC(m->alloc(&m->catT, N * 512));
-    RC(m->alloc(&m->q, N * D)); RC(m->alloc(&m->kv, N * 512)); RC(m->alloc(&m->att, N * D)); RC(m->alloc(&m->h512, N * 512));
+    RC(m->alloc(&m->kv, N * 768)); RC(m->alloc(&m->att, N * D)); RC(m->alloc(&m->h512, N * 512));
     // fused tracks [T] and the 30 detection slots share one row block (detections start at row T of the frame) so the
     // shared-weight GNN layers see both sets as ONE matrix
     RC(m->alloc(&m->catTr, (T + ND) * 512)); RC(m->alloc(&m->featD, ND * FPAD));
-    RC(m->alloc(&m->qX, (T + ND) * D)); RC(m->alloc(&m->kvX, (T + ND) * 512)); RC(m->alloc(&m->attX, (T + ND) * D));
+    RC(m->alloc(&m->kvX, (T + ND) * 768)); RC(m->alloc(&m->attX, (T + ND) * D));
     RC(m->alloc(&m->hX, (T + ND) * 512));
     RC(m->alloc(&m->mT, (T + ND) * D)); RC(m->alloc(&m->scores, T * 32));
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
@@ -334,7 +331,7 @@ extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, con
     RC(lin(m->enc2, m->h256, D, ND, XD, false, XD, 512, nullptr, st));
     // fuser: self-attention over each track's 100 time steps (associator.py:143-160, 230)
     for (const Prop& P : m->fuser)
-        RC(prop_forward(P, m->catT, N, m->catT, N, T, NT, NT, m->q, m->kv, m->att, m->h512, m->catT, m->catT, 512, st));
+        RC(prop_forward_self(P, m->catT, N, T, NT, m->kv, m->att, m->h512, st));
     hipLaunchKernelGGL(time_mean_kernel, dim3(T), dim3(256), 0, st, m->catT, NT, X);
     ODAM_HIP(hipGetLastError());
     // matching GNN between the fused tracks [T] and all 30 detection slots (associator.py:111-139, 240).  Both sets
@@ -344,14 +341,13 @@ extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, con
     for (size_t i = 0; i < m->gnn.size(); i++) {
         const Prop& P = m->gnn[i];
         const bool cross = m->gnn_cross[i] != 0;
-        RC(lin(P.q, X, 512, MX, nullptr, false, m->qX, D, nullptr, st));
-        RC(lin(P.kv, X, 512, MX, nullptr, false, m->kvX, 2 * D, nullptr, st));
-        const float* kvT = cross ? m->kvX + (size_t)T * 2 * D : m->kvX;      // source rows of the track queries
-        const float* kvD = cross ? m->kvX : m->kvX + (size_t)T * 2 * D;      // ... of the detection queries
+        RC(lin(P.qkv, X, 512, MX, nullptr, false, m->kvX, 3 * D, nullptr, st));     // rows: q | k | v
+        const float* srcT = cross ? m->kvX + (size_t)T * 3 * D : m->kvX;     // source rows of the track queries
+        const float* srcD = cross ? m->kvX : m->kvX + (size_t)T * 3 * D;     // ... of the detection queries
         const int nT = cross ? ND : T, nD = cross ? T : ND;
-        RC(odam_dk::launch_attention_d64(m->qX, D, kvT, 2 * D, kvT + D, 2 * D, m->attX, D, 1, 4, T, nT, st));
-        RC(odam_dk::launch_attention_d64(m->qX + (size_t)T * D, D, kvD, 2 * D, kvD + D, 2 * D, m->attX + (size_t)T * D, D, 1, 4,
-                                         ND, nD, st));
+        RC(odam_dk::launch_attention_d64(m->kvX, 3 * D, srcT + D, 3 * D, srcT + 2 * D, 3 * D, m->attX, D, 1, 4, T, nT, st));
+        RC(odam_dk::launch_attention_d64(m->kvX + (size_t)T * 3 * D, 3 * D, srcD + D, 3 * D, srcD + 2 * D, 3 * D,
+                                         m->attX + (size_t)T * D, D, 1, 4, ND, nD, st));
         RC(lin(P.merge, m->attX, D, MX, nullptr, false, X + D, 512, nullptr, st));
         RC(lin(P.m0, X, 512, MX, nullptr, true, m->hX, 2 * D, nullptr, st));
         RC(lin(P.m2, m->hX, 2 * D, MX, X, false, X, 512, nullptr, st));
