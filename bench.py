@@ -3,8 +3,9 @@
 scene, BASELINE.json configs[1] (1 GPU) / configs[2] (frames sharded over N GPUs + all-gather).
 
 One "step" = one pass of the hot path over one scene:
-  detect all frames of this rank's shard (inputs resident in HBM as normalised [3,800,1066] fp32 tensors,
-  forward in batches, per-query post-processing on device, threshold + NMS + row packing on the host)
+  detect all frames of this rank's shard (inputs resident in HBM as decoded uint8 [480,640,3] frames; the
+  reference transform -- PIL-bilinear resize to 800x1066, /255, normalise -- runs on the device, then the forward in
+  batches of 32 on two HIP streams, per-query post-processing on device, threshold + NMS + row packing on the host)
   -> all-gather of detections (N > 1) -> super-quadric fit of this rank's objects, twice (run_processor.py:81-83
   runs optim -> merge -> optim; the merge itself is outside the hot path) -> all-gather of fitted parameters.
 value = frames of the WHOLE scene x steps / wall time (max over ranks).  Strong scaling: the scene is fixed.
