@@ -14,7 +14,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // padded by one chunk (144-byte rows: 16-byte aligned, conflict-free for ds_read_b128).
 constexpr int LDS_STRIDE = 36;  // floats per LDS row
 #ifndef CG_ABLATE
-#define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier
+#define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores
 #endif
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
@@ -93,11 +93,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     bool a_ok[A_LD];
     const int hw = a.Ho * a.Wo;
     const int lda = a.lda > 0 ? a.lda : a.Cin;   // elements between consecutive input pixels
+    const bool plain = a.KH * a.KW == 1 && a.stride == 1 && a.pad == 0;
 #pragma unroll
     for (int i = 0; i < A_LD; i++) {
         const int m = m0 + r0 + RPP * i;
         a_ok[i] = m < a.M;
         const int mm = a_ok[i] ? m : 0;
+        if (plain) {   // 1x1, stride 1, no padding (a Linear layer, half of the detector's convolutions): pixel = row
+            a_iy0[i] = 0; a_ix0[i] = 0;
+            a_base[i] = mm * lda;
+            continue;
+        }
         const int b = mm / hw;
         const int rem = mm - b * hw;
         const int oy = rem / a.Wo;
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 #pragma unroll
         for (int i = 0; i < A_LD; i++) {
             a_voff[i] = (unsigned)(a_base[i] - b0 * a.H * a.W * lda + margin + csrc * EPC) * (unsigned)sizeof(T);
-            unsigned mk = 0;
-            for (int t = 0; t < ntaps; t++) {
+            unsigned mk = plain ? 1u : 0u;
+            for (int t = 0; t < (plain ? 0 : ntaps); t++) {
                 const int ky = (t * kw_inv) >> 16, kx = t - ky * a.KW;
                 if ((unsigned)(a_iy0[i] + ky) < (unsigned)a.H && (unsigned)(a_ix0[i] + kx) < (unsigned)a.W) mk |= 1u << t;
             }
@@ -357,13 +363,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
                     }
                 }
             }
-            if (i > 0) __syncthreads();          // previous slab fully read before it is overwritten
+            // The slab is private to this wavefront and a wavefront's LDS operations execute in order, so the
+            // transposition needs no workgroup barrier (the K loop ended with one): waves store as soon as they are done.
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int j = 0; j < TN; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int row = it * RPI + lane / LPR;
@@ -376,7 +386,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
                     o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
                     o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
                 }
-                if (n_ok && m < a.M) {
+                if (n_ok && m < a.M && (!(CG_ABLATE & 8) || o.x == 12345.678f)) {   // 8: (almost) never store
                     const size_t idx = (size_t)m * a.ldc + n;
                     if (out_f32) {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + idx) = o;
