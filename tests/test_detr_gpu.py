@@ -215,6 +215,24 @@ def test_resnet101_configuration_vs_oracle():
     det.close()
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 65, 97), (3, 32, 33), (1, 131, 77)])
+def test_odd_input_sizes_vs_oracle(B, H, W):
+    """sizes that leave ragged tiles everywhere (odd extents through every stride-2 stage, the 32-pixel minimum)"""
+    import detr_oracle as O
+    from odam_amd import detector, weights
+    sd = weights.make_state_dict(seed=3)
+    det = detector.Detector(max_batch=B, device=DEV, n_streams=1)
+    det.load_state_dict(sd)
+    torch.manual_seed(H * 7 + W)
+    img = torch.randn(B, 3, H, W)
+    ref = O.detr_forward(sd, img)
+    got = det(img.to(DEV))
+    for k in KEYS:
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= 2e-4 * max(1.0, ref[k].abs().max().item()), k
+    assert torch.equal(got["pred_logits"].cpu().argmax(-1), ref["pred_logits"].argmax(-1))
+    det.close()
+
+
 def test_missing_weight_is_an_error():
     from odam_amd import detector, weights, _lib
     sd = weights.make_state_dict(seed=0)
