@@ -80,6 +80,7 @@ struct FitArgs {
     float* xgrad;                     // [n_iters][n_obj][max_views][9]
     float* xloss;                     // [n_iters][n_obj][max_views][4] (only with loss_log)
     unsigned* done;                   // [n_obj][split]: steps published by each workgroup, zeroed before launch
+    int force_lanes_per_view;         // 0 = choose (experiments: ODAM_SQ_S)
     unsigned split_wait_ticks;        // bounded wait for a partner's rows, 100 MHz wall clock (30 us: > one slice of phase E)
 };
 
@@ -214,15 +215,22 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
     int Pn = 1;
     while (Pn < F) Pn <<= 1;
     const float invF = 1.0f / (float)F;
-    // lanes per view in phase E: the power of two that minimises rounds x (points per lane + per-round overhead)
+    // Lanes per view in phase E (a power of two; any choice gives the same bits).  Measured on one workgroup
+    // (tests/native/sweep_sq_s.py, 10..1024 views x S = 1..64): a round in which all 16 waves are busy takes
+    // t = 16 + P "units" for P = ceil(1000 / S) points per lane; a first round with only w waves busy takes
+    // (0.45 + 0.55 w/16) t (fewer waves per SIMD run faster, but far from proportionally), and a trailing partial
+    // round of w waves adds only (w/16) t because nothing separates the rounds.  The model is within 5 % of the
+    // measured step time at every point of the sweep and picks the measured optimum.
     int S = 1;
     {
-        int best_cost = 0x7fffffff;
+        float best_cost = 3.0e38f;
         for (int c = 1; c <= 64; c <<= 1) {
-            const int rounds = (fs * c + NT - 1) / NT;
-            const int cost = rounds * ((N_PTS + c - 1) / c + 24);
+            const int lanes = fs * c, full = lanes / NT, w = (lanes - full * NT + 63) / 64;
+            const float t = 16.0f + (float)((N_PTS + c - 1) / c);
+            const float cost = t * ((float)full + (full == 0 ? 0.45f + 0.55f * (float)w / 16.0f : (float)w / 16.0f));
             if (cost < best_cost) { best_cost = cost; S = c; }
         }
+        if (A.force_lanes_per_view > 0) S = A.force_lanes_per_view;
     }
 
 #ifdef SQ_STAMPS   // timing experiments: accumulated 100 MHz ticks per phase, written over out_points of object 0
@@ -503,6 +511,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         {
             const int lo = wj * fs < F ? wj * fs : F, hi = lo + fs < F ? lo + fs : F;
             views(lo, hi);
+            STAMP(7);
             if (keff > 1) {
                 // Publish my rows of this step and collect the other slices, one wavefront per partner: wavefront wj
                 // stores the rows and raises the flag (release), wavefront jj != wj waits for partner jj's flag
@@ -536,7 +545,15 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                     ready = __shfl(ready, 0);
                     if (ready) {
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        for (int idx = plo * 9 + lane; idx < phi * 9; idx += 64) L.vgrad[idx] = xg[idx];
+                        // twelve loads in flight per lane: a slice of up to 85 views arrives in one memory round trip
+                        for (int base = plo * 9 + lane; base < phi * 9; base += 64 * 12) {
+                            float tmp[12];
+#pragma unroll
+                            for (int q = 0; q < 12; q++) tmp[q] = (base + 64 * q < phi * 9) ? xg[base + 64 * q] : 0.0f;
+#pragma unroll
+                            for (int q = 0; q < 12; q++)
+                                if (base + 64 * q < phi * 9) L.vgrad[base + 64 * q] = tmp[q];
+                        }
                         if (want_loss)
                             for (int idx = plo * 4 + lane; idx < phi * 4; idx += 64) L.lterm[idx] = xl[idx];
                     }
@@ -685,6 +702,8 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     // the objects are large enough to gain, and the exchange history fits a modest buffer.
     static const int split_env = getenv("ODAM_SQ_SPLIT") ? atoi(getenv("ODAM_SQ_SPLIT")) : 4;
     static const int wait_env = getenv("ODAM_SQ_SPLIT_WAIT") ? atoi(getenv("ODAM_SQ_SPLIT_WAIT")) : 3000;   // 0: never wait (tests)
+    static const int s_env = getenv("ODAM_SQ_S") ? atoi(getenv("ODAM_SQ_S")) : 0;
+    A.force_lanes_per_view = s_env;
     A.n_obj = n_obj; A.split = 1; A.split_min_views = 64; A.max_views = max_views; A.split_wait_ticks = (unsigned)wait_env;
     int grid = n_obj;
     const int n_pad = (n_obj + 7) / 8 * 8;
