@@ -362,14 +362,29 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         }
         __syncthreads();
 #ifndef SQ_ABLATE_SCAN
-        if (tid == 0) {  // sampling.cpp:141-146: strictly ordered float32 running sum
-            float c = 0.001f;
-            L.cdf[0] = c;
-            for (int i = 1; i < BUF; i++) {
-                c = c + 0.001f + L.term[i];
-                L.cdf[i] = c;
+        if (wid == 0) {  // sampling.cpp:141-146: strictly ordered float32 running sum
+            // The chain of 2 x 200 dependent additions is what it is; what can go is the LDS round trip per element:
+            // the terms sit in registers (lane l holds entries l, l + 64, ...), every step broadcasts one of them
+            // with v_readlane, all 64 lanes carry the running sum and lane (i & 63) keeps entry i of the CDF.
+            float t[4], cd[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = lane + 64 * j;
+                t[j] = (i >= 1 && i < BUF) ? L.term[i] : 0.0f;
+                cd[j] = 0.0f;
             }
-            L.misc[0] = c;
+            float c = 0.001f;
+            if (lane == 0) cd[0] = c;
+#pragma unroll
+            for (int i = 1; i < BUF; i++) {
+                const float ti = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, t[i >> 6]), i & 63));
+                c = c + 0.001f + ti;
+                if (lane == (i & 63)) cd[i >> 6] = c;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (lane + 64 * j < BUF) L.cdf[lane + 64 * j] = cd[j];
+            if (lane == 0) L.misc[0] = c;
         }
 #endif
         __syncthreads();
