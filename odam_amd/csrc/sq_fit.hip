@@ -263,13 +263,15 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         //   B1  all 2 x 513 dyadic thetas and their curve points (the trig/pow work) in ONE parallel pass,
         //   B2  the breadth-first slot allocation then needs two distances, a division and a round per node;
         //       nodes deeper than the table (rare, strongly unbalanced curves) evaluate their point on the fly.
-        for (int w = tid; w < 2 * TABN; w += NT) {
-            const int c = w / TABN, q = w - c * TABN;
+        // 2 x 512 entries in one pass of the 1024 threads; the far end point of each curve (theta = -ta) is the mirror
+        // image of the near one -- cosf_ is even, sinf_ and fexp are odd, exactly -- so thread q = 0 writes both.
+        static_assert(TABN == 513 && NT >= 64, "table pass layout");
+        for (int w = tid; w < 2 * (TABN - 1); w += NT) {
+            const int c = w / (TABN - 1), q = w - c * (TABN - 1);
             const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
             const float ta = c ? PI_F : PI_F / 2;
             float lo = ta, hi = -ta, th;
             if (q == 0) th = lo;
-            else if (q == TABN - 1) th = hi;
             else {
                 int lq = 0, hq = TABN - 1;
                 for (;;) {
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             }
             float cx, cy;
             xy(th, a1, a2, e, cx, cy);
-            L.tth[w] = th; L.tcx[w] = cx; L.tcy[w] = cy;
+            const int t = c * TABN + q;
+            L.tth[t] = th; L.tcx[t] = cx; L.tcy[t] = cy;
+            if (q == 0) { L.tth[t + TABN - 1] = -ta; L.tcx[t + TABN - 1] = cx; L.tcy[t + TABN - 1] = -cy; }
         }
         if (tid < 6) L.cnt[tid] = (tid < 2) ? 1 : 0;
         if (tid < 2) {   // roots: the whole parameter range, 199 interior slots starting at 1
