@@ -101,3 +101,45 @@ def test_run_detector_rows_match_reference(sd, golden):
     assert np.array_equal(rows[:, :2], ref[:, :2])                       # frame id, class label: exact
     assert np.allclose(rows, ref, rtol=1e-4, atol=1e-5)
     assert np.all(rows[:, 15:] == -1)
+
+
+def test_select_nms_random_clusters_vs_oracle():
+    """C++ threshold + greedy NMS (odam_detr_select) against the oracle's python nms_3d on 300 random frames of
+    clustered, heavily overlapping detections (near-threshold scores, identical boxes with different scores, same /
+    different classes): identical keep lists in identical order.  Exactly tied scores are left out: the reference
+    orders them by numpy's unstable argsort."""
+    from odam_amd.detector import Detector
+    rs = np.random.RandomState(7)
+    n_kept = 0
+    for trial in range(300):
+        Q = int(rs.choice([1, 5, 30, 100]))
+        n_clu = int(rs.randint(1, 6))
+        centres = rs.uniform(-2, 2, (n_clu, 3)).astype(np.float32) + np.array([0, 0, 3], np.float32)
+        rows = np.zeros((Q, 16), np.float32)
+        which = rs.randint(0, n_clu, Q)
+        rows[:, 0] = rs.uniform(0.3, 1.0, Q).astype(np.float32)
+        rows[rs.rand(Q) < 0.2, 0] = np.float32(0.6) - np.float32(2e-5)                # straddles the threshold once the ramp is added
+        rows[:, 0] += np.arange(Q, dtype=np.float32) * np.float32(1e-6)              # no exact ties
+        rows[:, 1] = rs.randint(0, 3, Q)
+        jit = rs.choice([0.0, 0.02, 0.3], Q)[:, None].astype(np.float32)
+        t = centres[which] + rs.normal(0, 1, (Q, 3)).astype(np.float32) * jit
+        dims = np.abs(rs.normal(0.8, 0.3, (Q, 3))).astype(np.float32) + np.float32(0.05)
+        dims[rs.rand(Q) < 0.3] = np.float32(0.7)                                     # identical sizes
+        cx, cy = 320 + 100 * t[:, 0], 240 + 100 * t[:, 1]
+        hw = 40 + 30 * rs.rand(Q, 2)
+        rows[:, 2], rows[:, 3], rows[:, 4], rows[:, 5] = cx - hw[:, 0], cy - hw[:, 1], cx + hw[:, 0], cy + hw[:, 1]
+        rows[:, 6:9] = t
+        rows[:, 9] = rs.randint(0, 30, Q)
+        rows[:, 10:13] = dims
+        for nms_2d in (True, False):
+            got = Detector.select(rows, 0.6, nms_2d, 30)
+            keep = rows[:, 0] > np.float32(0.6)
+            idx = np.flatnonzero(keep)
+            k = O.nms_3d(rows[idx, 1].astype(np.int64), rows[idx, 0], rows[idx, 6:9], rows[idx, 10:13],
+                         rows[idx, 2:6].reshape(-1, 2, 2), nms_2d=nms_2d)
+            want = idx[np.asarray(k, np.int64)] if len(k) else np.zeros(0, np.int64)
+            assert np.array_equal(got["scores"], rows[want, 0]), (trial, nms_2d)
+            assert np.array_equal(got["classes"], rows[want, 1].astype(np.int64)), (trial, nms_2d)
+            assert np.array_equal(got["translates"], rows[want, 6:9]), (trial, nms_2d)
+            n_kept += len(want)
+    assert n_kept > 1000
