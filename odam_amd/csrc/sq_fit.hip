@@ -77,7 +77,7 @@ struct FitArgs {
     int split;                        // workgroups per object (1 = off)
     int split_min_views;              // objects with fewer views stay on one workgroup
     int max_views;                    // row pitch of the exchange buffers
-    float* xgrad;                     // [n_iters][n_obj][max_views][9]
+    float* xgrad;                     // [n_iters][n_obj][split][9] sub-tree roots
     float* xloss;                     // [n_iters][n_obj][max_views][4] (only with loss_log)
     unsigned* done;                   // [n_obj][split]: steps published by each workgroup, zeroed before launch
     int force_lanes_per_view;         // 0 = choose (experiments: ODAM_SQ_S)
@@ -94,6 +94,7 @@ struct Lds {
     float* misc;    // [8]   cdf sum, dirsum[4]
     int* cnt;       // [8]   3 x 2 level counters
     int* xready;    // [16]  view split: partner rows arrived this step
+    float* xroot;   // [8][9] sub-tree roots of the residue classes
     float* pwx;     // [1024] x3
     float* pwy;
     float* pwz;
@@ -112,7 +113,7 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_words(int pn) {
-    return 12 * 6 + 8 + 8 + 16 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
+    return 12 * 6 + 8 + 8 + 16 + 72 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
            (size_t)pn * 9 + (size_t)pn * 4;
 }
 
@@ -128,6 +129,7 @@ __device__ inline Lds carve(float* base, int pn) {
     L.misc = w; w += 8;
     L.cnt = (int*)w; w += 8;
     L.xready = (int*)w; w += 16;
+    L.xroot = w; w += 72;
     L.pwx = w; w += 1024;
     L.pwy = w; w += 1024;
     L.pwz = w; w += 1024;
@@ -430,11 +432,13 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         // each walks every S-th surface point keeping its four running extremes (value, first index), an
         // S-lane xor butterfly merges them, then the closed-form gradient of the view's four edges runs on
         // those same lanes and is added in the order (d0 + d1) + (d2 + d3).
-        auto views = [&](int f_lo, int f_hi) {
-        for (int v0 = f_lo; v0 < f_hi; v0 += NT / S) {
-            const int f = v0 + tid / S;
+        // views f = res, res + keff, res + 2 keff, ... (cnt of them); row m of L.vgrad receives view res + keff * m
+        auto views = [&](int res, int cnt) {
+        for (int v0 = 0; v0 < cnt; v0 += NT / S) {
+            const int mrow = v0 + tid / S;
+            const int f = res + keff * mrow;
             const int sub = tid & (S - 1);
-            const bool vf = f < f_hi;
+            const bool vf = mrow < cnt;
             float Mv[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) Mv[k] = vf ? Pm[(size_t)12 * f + k] : 0.0f;
@@ -523,75 +527,85 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             }
             if (vf && sub == 0) {
 #pragma unroll
-                for (int k = 0; k < 9; k++) L.vgrad[f * 9 + k] = g9[k];
+                for (int k = 0; k < 9; k++) L.vgrad[mrow * 9 + k] = g9[k];
             }
         }
         };
-        {
-            const int lo = wj * fs < F ? wj * fs : F, hi = lo + fs < F ? lo + fs : F;
-            views(lo, hi);
-            STAMP(7);
-            if (keff > 1) {
-                // Publish my rows of this step and collect the other slices, one wavefront per partner: wavefront wj
-                // stores the rows and raises the flag (release), wavefront jj != wj waits for partner jj's flag
-                // (acquire, bounded) and copies its rows into LDS.  Slices that did not arrive are computed here.
+        // The reference sums the per-view rows with a stride-halving tree over the view index (padded to Pn).  After
+        // its levels with stride >= keff, position j holds exactly the views f = j (mod keff), combined by the same
+        // stride-halving tree over THAT subsequence -- so the workgroup that owns residue class j can finish its
+        // sub-tree alone and only the keff sub-tree roots (9 floats each) travel; the last log2(keff) levels are
+        // repeated by everyone.  Bit-identical to the single-workgroup tree for every keff.
+        const int Pk = Pn / keff;
+        auto slice_root = [&](int res) {      // rows + sub-tree of one residue class -> L.xroot[res]
+            const int cnt = res < F ? (F - res + keff - 1) / keff : 0;
+            views(res, cnt);
+            for (int idx = cnt * 9 + tid; idx < Pk * 9; idx += NT) L.vgrad[idx] = 0.0f;
+            __syncthreads();
+            for (int stride = Pk >> 1; stride >= 1; stride >>= 1) {
+                for (int idx = tid; idx < stride * 9; idx += NT) L.vgrad[idx] += L.vgrad[idx + stride * 9];
                 __syncthreads();
-                const size_t row0 = ((size_t)it * A.n_obj + obj) * A.max_views;
-                float* xg = A.xgrad + row0 * 9;
-                float* xl = want_loss ? A.xloss + row0 * 4 : nullptr;
-                if (wid == wj) {
-                    for (int idx = lo * 9 + lane; idx < hi * 9; idx += 64) xg[idx] = L.vgrad[idx];
-                    if (want_loss)
-                        for (int idx = lo * 4 + lane; idx < hi * 4; idx += 64) xl[idx] = L.lterm[idx];
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                    if (lane == 0)
-                        __hip_atomic_store(&A.done[obj * A.split + wj], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                } else if (wid < keff) {
-                    const int jj = wid;
-                    const int plo = jj * fs < F ? jj * fs : F, phi = plo + fs < F ? plo + fs : F;
-                    const unsigned* flag = &A.done[obj * A.split + jj];
-                    int ready = 0;
-                    if (lane == 0) {
-                        ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
-                        if (!ready && !((absent >> jj) & 1)) {
-                            const unsigned long long t0 = wall_clock64();   // 100 MHz
-                            while (!ready && wall_clock64() - t0 < A.split_wait_ticks) {
-                                __builtin_amdgcn_s_sleep(4);
-                                ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
-                            }
+            }
+            if (tid < 9) L.xroot[res * 9 + tid] = L.vgrad[tid];
+            __syncthreads();
+        };
+        slice_root(wj);
+        STAMP(7);
+        if (keff > 1) {
+            // Publish my root (and, for the loss log, my views' loss terms) and collect the others, one wavefront per
+            // partner: wavefront wj stores and raises the flag (release), wavefront jj != wj waits for partner jj's
+            // flag (acquire, bounded).  Roots that did not arrive are computed here.
+            const size_t slot = (size_t)it * A.n_obj + obj;
+            float* xg = A.xgrad + slot * (size_t)(A.split * 9);
+            float* xl = want_loss ? A.xloss + slot * (size_t)A.max_views * 4 : nullptr;
+            if (wid == wj) {
+                if (lane < 9) xg[wj * 9 + lane] = L.xroot[wj * 9 + lane];
+                if (want_loss)
+                    for (int m = lane; m * keff + wj < F; m += 64) {
+                        const int f = m * keff + wj;
+#pragma unroll
+                        for (int d = 0; d < 4; d++) xl[f * 4 + d] = L.lterm[f * 4 + d];
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0)
+                    __hip_atomic_store(&A.done[obj * A.split + wj], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (wid < keff) {
+                const int jj = wid;
+                const unsigned* flag = &A.done[obj * A.split + jj];
+                int ready = 0;
+                if (lane == 0) {
+                    ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
+                    if (!ready && !((absent >> jj) & 1)) {
+                        const unsigned long long t0 = wall_clock64();   // 100 MHz
+                        while (!ready && wall_clock64() - t0 < A.split_wait_ticks) {
+                            __builtin_amdgcn_s_sleep(2);
+                            ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
                         }
                     }
-                    ready = __shfl(ready, 0);
-                    if (ready) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                        // twelve loads in flight per lane: a slice of up to 85 views arrives in one memory round trip
-                        for (int base = plo * 9 + lane; base < phi * 9; base += 64 * 12) {
-                            float tmp[12];
+                }
+                ready = __shfl(ready, 0);
+                if (ready) {
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    if (lane < 9) L.xroot[jj * 9 + lane] = xg[jj * 9 + lane];
+                    if (want_loss && lead)
+                        for (int m = lane; m * keff + jj < F; m += 64) {
+                            const int f = m * keff + jj;
 #pragma unroll
-                            for (int q = 0; q < 12; q++) tmp[q] = (base + 64 * q < phi * 9) ? xg[base + 64 * q] : 0.0f;
-#pragma unroll
-                            for (int q = 0; q < 12; q++)
-                                if (base + 64 * q < phi * 9) L.vgrad[base + 64 * q] = tmp[q];
+                            for (int d = 0; d < 4; d++) L.lterm[f * 4 + d] = xl[f * 4 + d];
                         }
-                        if (want_loss)
-                            for (int idx = plo * 4 + lane; idx < phi * 4; idx += 64) L.lterm[idx] = xl[idx];
-                    }
-                    if (lane == 0) L.xready[jj] = ready;
                 }
-                __syncthreads();
-                for (int jj = 0; jj < keff; jj++) {
-                    if (jj == wj || L.xready[jj]) continue;      // uniform: read from LDS after the barrier
-                    absent |= 1 << jj;                           // no more waiting for this partner
-                    const int plo = jj * fs < F ? jj * fs : F, phi = plo + fs < F ? plo + fs : F;
-                    views(plo, phi);
-                }
+                if (lane == 0) L.xready[jj] = ready;
+            }
+            __syncthreads();
+            for (int jj = 0; jj < keff; jj++) {
+                if (jj == wj || L.xready[jj]) continue;      // uniform: read from LDS after the barrier
+                absent |= 1 << jj;                           // no more waiting for this partner
+                slice_root(jj);
             }
         }
-        for (int idx = tid; idx < (Pn - F) * 9; idx += NT) L.vgrad[F * 9 + idx] = 0.0f;
-        __syncthreads();
 
         STAMP(5);
-        // ---------------- F: tree over views, prior, Adam ---------------------------------------
+        // ---------------- F: last tree levels, prior, Adam ---------------------------------------
         if (want_loss) {
             if (tid >= 64 && tid < 68) {
                 const int dd = tid - 64;
@@ -599,13 +613,14 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                 for (int f = 0; f < F; f++) s += L.lterm[f * 4 + dd];
                 L.misc[1 + dd] = s;
             }
-        }
-        for (int stride = Pn >> 1; stride >= 1; stride >>= 1) {
-            for (int idx = tid; idx < stride * 9; idx += NT) L.vgrad[idx] += L.vgrad[idx + stride * 9];
-            __syncthreads();
+            __syncthreads();   // the sums are read by thread 0 below
         }
         if (tid < 9) {
-            float g = (F > 0) ? L.vgrad[tid] : 0.0f;
+            for (int stride = keff >> 1; stride >= 1; stride >>= 1)       // 9 lanes of one wavefront: in order
+                for (int i = 0; i < stride; i++) L.xroot[i * 9 + tid] += L.xroot[(i + stride) * 9 + tid];
+        }
+        if (tid < 9) {
+            float g = (F > 0) ? L.xroot[tid] : 0.0f;
             if (use_prior && tid >= 4 && tid < 7) {
                 float gs[3];
                 prior_term(L.icov, L.s0, p, gs);
@@ -729,8 +744,9 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     int k = split_env < 1 ? 1 : (split_env > 8 ? 8 : split_env);   // measured: 4 is best from 1 to 60 objects
     while (k > 1 && n_pad * k > ctx->n_cu) k >>= 1;
     if (k > 1 && A.n_iters > 0 && max_views >= A.split_min_views) {
-        const size_t rows = (size_t)A.n_iters * n_obj * max_views;
-        const size_t need = rows * (A.loss_log ? 13 : 9) * sizeof(float);
+        const size_t roots = (size_t)A.n_iters * n_obj * k * 9;                 // one 9-float root per workgroup and step
+        const size_t rows = A.loss_log ? (size_t)A.n_iters * n_obj * max_views * 4 : 0;   // loss terms, only when logged
+        const size_t need = (roots + rows) * sizeof(float);
         if (need <= ((size_t)1 << 30)) {
             if (need > ctx->xch_bytes) {
                 if (ctx->d_xch) { ODAM_HIP(hipStreamSynchronize(stream)); (void)hipFree(ctx->d_xch); ctx->d_xch = nullptr; ctx->xch_bytes = 0; }
@@ -745,7 +761,7 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
             ODAM_HIP(hipMemsetAsync(ctx->d_done, 0, sizeof(unsigned) * n_obj * k, stream));
             A.split = k;
             A.xgrad = ctx->d_xch;
-            A.xloss = A.loss_log ? ctx->d_xch + rows * 9 : nullptr;
+            A.xloss = A.loss_log ? ctx->d_xch + roots : nullptr;
             A.done = ctx->d_done;
             grid = n_pad * k;
         }
