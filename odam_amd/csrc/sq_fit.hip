@@ -77,7 +77,7 @@ struct FitArgs {
     int split;                        // workgroups per object (1 = off)
     int split_min_views;              // objects with fewer views stay on one workgroup
     int max_views;                    // row pitch of the exchange buffers
-    float* xgrad;                     // [n_iters][n_obj][split][9] sub-tree roots
+    unsigned long long* xroots;       // [n_iters][n_obj][split][9] sub-tree roots as {step + 1, float bits}, zeroed before launch
     float* xloss;                     // [n_iters][n_obj][max_views][4] (only with loss_log)
     unsigned* done;                   // [n_obj][split]: steps published by each workgroup, zeroed before launch
     int force_lanes_per_view;         // 0 = choose (experiments: ODAM_SQ_S)
@@ -94,7 +94,7 @@ struct Lds {
     float* misc;    // [8]   cdf sum, dirsum[4]
     int* cnt;       // [8]   3 x 2 level counters
     int* xready;    // [16]  view split: partner rows arrived this step
-    float* xroot;   // [8][9] sub-tree roots of the residue classes
+    float* xroot;   // [16][9] sub-tree roots of the residue classes
     float* pwx;     // [1024] x3
     float* pwy;
     float* pwz;
@@ -113,7 +113,7 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_words(int pn) {
-    return 12 * 6 + 8 + 8 + 16 + 72 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
+    return 12 * 6 + 8 + 8 + 16 + 144 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
            (size_t)pn * 9 + (size_t)pn * 4;
 }
 
@@ -129,7 +129,7 @@ __device__ inline Lds carve(float* base, int pn) {
     L.misc = w; w += 8;
     L.cnt = (int*)w; w += 8;
     L.xready = (int*)w; w += 16;
-    L.xroot = w; w += 72;
+    L.xroot = w; w += 144;
     L.pwx = w; w += 1024;
     L.pwy = w; w += 1024;
     L.pwz = w; w += 1024;
@@ -555,45 +555,68 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             // Publish my root (and, for the loss log, my views' loss terms) and collect the others, one wavefront per
             // partner: wavefront wj stores and raises the flag (release), wavefront jj != wj waits for partner jj's
             // flag (acquire, bounded).  Roots that did not arrive are computed here.
+            // A root travels as nine 64-bit words {step + 1, float bits}, each written and polled with one relaxed
+            // device-scope atomic: the tag arrives with the payload, so there is no separate flag, no cache write-back
+            // on the writer's side and no invalidate on the reader's (the buffer is zeroed before the launch and every
+            // step has its own slot).  The loss terms (only when the loss is logged) use a fenced flag.
             const size_t slot = (size_t)it * A.n_obj + obj;
-            float* xg = A.xgrad + slot * (size_t)(A.split * 9);
+            unsigned long long* xq = A.xroots + slot * (size_t)(A.split * 9);
             float* xl = want_loss ? A.xloss + slot * (size_t)A.max_views * 4 : nullptr;
+            const unsigned long long tag = (unsigned long long)(it + 1) << 32;
             if (wid == wj) {
-                if (lane < 9) xg[wj * 9 + lane] = L.xroot[wj * 9 + lane];
-                if (want_loss)
+                if (lane < 9)
+                    __hip_atomic_store(&xq[wj * 9 + lane], tag | (unsigned long long)__float_as_uint(L.xroot[wj * 9 + lane]),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (want_loss) {
                     for (int m = lane; m * keff + wj < F; m += 64) {
                         const int f = m * keff + wj;
 #pragma unroll
                         for (int d = 0; d < 4; d++) xl[f * 4 + d] = L.lterm[f * 4 + d];
                     }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                if (lane == 0)
-                    __hip_atomic_store(&A.done[obj * A.split + wj], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    if (lane == 0)
+                        __hip_atomic_store(&A.done[obj * A.split + wj], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
             } else if (wid < keff) {
                 const int jj = wid;
-                const unsigned* flag = &A.done[obj * A.split + jj];
-                int ready = 0;
-                if (lane == 0) {
-                    ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
-                    if (!ready && !((absent >> jj) & 1)) {
-                        const unsigned long long t0 = wall_clock64();   // 100 MHz
-                        while (!ready && wall_clock64() - t0 < A.split_wait_ticks) {
-                            __builtin_amdgcn_s_sleep(2);
-                            ready = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
+                unsigned long long v = 0;
+                bool ok = lane >= 9;
+                if (!ok) {
+                    v = __hip_atomic_load(&xq[jj * 9 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (v >> 32) == (unsigned long long)(it + 1);
+                }
+                int ready = __all(ok);
+                if (!ready && !((absent >> jj) & 1)) {
+                    const unsigned long long t0 = wall_clock64();   // 100 MHz
+                    while (!ready && wall_clock64() - t0 < A.split_wait_ticks) {
+                        __builtin_amdgcn_s_sleep(1);
+                        if (lane < 9 && !ok) {
+                            v = __hip_atomic_load(&xq[jj * 9 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            ok = (v >> 32) == (unsigned long long)(it + 1);
                         }
+                        ready = __all(ok);
                     }
                 }
-                ready = __shfl(ready, 0);
-                if (ready) {
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    if (lane < 9) L.xroot[jj * 9 + lane] = xg[jj * 9 + lane];
-                    if (want_loss && lead)
+                if (ready && want_loss && lead) {   // the partner's loss terms: published before its `done` flag
+                    int lr = 0;
+                    if (lane == 0) {
+                        const unsigned* flag = &A.done[obj * A.split + jj];
+                        const unsigned long long t0 = wall_clock64();
+                        do {
+                            lr = __hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(it + 1);
+                        } while (!lr && wall_clock64() - t0 < A.split_wait_ticks);
+                    }
+                    ready = __shfl(lr, 0);
+                    if (ready) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                         for (int m = lane; m * keff + jj < F; m += 64) {
                             const int f = m * keff + jj;
 #pragma unroll
                             for (int d = 0; d < 4; d++) L.lterm[f * 4 + d] = xl[f * 4 + d];
                         }
+                    }
                 }
+                if (ready && lane < 9) L.xroot[jj * 9 + lane] = __uint_as_float((unsigned)(v & 0xffffffffull));
                 if (lane == 0) L.xready[jj] = ready;
             }
             __syncthreads();
@@ -734,19 +757,19 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     if (bytes > 160 * 1024) return odam_fail(ODAM_E_LIMIT, "odam_sq: LDS budget exceeded");
     // View split: only when every workgroup of the grid can be resident at once (one 1024-thread workgroup per CU),
     // the objects are large enough to gain, and the exchange history fits a modest buffer.
-    static const int split_env = getenv("ODAM_SQ_SPLIT") ? atoi(getenv("ODAM_SQ_SPLIT")) : 4;
+    static const int split_env = getenv("ODAM_SQ_SPLIT") ? atoi(getenv("ODAM_SQ_SPLIT")) : 16;
     static const int wait_env = getenv("ODAM_SQ_SPLIT_WAIT") ? atoi(getenv("ODAM_SQ_SPLIT_WAIT")) : 3000;   // 0: never wait (tests)
     static const int s_env = getenv("ODAM_SQ_S") ? atoi(getenv("ODAM_SQ_S")) : 0;
     A.force_lanes_per_view = s_env;
     A.n_obj = n_obj; A.split = 1; A.split_min_views = 64; A.max_views = max_views; A.split_wait_ticks = (unsigned)wait_env;
     int grid = n_obj;
     const int n_pad = (n_obj + 7) / 8 * 8;
-    int k = split_env < 1 ? 1 : (split_env > 8 ? 8 : split_env);   // measured: 4 is best from 1 to 60 objects
+    int k = split_env < 1 ? 1 : (split_env > 16 ? 16 : split_env);
     while (k > 1 && n_pad * k > ctx->n_cu) k >>= 1;
     if (k > 1 && A.n_iters > 0 && max_views >= A.split_min_views) {
-        const size_t roots = (size_t)A.n_iters * n_obj * k * 9;                 // one 9-float root per workgroup and step
+        const size_t roots = (size_t)A.n_iters * n_obj * k * 9;                 // 64-bit words: one tagged root per workgroup and step
         const size_t rows = A.loss_log ? (size_t)A.n_iters * n_obj * max_views * 4 : 0;   // loss terms, only when logged
-        const size_t need = (roots + rows) * sizeof(float);
+        const size_t need = roots * sizeof(unsigned long long) + rows * sizeof(float);
         if (need <= ((size_t)1 << 30)) {
             if (need > ctx->xch_bytes) {
                 if (ctx->d_xch) { ODAM_HIP(hipStreamSynchronize(stream)); (void)hipFree(ctx->d_xch); ctx->d_xch = nullptr; ctx->xch_bytes = 0; }
@@ -759,9 +782,10 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
                 ctx->done_n = (size_t)n_obj * k;
             }
             ODAM_HIP(hipMemsetAsync(ctx->d_done, 0, sizeof(unsigned) * n_obj * k, stream));
+            ODAM_HIP(hipMemsetAsync(ctx->d_xch, 0, roots * sizeof(unsigned long long), stream));
             A.split = k;
-            A.xgrad = ctx->d_xch;
-            A.xloss = A.loss_log ? ctx->d_xch + roots : nullptr;
+            A.xroots = (unsigned long long*)ctx->d_xch;
+            A.xloss = A.loss_log ? (float*)((unsigned long long*)ctx->d_xch + roots) : nullptr;
             A.done = ctx->d_done;
             grid = n_pad * k;
         }
