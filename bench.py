@@ -199,7 +199,11 @@ def main():
                               # HBM-side bytes of this kernel per frame from rocprofv3 PMC passes of B=32 forwards
                               # (profiles/r1_detr_forward_B32_pmc_*.csv): (2 x FETCH_SIZE + WRITE_SIZE) KB x 1024 / 64;
                               # counters cannot be read from inside this process, so the figure is the recorded one
-                              "traffic": TRAFFIC_BYTES_PER_FRAME_PMC, "traffic_unit": "bytes per frame (all launches)",
+                              "traffic": TRAFFIC_BYTES_PER_FRAME_PMC * args.batch / max(n_launch, 1),
+                              "traffic_unit": "HBM-side bytes per launch, average over the %d launches of a forward of %d "
+                                              "frames (PMC: 2 x FETCH_SIZE + WRITE_SIZE)" % (n_launch, args.batch),
+                              "traffic_bytes_per_frame": TRAFFIC_BYTES_PER_FRAME_PMC,
+                              "algorithmic_gflop_per_launch_avg": conv_flops / max(n_launch, 1) / 1e9,
                               "kernel": "conv_gemm_kernel (fp32 implicit-GEMM conv / linear, v_mfma_f32_32x32x2_f32)",
                               "launches_per_forward": n_launch,
                               "algorithmic_gflop_per_frame": flops_per_frame / 1e9,
