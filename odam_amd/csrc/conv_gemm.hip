@@ -14,7 +14,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // padded by one chunk (144-byte rows: 16-byte aligned, conflict-free for ds_read_b128).
 constexpr int LDS_STRIDE = 36;  // floats per LDS row
 #ifndef CG_ABLATE
-#define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores
+#define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores, 16 no first-tile load
 #endif
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     };
 
     if constexpr (NST == 2) {
-        load_tile(0, 0);
+        if (!(CG_ABLATE & 16)) load_tile(0, 0);   // 16: pretend the first tile is already there (cross-tile prefetch bound)
         store_tile(0);
         if constexpr (UT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
