@@ -56,14 +56,15 @@ def _worker(rank, ws, port, q):
     dist.destroy_process_group()
 
 
-def test_allgather_world2_gloo():
+@pytest.mark.parametrize("ws", [2, 3])     # 3: uneven frame shards (4, 4, 3) and object shards (2, 2, 1)
+def test_allgather_gloo(ws):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 7 * ws) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, q)) for r in range(ws)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=120) for _ in range(2)]
+    res = [q.get(timeout=180) for _ in range(ws)]
     for p in procs:
         p.join(timeout=60)
-    assert all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
+    assert len(res) == ws and all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
