@@ -700,6 +700,8 @@ static std::vector<float> sampler_draws() {
     return d;
 }
 
+extern "C" int odam_sq_destroy(odam_sq_ctx* c);
+
 extern "C" int odam_sq_create(int max_iters, odam_sq_ctx** out) {
     if (!out || max_iters < 0) return odam_fail(ODAM_E_INVALID, "odam_sq_create: bad arguments");
     std::vector<float> draws = sampler_draws();
@@ -719,14 +721,22 @@ extern "C" int odam_sq_create(int max_iters, odam_sq_ctx** out) {
     }
     odam_sq_ctx* c = new odam_sq_ctx();
     c->max_iters = max_iters;
-    ODAM_HIP(hipMalloc(&c->d_draws, sizeof(float) * N_PTS));
-    ODAM_HIP(hipMalloc(&c->d_omega_idx, sizeof(unsigned short) * N_PTS));
-    ODAM_HIP(hipMalloc(&c->d_adam, sizeof(float) * tab.size()));
-    ODAM_HIP(hipMemcpy(c->d_draws, draws.data(), sizeof(float) * N_PTS, hipMemcpyHostToDevice));
-    ODAM_HIP(hipMemcpy(c->d_omega_idx, oidx.data(), sizeof(unsigned short) * N_PTS, hipMemcpyHostToDevice));
-    ODAM_HIP(hipMemcpy(c->d_adam, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
-    ODAM_HIP(hipFuncSetAttribute((const void*)sq_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 160 * 1024));
+    c->d_draws = nullptr; c->d_omega_idx = nullptr; c->d_adam = nullptr; c->d_dummy_params = nullptr;
+    const int rc = [&]() -> int {   // any failure below frees what was allocated so far
+        ODAM_HIP(hipMalloc(&c->d_draws, sizeof(float) * N_PTS));
+        ODAM_HIP(hipMalloc(&c->d_omega_idx, sizeof(unsigned short) * N_PTS));
+        ODAM_HIP(hipMalloc(&c->d_adam, sizeof(float) * tab.size()));
+        ODAM_HIP(hipMemcpy(c->d_draws, draws.data(), sizeof(float) * N_PTS, hipMemcpyHostToDevice));
+        ODAM_HIP(hipMemcpy(c->d_omega_idx, oidx.data(), sizeof(unsigned short) * N_PTS, hipMemcpyHostToDevice));
+        ODAM_HIP(hipMemcpy(c->d_adam, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
+        ODAM_HIP(hipFuncSetAttribute((const void*)sq_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     160 * 1024));
+        return ODAM_OK;
+    }();
+    if (rc != ODAM_OK) {
+        (void)odam_sq_destroy(c);
+        return rc;
+    }
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
