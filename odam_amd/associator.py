@@ -73,16 +73,20 @@ class Associator:
         with torch.cuda.device(self.device):
             _lib.check(L.odam_assoc_create(self.max_tracks, self.n_self, cross, len(self.gnn_layers), self.iters,
                                            ctypes.byref(h)), "odam_assoc_create")
-            tensors = dict(self._sd)
-            # PositionalEncoding.div_term (associator.py:320), torch CPU float32 ops
-            tensors["pe_div_term"] = torch.exp(torch.arange(0, 256, 2).float() * (-math.log(10000.0) / 256))
-            for name, t in tensors.items():
-                t = t.reshape(t.shape[0], t.shape[1]) if t.dim() == 3 else t     # Conv1d weight [N, K, 1]
-                t = t.contiguous()
-                shape = (ctypes.c_longlong * max(t.dim(), 1))(*t.shape)
-                _lib.check(L.odam_assoc_set_weight(h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
-                           f"odam_assoc_set_weight({name})")
-            _lib.check(L.odam_assoc_finalize(h), "odam_assoc_finalize")
+            try:
+                tensors = dict(self._sd)
+                # PositionalEncoding.div_term (associator.py:320), torch CPU float32 ops
+                tensors["pe_div_term"] = torch.exp(torch.arange(0, 256, 2).float() * (-math.log(10000.0) / 256))
+                for name, t in tensors.items():
+                    t = t.reshape(t.shape[0], t.shape[1]) if t.dim() == 3 else t     # Conv1d weight [N, K, 1]
+                    t = t.contiguous()
+                    shape = (ctypes.c_longlong * max(t.dim(), 1))(*t.shape)
+                    _lib.check(L.odam_assoc_set_weight(h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
+                               f"odam_assoc_set_weight({name})")
+                _lib.check(L.odam_assoc_finalize(h), "odam_assoc_finalize")
+            except Exception:
+                L.odam_assoc_destroy(h)      # a half-built handle is not kept
+                raise
         self._h = h
         return h
 

@@ -110,17 +110,27 @@ class Detector:
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.odam_detr_create(ctypes.byref(cfg), ctypes.byref(h)), "odam_detr_create")
-            fh, fw = ctypes.c_int(), ctypes.c_int()
-            _lib.check(L.odam_detr_feature_hw(h, ctypes.byref(fh), ctypes.byref(fw)), "odam_detr_feature_hw")
-            tensors = dict(self._sd)
-            tensors["pos_embed"] = sine_position_embedding(fh.value, fw.value, a["hidden_dim"] // 2)
-            for name, t in tensors.items():
-                shape = (ctypes.c_longlong * max(t.dim(), 1))(*t.shape)
-                _lib.check(L.odam_detr_set_weight(h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
-                           f"odam_detr_set_weight({name})")
-            _lib.check(L.odam_detr_finalize(h), "odam_detr_finalize")
+            try:
+                self._fill_handle(h)
+            except Exception:
+                L.odam_detr_destroy(h)     # a half-built handle (e.g. a missing weight) is not kept
+                raise
         self._handles[key] = h
         return h
+
+    def _fill_handle(self, h):
+        """weights (reference key names) + the position table of this input size, then finalize"""
+        L = _lib.lib()
+        a = self.arch
+        fh, fw = ctypes.c_int(), ctypes.c_int()
+        _lib.check(L.odam_detr_feature_hw(h, ctypes.byref(fh), ctypes.byref(fw)), "odam_detr_feature_hw")
+        tensors = dict(self._sd)
+        tensors["pos_embed"] = sine_position_embedding(fh.value, fw.value, a["hidden_dim"] // 2)
+        for name, t in tensors.items():
+            shape = (ctypes.c_longlong * max(t.dim(), 1))(*t.shape)
+            _lib.check(L.odam_detr_set_weight(h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
+                       f"odam_detr_set_weight({name})")
+        _lib.check(L.odam_detr_finalize(h), "odam_detr_finalize")
 
     # ---- DETR.forward (detr.py:49-94) ---------------------------------------------------------------
     def __call__(self, samples):
