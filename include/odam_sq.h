@@ -27,7 +27,8 @@ extern "C" {
 #define ODAM_E_LIMIT 3     /* problem exceeds a compiled limit (views per object, iterations) */
 
 #define ODAM_SQ_POINTS 1000      /* surface samples per super-quadric   (sq_libs.py:545) */
-#define ODAM_SQ_MAX_VIEWS 1024   /* views per object handled by one workgroup */
+#define ODAM_SQ_MAX_VIEWS 1024   /* views one workgroup reduces; an object split over k workgroups may have k times as many
+                                    (k <= 16, and k * padded object count <= number of CUs) */
 
 /* representation codes, sq_libs.py:362-386 */
 #define ODAM_SQ_SUPER_QUADRIC 0  /* 9 parameters optimised */
@@ -60,7 +61,8 @@ int odam_sq_destroy(odam_sq_ctx* ctx);
  *   out_points   [dev] [n_obj][1000][3]  surface of the fitted SQ (compute_ellipsoid_points); nullable
  *   loss_log     [dev] [n_obj][n_iters]  loss_2d per step (sq_libs.py:471); nullable
  *   traj         [dev] [n_obj][n_iters][9] parameters after every step; nullable (parity tests)
- *   max_views    largest view count of any object (host-known; sizes the workgroup's LDS)
+ *   max_views    largest view count of any object (host-known; sizes the workgroup's LDS); up to 16 * ODAM_SQ_MAX_VIEWS
+ *                when few enough objects are fitted per call for the view split to cover it, else ODAM_E_LIMIT
  */
 int odam_sq_fit_batch(odam_sq_ctx* ctx, int n_obj, const float* init_params, const int* class_id,
                       const int* view_offsets, const float* P, const float* tgt, const float* mask,

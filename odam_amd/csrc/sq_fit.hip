@@ -67,7 +67,7 @@ struct FitArgs {
     const float* adam_tab;            // [max_iters][4]: -lr/bc1 (main), -lr/bc1 (shapes), sqrt(bc2), pad
     int n_iters;
     int representation;
-    int pn_views;                     // power of two >= max views per object (LDS sizing)
+    int pn_views;                     // rows of the per-view gradient buffer in LDS (largest sub-tree of any workgroup)
     float* out_params;
     float* out_points;
     float* loss_log;
@@ -109,12 +109,12 @@ struct Lds {
     float* tcx;
     float* tcy;
     float* vgrad;   // [pn][9]
-    float* lterm;   // [pn][4]
+    float* lterm;   // [views][4], only when the loss is logged
 };
 
-__host__ __device__ inline size_t lds_words(int pn) {
+__host__ __device__ inline size_t lds_words(int rows, int loss_rows) {
     return 12 * 6 + 8 + 8 + 16 + 144 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
-           (size_t)pn * 9 + (size_t)pn * 4;
+           (size_t)rows * 9 + (size_t)loss_rows * 4;
 }
 
 __device__ inline Lds carve(float* base, int pn) {
@@ -759,12 +759,9 @@ extern "C" int odam_sq_destroy(odam_sq_ctx* c) {
 static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hipStream_t stream) {
     int pn = 1;
     while (pn < max_views) pn <<= 1;
-    A.pn_views = pn;
     A.draws = ctx->d_draws;
     A.omega_idx = ctx->d_omega_idx;
     A.adam_tab = ctx->d_adam;
-    size_t bytes = lds_words(pn) * sizeof(float);
-    if (bytes > 160 * 1024) return odam_fail(ODAM_E_LIMIT, "odam_sq: LDS budget exceeded");
     // View split: only when every workgroup of the grid can be resident at once (one 1024-thread workgroup per CU),
     // the objects are large enough to gain, and the exchange history fits a modest buffer.
     static const int split_env = getenv("ODAM_SQ_SPLIT") ? atoi(getenv("ODAM_SQ_SPLIT")) : 16;
@@ -800,6 +797,19 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
             grid = n_pad * k;
         }
     }
+    // LDS: a workgroup reduces at most its own residue class (pn / split rows; objects too small to be split have
+    // fewer than split_min_views rows), so the views one object may have grow with the split.
+    int rows = pn;
+    if (A.split > 1) {
+        rows = pn / A.split;
+        if (rows < A.split_min_views) rows = A.split_min_views;
+    }
+    if (rows > ODAM_SQ_MAX_VIEWS)
+        return odam_fail(ODAM_E_LIMIT, "odam_sq: more than ODAM_SQ_MAX_VIEWS views per workgroup (too many views per object "
+                                       "for this many objects: fit fewer objects per call)");
+    A.pn_views = rows;
+    const size_t bytes = lds_words(rows, A.loss_log ? max_views : 0) * sizeof(float);
+    if (bytes > 160 * 1024) return odam_fail(ODAM_E_LIMIT, "odam_sq: LDS budget exceeded (loss logging with this many views)");
     hipLaunchKernelGGL(sq_fit_kernel, dim3(grid), dim3(NT), bytes, stream, A);
     ODAM_HIP(hipGetLastError());
     return ODAM_OK;
@@ -815,8 +825,8 @@ extern "C" int odam_sq_fit_batch(odam_sq_ctx* ctx, int n_obj, const float* init_
     if (n_obj < 0 || n_iters < 0 || representation < 0 || representation > 2)
         return odam_fail(ODAM_E_INVALID, "odam_sq_fit_batch: bad size / representation");
     if (n_iters > ctx->max_iters) return odam_fail(ODAM_E_LIMIT, "odam_sq_fit_batch: n_iters > max_iters of the context");
-    if (max_views < 1 || max_views > ODAM_SQ_MAX_VIEWS)
-        return odam_fail(ODAM_E_LIMIT, "odam_sq_fit_batch: max_views outside 1..ODAM_SQ_MAX_VIEWS");
+    if (max_views < 1 || max_views > 16 * ODAM_SQ_MAX_VIEWS)
+        return odam_fail(ODAM_E_LIMIT, "odam_sq_fit_batch: max_views outside 1..16 * ODAM_SQ_MAX_VIEWS");
     if (n_obj == 0) return ODAM_OK;
     FitArgs A{};
     A.init_params = init_params; A.class_id = class_id; A.view_offsets = view_offsets;

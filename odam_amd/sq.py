@@ -15,7 +15,8 @@ import torch
 from . import _lib
 
 N_POINTS = 1000
-MAX_VIEWS = 1024
+WG_VIEWS = 1024          # rows one workgroup reduces (ODAM_SQ_MAX_VIEWS)
+MAX_VIEWS = 16 * WG_VIEWS  # per object: split over up to 16 workgroups
 NAMES = ("x_min", "x_max", "y_min", "y_max")  # sq_libs.py:438
 REPRESENTATIONS = {"super_quadric": 0, "cube": 1, "quadric": 2}
 # sq_libs.py:13-22
@@ -97,7 +98,49 @@ class SqFitter:
 
         params0 [n,9] f32; class_ids [n] int; view_counts [n] int; P [sumF,3,4]/[sumF,12] f32;
         tgt, mask [sumF,4] f32 (numpy or torch, host or device).  Returns dict of device tensors.
+
+        Objects with more than 1024 views need the library's view split (k workgroups per object, k x padded object
+        count <= number of CUs): they are fitted in groups small enough for that; fits are independent, so the
+        grouping does not change any result.
         """
+        vc = np.asarray(view_counts, np.int64)
+        if len(vc) and vc.max() > WG_VIEWS:
+            return self._fit_grouped(params0, class_ids, vc, P, tgt, mask, dict(
+                n_iters=n_iters, representation=representation, prior=prior, want_points=want_points,
+                want_loss=want_loss, want_traj=want_traj))
+        return self._fit_once(params0, class_ids, view_counts, P, tgt, mask, n_iters, representation, prior,
+                              want_points, want_loss, want_traj)
+
+    def _fit_grouped(self, params0, class_ids, vc, P, tgt, mask, kw):
+        if vc.max() > MAX_VIEWS:
+            raise _lib.OdamError(f"views per object must be in 1..{MAX_VIEWS}, got {vc.min()}..{vc.max()}")
+        as_t = lambda x: x if torch.is_tensor(x) else torch.as_tensor(np.asarray(x))
+        P, tgt, mask, params0 = as_t(P).reshape(-1, 12), as_t(tgt).reshape(-1, 4), as_t(mask).reshape(-1, 4), as_t(params0).reshape(-1, 9)
+        offs = np.concatenate([[0], np.cumsum(vc)])
+        need = np.ones(len(vc), np.int64)                      # workgroups an object needs
+        big = vc > WG_VIEWS
+        need[big] = (2 ** np.ceil(np.log2(vc[big])).astype(np.int64)) // WG_VIEWS
+        groups = [np.flatnonzero(~big)] if (~big).any() else []
+        for k in sorted(set(need[big].tolist())):
+            idx = np.flatnonzero(need == k)
+            per = max(8, (256 // k) // 8 * 8)                  # padded object count x k <= 256 CUs
+            groups += [idx[i:i + per] for i in range(0, len(idx), per)]
+        outs = {}
+        for g in groups:
+            rows = np.concatenate([np.arange(offs[i], offs[i + 1]) for i in g])
+            o = self._fit_once(params0[g], [class_ids[i] for i in g], vc[g], P[rows], tgt[rows], mask[rows],
+                               kw["n_iters"], kw["representation"], kw["prior"], kw["want_points"], kw["want_loss"], kw["want_traj"])
+            for key, val in o.items():
+                if val is None:
+                    outs[key] = None
+                    continue
+                if key not in outs:
+                    outs[key] = torch.empty((len(vc),) + tuple(val.shape[1:]), device=val.device, dtype=val.dtype)
+                outs[key][torch.as_tensor(g, device=val.device)] = val
+        return outs
+
+    def _fit_once(self, params0, class_ids, view_counts, P, tgt, mask, n_iters=200, representation="super_quadric",
+                  prior=True, want_points=True, want_loss=False, want_traj=False):
         dev = self.device
         n = len(view_counts)
         as_dev = lambda x, dt: torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x).to(

@@ -150,11 +150,28 @@ def test_limits_are_reported(fitter):
     from odam_amd import synth, _lib
     pr = synth.make_sq_problem(4, 1)
     p0, cls, vc, P, tgt, mask = _pack([pr])
+    n = 16 * 1024 + 1        # one view more than 16 workgroups x 1024 rows can hold
     with pytest.raises(_lib.OdamError):
-        fitter.fit(p0, cls, [2000], np.zeros((2000, 12), np.float32), np.zeros((2000, 4), np.float32),
-                   np.zeros((2000, 4), np.float32))
+        fitter.fit(p0, cls, [n], np.zeros((n, 12), np.float32), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32))
     with pytest.raises(KeyError):
         fitter.fit(p0, [9], vc, P, tgt, mask)
+
+
+def test_more_views_than_one_workgroup_holds(fitter, oracle):
+    """3000 and 1500 views per object: beyond the 1024 rows of one workgroup, fitted through the view split --
+    trajectory and parameters bit-exact vs the oracle (20 steps keep the serial oracle short)"""
+    from odam_amd import synth
+    probs = [synth.make_sq_problem(F, 900 + F) for F in (3000, 1500, 40)]
+    p0, cls, vc, P, tgt, mask = _pack(probs)
+    out = fitter.fit(p0, cls, vc, P, tgt, mask, n_iters=20, want_traj=True)
+    gp, gt = out["params"].cpu().numpy(), out["traj"].cpu().numpy()
+    off = 0
+    for i, F in enumerate(vc):
+        op, otraj, _ = oracle.fit(p0[i], P[off:off + F], tgt[off:off + F], mask[off:off + F], cls[i], n_iters=20,
+                                  want_traj=True)
+        assert np.array_equal(_bits(otraj), _bits(gt[i][:20])), F
+        assert np.array_equal(_bits(op), _bits(gp[i])), F
+        off += F
 
 
 def test_view_split_is_bit_identical_on_every_path():
