@@ -378,3 +378,17 @@ def test_bf16_forward_close_to_fp32_oracle():
     feats = out["pred_obj_features"].cpu()
     assert (feats - ref["pred_obj_features"]).abs().max().item() <= 0.15
     det.close()
+
+
+@pytest.mark.parametrize("env", [{"ODAM_CG_NO_UT": "1"}, {"ODAM_CG_VARIANT": "0"}, {"ODAM_CG_FORCE": "2"}])
+def test_conv_gemm_alternative_paths(env):
+    """the register-staged gather (what layers too large for 31-bit buffer offsets fall back to), the 4-wave tiles
+    and the four-stage small-tile pipeline on every shape: same parity.  The switches are read once per process."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("ODAM_NESTED"):
+        pytest.skip("already inside the nested run")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", "conv_gemm_vs_torch or conv_gemm_bf16"],
+                       env={**os.environ, **env, "ODAM_NESTED": "1"}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
