@@ -4,7 +4,7 @@ import csv, re, sys
 from collections import defaultdict
 busy, act, n = defaultdict(float), defaultdict(float), defaultdict(int)
 for r in csv.DictReader(open(sys.argv[1])):
-    k = re.sub(r"\(.*", "", r["Kernel_Name"])[:100]
+    k = re.sub(r"\([^()]*\)$", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))[:100]
     if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES": busy[k] += float(r["Counter_Value"]); n[k] += 1
     elif r["Counter_Name"] == "GRBM_GUI_ACTIVE": act[k] += float(r["Counter_Value"])
 print("kernel,dispatches,sum_SQ_VALU_MFMA_BUSY_CYCLES,sum_GRBM_GUI_ACTIVE,mfma_util")

@@ -6,7 +6,7 @@ tot, n = defaultdict(float), defaultdict(int)
 for r in csv.DictReader(open(path)):
     if r["Counter_Name"] != name:
         continue
-    k = re.sub(r"\(.*", "", r["Kernel_Name"])[:100]
+    k = re.sub(r"\([^()]*\)$", "", r["Kernel_Name"].replace("(anonymous namespace)::", ""))[:100]
     tot[k] += float(r["Counter_Value"]); n[k] += 1
 print(f"kernel,dispatches,sum_{name}")
 for k in sorted(tot, key=lambda k: -tot[k]):
