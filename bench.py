@@ -266,7 +266,7 @@ def cpu_baseline(scene, tracks, N):
     from conftest import Oracle
     sd = weights.make_state_dict(seed=0)
     t = transforms.get_transforms()
-    imgs = list(synth.make_frames(3, seed=0))
+    imgs = list(synth.make_frames(6, seed=0))      # 1 warm-up + 5 timed frames
     detr_oracle.detr_forward(sd, t(imgs[0])[0][None])  # warm-up
     s = time.perf_counter()
     for f in imgs[1:]:
