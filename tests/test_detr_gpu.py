@@ -138,6 +138,18 @@ def test_forward_vs_reference_golden(model, golden):
             assert np.allclose(post[k][b], z[f"post{b}_{k}"], rtol=1e-4, atol=1e-3), (b, k)
 
 
+def test_full_size_forward_vs_reference_golden(model, golden):
+    """the reference's own DETR output on one 3x800x1066 frame (850 encoder tokens): BASELINE's full size"""
+    det, _ = model
+    z = golden("detr_full.npz")
+    torch.manual_seed(int(z["img_seed"]))
+    img = torch.randn(1, 3, 800, 1066)
+    out = det(img.to(DEV))
+    for k in KEYS:
+        assert np.abs(out[k].cpu().numpy() - z[k]).max() <= 1e-4 * max(1.0, float(np.abs(z[k]).max())), k
+    assert np.array_equal(out["pred_logits"].argmax(-1).cpu().numpy(), z["pred_logits"].argmax(-1))   # class labels: exact
+
+
 def test_full_size_forward_vs_oracle(model):
     """BASELINE config size (800x1066 from a 640x480 frame): taps + outputs + discrete decisions vs the oracle"""
     import detr_oracle as O

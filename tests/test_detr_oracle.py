@@ -23,6 +23,17 @@ def sd():
     return weights.make_state_dict(seed=0)
 
 
+def test_full_size_forward_matches_reference_detr(sd, golden):
+    """oracle vs the reference's DETR on one 3x800x1066 frame"""
+    z = golden("detr_full.npz")
+    torch.manual_seed(int(z["img_seed"]))
+    img = torch.randn(1, 3, 800, 1066)
+    out = O.detr_forward(sd, img)
+    for k in KEYS:
+        assert np.abs(out[k].numpy() - z[k]).max() <= 2e-5 * max(1.0, float(np.abs(z[k]).max())), k
+    assert np.array_equal(out["pred_logits"].argmax(-1).numpy(), z["pred_logits"].argmax(-1))
+
+
 def test_forward_matches_reference_detr(sd, golden):
     z = golden("detr_small.npz")
     torch.manual_seed(int(z["img_seed"]))
