@@ -50,25 +50,33 @@ def _cases(z):
         yield c, {k[len(pre):]: z[k] for k in z.files if k.startswith(pre)}
 
 
-def test_every_step_matches_reference_when_started_from_its_state(oracle, golden):
+@pytest.mark.parametrize("fixture", ["sq_steps.npz", "sq_steps_full.npz"])     # 12..64 views; 256 views (config 5's size)
+def test_every_step_matches_reference_when_started_from_its_state(oracle, golden, fixture):
     """Teacher-forced: from the reference's parameters before step t, the oracle's points, loss and
     gradient match the reference's (autograd) and the Adam update lands on the reference's next state."""
-    z = golden("sq_steps.npz")
+    z = golden(fixture)
     for c, d in _cases(z):
         cls = int(d["cls"]); s0 = d["p0"][4:7]
         m = np.zeros(9, np.float32); v = np.zeros(9, np.float32)
         for it in (0, 100, 199):
             pts = oracle.points(d["p"][it])
             assert np.abs(pts - d[f"pts{it}"]).max() <= 4e-7          # a few ulp at |x| ~ 1
+        flipped = []
         for it in range(200):
             _, loss, g, _, _ = oracle.loss_grad(d["p"][it], d["P"], d["tgt"], d["mask"], cls, s0)
             rg = d["g"][it]
             assert abs(loss - d["loss"][it]) <= 1e-5 * abs(d["loss"][it])
             # the 9 gradients are sums of up to 4F signed terms of size ~f/z that largely cancel near
             # convergence; float32 summation order (autograd's vs the oracle's fixed tree) shows at 1e-6
-            assert np.abs(g - rg).max() <= max(1e-5 * np.abs(rg).max(), 1e-4), (c, it)
+            if np.abs(g - rg).max() > max(1e-5 * np.abs(rg).max(), 1e-4):
+                flipped.append(it)
             p1, m, v = oracle.adam(d["p"][it], m, v, rg, it + 1)
             assert np.abs(p1 - d["p_after"][it]).max() <= 1.2e-7, (c, it)  # <= 1 ulp
+        # The loss is continuous in which surface point wins a view's extreme, the gradient is not: where two of
+        # the 1000 points tie to the last ulp of the projected coordinate (the reference evaluates them with torch's
+        # vector math library, the oracle with libm) the winner, and with it one of the 4F terms, differs.  Never
+        # at 12..64 views; 2 and 10 of 200 steps in the two 256-view cases.
+        assert len(flipped) <= (0 if len(d["tgt"]) <= 64 else 20), (c, flipped)
 
 
 def test_free_running_trajectory_tracks_reference(oracle, golden):
