@@ -392,6 +392,26 @@ def test_bf16_forward_close_to_fp32_oracle():
     det.close()
 
 
+def test_bf16_r101_full_size_close_to_fp32_oracle():
+    """BASELINE config 4 at its full size: DETR-R101, one 800x600 frame resized to 3x800x1066, bf16 weights and
+    activations on the bf16 matrix instruction -- same documented tolerance against the fp32 oracle"""
+    import detr_oracle as O
+    from odam_amd import detector, weights
+    sd = weights.make_state_dict(backbone="resnet101", seed=1)
+    det = detector.Detector(backbone="resnet101", max_batch=1, device=DEV, dtype="bf16", n_streams=1)
+    det.load_state_dict(sd)
+    torch.manual_seed(4)
+    img = torch.randn(1, 3, 800, 1066)
+    ref = O.detr_forward(sd, img, blocks=(3, 4, 23, 3))
+    out = det(img.to(DEV))
+    for k in KEYS:
+        err = (out[k].cpu() - ref[k]).abs().max().item()
+        assert err <= 0.05 * max(1.0, ref[k].abs().max().item()), (k, err)
+    agree = (out["pred_logits"].cpu().argmax(-1) == ref["pred_logits"].argmax(-1)).float().mean().item()
+    assert agree >= 0.9, agree
+    det.close()
+
+
 @pytest.mark.parametrize("env", [{"ODAM_CG_NO_UT": "1"}, {"ODAM_CG_VARIANT": "0"}, {"ODAM_CG_FORCE": "2"}])
 def test_conv_gemm_alternative_paths(env):
     """the register-staged gather (what layers too large for 31-bit buffer offsets fall back to), the 4-wave tiles
