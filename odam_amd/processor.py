@@ -135,49 +135,45 @@ class OdamProcess:
         m = self.sequence_meta
         return np.array([[m.img_w, m.img_h, m.img_w, m.img_h]])
 
+    def _track_rows(self, det, T_wc, with_code):
+        """[n,79] detection rows of one frame -> [n,82] track rows (layout processor.py:98-108): boxes in pixels, centre
+        and azimuth moved from the camera to the world frame, the detected box repeated as the projected one."""
+        rows = np.full((len(det), 82), -1.0)
+        px = det[:, 2:6] * self._img_size_row()
+        rows[:, :9] = det[:, :9]
+        rows[:, 2:6] = px
+        rows[:, 9:12] = (get_homogeneous(det[:, 9:12]) @ T_wc.T)[:, :3]
+        rows[:, 12] = np.arctan2(det[:, 12], det[:, 13]) + get_cam_azi(T_wc)
+        rows[:, 13] = det[:, 14]
+        if with_code:
+            rows[:, 14:78] = det[:, 15:79]
+        rows[:, 78:82] = px
+        return rows
+
     def _init_tracks(self, detections, T_wc):
-        img_size = self._img_size_row()
-        detect_bboxes = detections[:, 2:6] * img_size
-        cam_azi = get_cam_azi(T_wc)
-        tracks = np.zeros((len(detections), 1, 82)) - 1
-        tracks[:, 0, :9] = detections[:, :9]
-        tracks[:, 0, 2:6] *= img_size
-        tracks[:, 0, -4:] = detect_bboxes
-        azi_wo = np.arctan2(detections[:, 12], detections[:, 13]) + cam_azi
-        t_wo = (get_homogeneous(detections[:, 9:12]) @ T_wc.T)[:, :3]
-        tracks[:, 0, 9:12] = t_wo
-        tracks[:, 0, 12] = azi_wo
-        tracks[:, 0, 13] = detections[:, 14]
-        return [t for t in tracks]
+        """processor.py:95-131: every detection of the first frame with detections starts a track"""
+        return [r[None, :] for r in self._track_rows(detections, T_wc, with_code=False)]
 
     def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100):
-        """processor.py:139-170.  Built in numpy and wrapped once: on a many-core host every torch CPU op above the
-        intra-op grain size forks the whole OpenMP pool, which costs milliseconds per frame in this loop."""
+        """processor.py:133-170: the last `n_times` observations of every track in the CURRENT camera frame,
+        [T, n_times, 79] float32 padded with -1.  Built in numpy and wrapped once: on a many-core host every torch
+        CPU op above the intra-op grain size forks the whole OpenMP pool, which costs milliseconds per frame here."""
         T_cw = np.linalg.inv(T_wc)
+        img = self._img_size_row()[0]
         in_ = np.full((len(tracks), n_times, 79), -1.0, np.float32)
         for idx, track in enumerate(tracks):
-            n_steps = len(track)
-            tmp = np.zeros((n_steps, 79)) - 1
-            projected_bbox = track[-1, -4:]
-            assert not (projected_bbox == -1).all(), "wrong projected bbox"
-            projected_bbox /= self._img_size_row()[0]
-            projected_bbox = np.clip(projected_bbox, a_min=-1, a_max=2)
-            track[:, 2:6] = projected_bbox
-            tmp[:, 0] = track[:, 0]
-            tmp[:, 1] = track[:, 1]
-            tmp[:, 2:6] = track[:, 2:6]
-            tmp[:, 6:9] = track[:, 6:9]
-            tmp[:, 9:12] = (get_homogeneous(track[:, 9:12]) @ T_cw.T)[:, :3]
-            angle = track[:, 12] - cam_azi
-            tmp[:, 12] = np.sin(angle)
-            tmp[:, 13] = np.cos(angle)
-            tmp[:, 14] = track[:, 13]
-            tmp[:, 15:79] = track[:, 14:78]
-            tmp = tmp.astype(np.float32)           # torch.tensor(tmp, dtype=float32): round to nearest
-            if n_steps > n_times:
-                in_[idx, :, :] = tmp[-100:, :]
-            else:
-                in_[idx, :n_steps, :] = tmp
+            assert not (track[-1, -4:] == -1).all(), "wrong projected bbox"
+            track[-1, -4:] /= img                                   # (the reference normalises in place, too)
+            track[:, 2:6] = np.clip(track[-1, -4:], a_min=-1, a_max=2)
+            obs = np.full((len(track), 79), -1.0)
+            obs[:, :9] = track[:, :9]
+            obs[:, 9:12] = (get_homogeneous(track[:, 9:12]) @ T_cw.T)[:, :3]
+            rel = track[:, 12] - cam_azi
+            obs[:, 12], obs[:, 13] = np.sin(rel), np.cos(rel)
+            obs[:, 14] = track[:, 13]
+            obs[:, 15:79] = track[:, 14:78]
+            obs = obs[-n_times:].astype(np.float32)                 # torch.tensor(., dtype=float32): round to nearest
+            in_[idx, :len(obs)] = obs
         return in_
 
     def _prepare_tracks(self, T_wc, n_times=100):
@@ -223,26 +219,16 @@ class OdamProcess:
                 "track_batch_split": tsplit, "detection_batch_split": dsplit, "poses": poses, "valid_list": valid}
 
     def _attach_to_tracks(self, pred_match, detections, T_wc, score_mat):
-        cam_azi = get_cam_azi(T_wc)
-        t_wo = (get_homogeneous(detections[:, 9:12]) @ T_wc.T)[:, :3]
-        detections[:, 9:12] = t_wo
-        azi_wo = np.arctan2(detections[:, 12], detections[:, 13]) + cam_azi
-        img_size = self._img_size_row()[0]
-        for match_track_id, det_id, detection in zip(pred_match, np.arange(len(detections)), detections):
-            if score_mat[match_track_id, det_id] < self.score_threshold:
+        """processor.py:212-257: a matched detection extends its track, an unmatched one (-1) starts a new one;
+        matches scoring below `score_threshold` are dropped (index -1 reads the dustbin row, as in the reference)."""
+        rows = self._track_rows(detections, T_wc, with_code=not self.no_code)
+        for det_id, track_id in enumerate(pred_match):
+            if score_mat[track_id, det_id] < self.score_threshold:
                 continue
-            attach_ = np.zeros((1, 82))
-            attach_[0, :9] = detection[:9]
-            attach_[0, 2:6] *= img_size
-            attach_[0, 9:12] = t_wo[det_id]
-            attach_[0, 12] = azi_wo[det_id]
-            attach_[0, 13] = detection[14]
-            attach_[0, 14:78] = -1 if self.no_code else detection[15:79]
-            attach_[0, 78:82] = detection[2:6] * img_size
-            if match_track_id == -1:
-                self.tracks.append(attach_)
+            if track_id == -1:
+                self.tracks.append(rows[det_id:det_id + 1])
             else:
-                self.tracks[match_track_id] = np.concatenate([self.tracks[match_track_id], attach_], axis=0)
+                self.tracks[track_id] = np.concatenate([self.tracks[track_id], rows[det_id:det_id + 1]], axis=0)
 
     # ---- per-frame driver (processor.py:306-345) ---------------------------------------------------
     def process_frame(self, rgb, frame_id, T_wc, detections=None):
