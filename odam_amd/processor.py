@@ -156,24 +156,30 @@ class OdamProcess:
 
     def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100):
         """processor.py:133-170: the last `n_times` observations of every track in the CURRENT camera frame,
-        [T, n_times, 79] float32 padded with -1.  Built in numpy and wrapped once: on a many-core host every torch
-        CPU op above the intra-op grain size forks the whole OpenMP pool, which costs milliseconds per frame here."""
-        T_cw = np.linalg.inv(T_wc)
-        img = self._img_size_row()[0]
+        [T, n_times, 79] float32 padded with -1.  All observations of all tracks go through numpy at once (the
+        reference loops over tracks; every row is computed by the same operations), and nothing here is a torch CPU
+        op: on a many-core host those fork the whole OpenMP pool, which costs milliseconds per frame in this loop."""
         in_ = np.full((len(tracks), n_times, 79), -1.0, np.float32)
-        for idx, track in enumerate(tracks):
-            assert not (track[-1, -4:] == -1).all(), "wrong projected bbox"
-            track[-1, -4:] /= img                                   # (the reference normalises in place, too)
-            track[:, 2:6] = np.clip(track[-1, -4:], a_min=-1, a_max=2)
-            obs = np.full((len(track), 79), -1.0)
-            obs[:, :9] = track[:, :9]
-            obs[:, 9:12] = (get_homogeneous(track[:, 9:12]) @ T_cw.T)[:, :3]
-            rel = track[:, 12] - cam_azi
-            obs[:, 12], obs[:, 13] = np.sin(rel), np.cos(rel)
-            obs[:, 14] = track[:, 13]
-            obs[:, 15:79] = track[:, 14:78]
-            obs = obs[-n_times:].astype(np.float32)                 # torch.tensor(., dtype=float32): round to nearest
-            in_[idx, :len(obs)] = obs
+        if not len(tracks):
+            return in_
+        lens = np.array([len(t) for t in tracks])
+        ends = np.cumsum(lens)
+        cat = np.concatenate(tracks, axis=0)                         # [sum n, 82]
+        proj = cat[ends - 1, -4:]                                    # the box projected by _prepare_tracks: last row
+        assert not np.any(np.all(proj == -1, axis=1)), "wrong projected bbox"
+        proj = np.clip(proj / self._img_size_row()[0], a_min=-1, a_max=2)
+        obs = np.full((len(cat), 79), -1.0)
+        obs[:, :9] = cat[:, :9]
+        obs[:, 2:6] = proj[np.repeat(np.arange(len(tracks)), lens)]
+        obs[:, 9:12] = (get_homogeneous(cat[:, 9:12]) @ np.linalg.inv(T_wc).T)[:, :3]
+        rel = cat[:, 12] - cam_azi
+        obs[:, 12], obs[:, 13] = np.sin(rel), np.cos(rel)
+        obs[:, 14] = cat[:, 13]
+        obs[:, 15:79] = cat[:, 14:78]
+        obs = obs.astype(np.float32)                                 # torch.tensor(., dtype=float32): round to nearest
+        for idx, (n, e) in enumerate(zip(lens, ends)):
+            k = min(int(n), n_times)
+            in_[idx, :k] = obs[e - k:e]
         return in_
 
     def _prepare_tracks(self, T_wc, n_times=100):
@@ -182,19 +188,22 @@ class OdamProcess:
         # one batched surface evaluation for all tracks (reference: one SuperQuadric + sampler call each)
         params = []
         for track in tracks:
-            azi_wo = np.mean(track[:, 12], axis=0)
-            t_wo = np.mean(track[:, 9:12], axis=0)
-            dims = np.clip(np.mean(track[:, 6:9], axis=0), a_min=0.05, a_max=np.inf)
+            n = len(track)                       # np.mean = np.add.reduce / n, without mean()'s Python overhead
+            azi_wo = np.add.reduce(track[:, 12], axis=0) / n
+            t_wo = np.add.reduce(track[:, 9:12], axis=0) / n
+            dims = np.maximum(np.add.reduce(track[:, 6:9], axis=0) / n, 0.05)    # np.clip(., 0.05, inf)
             params.append(init_params(t_wo, azi_wo, dims))  # scales = sqrt(dims/2), shapes = -0
         pts_all = self._fitter().points(np.stack(params)).cpu().numpy() if params else np.zeros((0, 1000, 3))
-        T_cw = np.linalg.inv(T_wc)
-        for idx, track in enumerate(tracks):
-            box_3d_c = (get_homogeneous(pts_all[idx]) @ T_cw.T)[:, :3]
-            pixels = projection(box_3d_c, self.sequence_meta.K)
-            x_min, y_min, _ = np.min(pixels, axis=0)
-            x_max, y_max, _ = np.max(pixels, axis=0)
-            track[:, -4:] = np.array([[x_min, y_min, x_max, y_max]])
-            tracks[idx] = track
+        if len(tracks):
+            # projected extent of every track's surface in this camera, all tracks at once (the reference loops over
+            # tracks; same float64 products, and min / max do not depend on the order of the points)
+            T_cw = np.linalg.inv(T_wc)
+            cam = (np.concatenate([pts_all, np.ones_like(pts_all[..., 2:])], axis=2) @ T_cw.T)[..., :3]
+            pix = cam @ np.asarray(self.sequence_meta.K).T
+            pix = np.ascontiguousarray((pix / pix[..., -1:]).transpose(0, 2, 1))      # [T, 3, 1000]
+            lo, hi = pix.min(axis=2), pix.max(axis=2)
+            for idx, track in enumerate(tracks):
+                track[:, -4:] = np.array([[lo[idx, 0], lo[idx, 1], hi[idx, 0], hi[idx, 1]]])
         in_ = self._preprocess_tracks(tracks, T_wc, cam_azi, n_times)
         return torch.from_numpy(np.ascontiguousarray(in_.transpose(0, 2, 1)))   # [T, 79, n_times], as .permute(0, 2, 1)
 
