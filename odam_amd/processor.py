@@ -16,13 +16,11 @@ The associator (src/models/associator.py) is the reference's own and stays calle
 between the two fit passes is restated in odam_amd/merge.py (run_merge.py:79-130).
 """
 import logging
-from copy import deepcopy
 
 import numpy as np
 import torch
 
 from . import merge, multi_view
-from .sq import init_params
 
 
 class _Meta(dict):
@@ -184,16 +182,19 @@ class OdamProcess:
 
     def _prepare_tracks(self, T_wc, n_times=100):
         cam_azi = get_cam_azi(T_wc)
-        tracks = deepcopy(self.tracks)
-        # one batched surface evaluation for all tracks (reference: one SuperQuadric + sampler call each)
-        params = []
-        for track in tracks:
+        tracks = [t.copy() for t in self.tracks]     # (the reference deep-copies: the projected box is scratch)
+        # one batched surface evaluation for all tracks (reference: one SuperQuadric + sampler call each);
+        # parameters as sq.init_params builds them: mean centre, mean azimuth, sqrt(mean dims / 2), shapes -0
+        params = np.zeros((len(tracks), 9))
+        params[:, 7:] = -0.0
+        for i, track in enumerate(tracks):
             n = len(track)                       # np.mean = np.add.reduce / n, without mean()'s Python overhead
-            azi_wo = np.add.reduce(track[:, 12], axis=0) / n
-            t_wo = np.add.reduce(track[:, 9:12], axis=0) / n
-            dims = np.maximum(np.add.reduce(track[:, 6:9], axis=0) / n, 0.05)    # np.clip(., 0.05, inf)
-            params.append(init_params(t_wo, azi_wo, dims))  # scales = sqrt(dims/2), shapes = -0
-        pts_all = self._fitter().points(np.stack(params)).cpu().numpy() if params else np.zeros((0, 1000, 3))
+            params[i, :3] = np.add.reduce(track[:, 9:12], axis=0) / n
+            params[i, 3] = np.add.reduce(track[:, 12], axis=0) / n
+            params[i, 4:7] = np.maximum(np.add.reduce(track[:, 6:9], axis=0) / n, 0.05)    # np.clip(., 0.05, inf)
+        params[:, 4:7] = np.sqrt(params[:, 4:7] / 2)
+        params = params.astype(np.float32)
+        pts_all = self._fitter().points(params).cpu().numpy() if len(tracks) else np.zeros((0, 1000, 3))
         if len(tracks):
             # projected extent of every track's surface in this camera, all tracks at once (the reference loops over
             # tracks; same float64 products, and min / max do not depend on the order of the points)
