@@ -160,9 +160,10 @@ class OdamProcess:
         in_ = np.full((len(tracks), n_times, 79), -1.0, np.float32)
         if not len(tracks):
             return in_
-        lens = np.array([len(t) for t in tracks])
+        tails = [t[-n_times:] for t in tracks]                       # only the window that is used (rows are independent)
+        lens = np.array([len(t) for t in tails])
         ends = np.cumsum(lens)
-        cat = np.concatenate(tracks, axis=0)                         # [sum n, 82]
+        cat = np.concatenate(tails, axis=0)                          # [sum min(n, n_times), 82]
         proj = cat[ends - 1, -4:]                                    # the box projected by _prepare_tracks: last row
         assert not np.any(np.all(proj == -1, axis=1)), "wrong projected bbox"
         proj = np.clip(proj / self._img_size_row()[0], a_min=-1, a_max=2)
