@@ -152,7 +152,7 @@ class OdamProcess:
         """processor.py:95-131: every detection of the first frame with detections starts a track"""
         return [r[None, :] for r in self._track_rows(detections, T_wc, with_code=False)]
 
-    def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100):
+    def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100, proj_px=None):
         """processor.py:133-170: the last `n_times` observations of every track in the CURRENT camera frame,
         [T, n_times, 79] float32 padded with -1.  All observations of all tracks go through numpy at once (the
         reference loops over tracks; every row is computed by the same operations), and nothing here is a torch CPU
@@ -164,7 +164,8 @@ class OdamProcess:
         lens = np.array([len(t) for t in tails])
         ends = np.cumsum(lens)
         cat = np.concatenate(tails, axis=0)                          # [sum min(n, n_times), 82]
-        proj = cat[ends - 1, -4:]                                    # the box projected by _prepare_tracks: last row
+        # the box projected by _prepare_tracks: handed over directly, or (reference calling convention) in the last row
+        proj = cat[ends - 1, -4:] if proj_px is None else proj_px
         assert not np.any(np.all(proj == -1, axis=1)), "wrong projected bbox"
         proj = np.clip(proj / self._img_size_row()[0], a_min=-1, a_max=2)
         obs = np.full((len(cat), 79), -1.0)
@@ -183,7 +184,7 @@ class OdamProcess:
 
     def _prepare_tracks(self, T_wc, n_times=100):
         cam_azi = get_cam_azi(T_wc)
-        tracks = [t.copy() for t in self.tracks]     # (the reference deep-copies: the projected box is scratch)
+        tracks = self.tracks                         # read-only here (the reference deep-copies and scribbles on the copy)
         # one batched surface evaluation for all tracks (reference: one SuperQuadric + sampler call each);
         # parameters as sq.init_params builds them: mean centre, mean azimuth, sqrt(mean dims / 2), shapes -0
         params = np.zeros((len(tracks), 9))
@@ -204,9 +205,10 @@ class OdamProcess:
             pix = cam @ np.asarray(self.sequence_meta.K).T
             pix = np.ascontiguousarray((pix / pix[..., -1:]).transpose(0, 2, 1))      # [T, 3, 1000]
             lo, hi = pix.min(axis=2), pix.max(axis=2)
-            for idx, track in enumerate(tracks):
-                track[:, -4:] = np.array([[lo[idx, 0], lo[idx, 1], hi[idx, 0], hi[idx, 1]]])
-        in_ = self._preprocess_tracks(tracks, T_wc, cam_azi, n_times)
+            proj_px = np.concatenate([lo[:, :2], hi[:, :2]], axis=1)                  # x_min, y_min, x_max, y_max
+        else:
+            proj_px = np.zeros((0, 4))
+        in_ = self._preprocess_tracks(tracks, T_wc, cam_azi, n_times, proj_px=proj_px)
         return torch.from_numpy(np.ascontiguousarray(in_.transpose(0, 2, 1)))   # [T, 79, n_times], as .permute(0, 2, 1)
 
     def _collater(self, data_list):
