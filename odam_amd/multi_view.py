@@ -156,11 +156,21 @@ class SuperQuadric:
     def params(self):
         return np.concatenate([self.translate, [self.angle], self.scales, self.shapes]).astype(np.float32)
 
+    # run_processor.py:85-92 pickles the result dict; eval_scan2cad.py:191-215 and result_viewer.py:25-43 load it and
+    # call compute_ellipsoid_points.  The device context does not travel: a loaded object without cached points
+    # computes them with the default fitter.
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_fitter"] = None
+        return st
+
+    def __setstate__(self, st):
+        self.__dict__.update(st)
+
     def compute_ellipsoid_points(self, use_numpy=True):
         if self._points is None:
-            if self._fitter is None:
-                raise _sq._lib.OdamError("SuperQuadric has no cached surface and no fitter to compute one")
-            self._points = self._fitter.points(self.params[None])[0].cpu().numpy()
+            fitter = self._fitter or default_fitter()
+            self._points = fitter.points(self.params[None])[0].cpu().numpy()
         return self._points, None
 
 

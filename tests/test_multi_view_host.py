@@ -84,3 +84,23 @@ def test_edge_lines_threshold():
     d = _edge_lines(np.array([[20.0, 25.0], [619.9, 460.0]]), 480, 640)
     assert set(d) == {"y_min", "x_max"}          # x_min == 20 is not > 20; y_max == 460 is not < 460
     assert np.array_equal(d["x_max"], np.array([1, 0, -619.9]))
+
+
+def test_result_objects_pickle_like_the_reference_output():
+    """run_processor.py:85-92 pickles {"tracks", "bboxes_qc", "bboxes_dl", "quadrics"}; the loaded quadrics keep the
+    attributes eval_scan2cad.py / result_viewer.py read and the cached surface points (no device context inside)."""
+    import pickle
+    from odam_amd.multi_view import SuperQuadric
+
+    class _Ctx:            # stands in for a fitter holding a device handle: must not be pickled
+        def __reduce__(self):
+            raise TypeError("device context is not picklable")
+
+    pts = np.arange(3000, dtype=np.float32).reshape(1000, 3)
+    q = SuperQuadric(np.arange(9, dtype=np.float32), 3, pts, _Ctx())
+    out = {"tracks": [np.zeros((2, 82))], "bboxes_qc": [np.zeros((8, 3))], "bboxes_dl": [np.zeros((8, 3))], "quadrics": [q]}
+    back = pickle.loads(pickle.dumps(out))["quadrics"][0]
+    assert np.array_equal(back.translate, q.translate) and back.angle == q.angle and back.obj_class == 3
+    assert np.array_equal(back.scales, q.scales) and np.array_equal(back.shapes, q.shapes)
+    got, nrm = back.compute_ellipsoid_points(use_numpy=True)
+    assert nrm is None and np.array_equal(got, pts)
