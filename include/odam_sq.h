@@ -73,8 +73,15 @@ int odam_sq_fit_batch(odam_sq_ctx* ctx, int n_obj, const float* init_params, con
 /* Surface points of n super-quadrics: params [dev][n][9] -> out_points [dev][n][1000][3]. */
 int odam_sq_points_batch(odam_sq_ctx* ctx, int n, const float* params, float* out_points, void* stream);
 
-/* Host-side sampler with the reference's C signature semantics for B = M = 1, N = 1000,
- * buffer_size = 201, seed = 0:  a[3], e[2] -> etas[1000], omegas[1000]  (all [host]). */
+/* The reference's one native symbol under its own name and signature
+ * (learnable_primitives/fast_sampler/sampling.hpp:5-15; bound by _sampler.pyx:430-439, which passes
+ * buffer_size = 201, seed = 0):  shapes [host][B][M][3], epsilons [host][B][M][2] -> etas, omegas [host][B][M][N].
+ * One std::mt19937(seed) stream over all primitives in (b, m) order.  void, no error path, re-entrant -- as upstream. */
+void sample_on_batch(float* shapes, float* epsilons, float* etas, float* omegas, int B, int M, int N,
+                     int buffer_size, int seed);
+
+/* sample_on_batch for the call the pipeline makes (B = M = 1, N = 1000, buffer_size = 201, seed = 0) with this
+ * library's return-code convention:  a[3], e[2] -> etas[1000], omegas[1000]  (all [host]). */
 int odam_sq_sample(const float* a, const float* e, float* etas, float* omegas);
 
 #ifdef __cplusplus

@@ -93,6 +93,13 @@ class Associator:
     def assignment(self, tracks, detections, n_tracks, n_det):
         """tracks [T,79,100], detections [1,79,30] or [79,30] (any device) -> Z [(T+1),(n_det+1)] device tensor"""
         dev = self.device
+        if n_tracks > self.max_tracks:
+            # the reference has no track limit (associator.py:202-268): the native workspace is sized per handle, so a
+            # scene with more live tracks gets a new handle with twice the room (weights are kept in self._sd)
+            while self.max_tracks < n_tracks:
+                self.max_tracks *= 2
+            torch.cuda.synchronize(dev)
+            self.close()
         tr = tracks.to(dev, torch.float32).contiguous()
         de = detections.to(dev, torch.float32).reshape(79, 30).contiguous()
         Z = torch.empty(n_tracks + 1, n_det + 1, device=dev, dtype=torch.float32)
@@ -120,5 +127,9 @@ class Associator:
 def build(args):
     """src/models/associator.py:330-340"""
     g = (lambda k: args[k]) if isinstance(args, dict) else (lambda k: getattr(args, k))
+    try:
+        max_tracks = int(g("max_tracks"))      # optional: initial workspace size (grows on demand)
+    except (KeyError, AttributeError):
+        max_tracks = 256
     return Associator({"GNN_layers": g("GNN_layers"), "self_GNN_layers": g("self_GNN_layers"),
-                       "sinkhorn_iterations": g("sinkhorn_iterations")})
+                       "sinkhorn_iterations": g("sinkhorn_iterations")}, max_tracks=max_tracks)

@@ -849,48 +849,72 @@ extern "C" int odam_sq_points_batch(odam_sq_ctx* ctx, int n, const float* params
     return launch_fit(ctx, n, A, 1, (hipStream_t)stream);
 }
 
-// host sampler: same leaf arithmetic as the device path, serial walk (sampling.cpp:158-215)
-static void host_subdivide(const Arc& nd, float a1, float a2, float e, float* buf) {
-    if (nd.n <= 0) return;
-    Arc lf, rt;
-    float th;
-    int slot = arc_step(nd, a1, a2, e, th, lf, rt);
-    buf[slot] = th;
-    host_subdivide(lf, a1, a2, e, buf);
-    host_subdivide(rt, a1, a2, e, buf);
-}
-
-static void host_buffer(float a1, float a2, float e, float ta, float tb, float* buf) {
+// host sampler: same leaf arithmetic as the device path, serial walk with an explicit work list
+// (sampling.cpp:76-125; the order in which pending arcs are visited does not matter -- every arc fills its own slot)
+static void host_buffer(float a1, float a2, float e, float ta, float tb, float* buf, int nbuf, std::vector<Arc>& work) {
     Arc root;
     xy(ta, a1, a2, e, root.ax, root.ay);
     xy(tb, a1, a2, e, root.bx, root.by);
-    root.ta = ta; root.tb = tb; root.n = BUF - 2; root.off = 1;
+    root.ta = ta; root.tb = tb; root.n = nbuf - 2; root.off = 1;
     buf[0] = ta;
-    host_subdivide(root, a1, a2, e, buf);
-    buf[BUF - 1] = tb;
+    work.clear();
+    work.push_back(root);
+    while (!work.empty()) {
+        const Arc nd = work.back();
+        work.pop_back();
+        if (nd.n <= 0) continue;
+        Arc lf, rt;
+        float th;
+        const int slot = arc_step(nd, a1, a2, e, th, lf, rt);
+        buf[slot] = th;
+        work.push_back(lf);
+        work.push_back(rt);
+    }
+    buf[nbuf - 1] = tb;
 }
 
+// The reference's one native symbol, with its exact signature (fast_sampler/sampling.hpp:5-15, bound by
+// _sampler.pyx:430-439): B x M primitives, N samples each, `buffer_size` equal-arc-length angles per curve, one
+// std::mt19937(seed) stream shared by all primitives in (b, m) order -- N draws for the etas, then N for the omegas.
+// Host buffers in, host buffers out, no error path (void), re-entrant.
+extern "C" void sample_on_batch(float* shapes, float* epsilons, float* etas, float* omegas, int B, int M, int N,
+                                int buffer_size, int seed) {
+    if (!shapes || !epsilons || !etas || !omegas || B <= 0 || M <= 0 || N <= 0 || buffer_size < 2) return;
+    std::mt19937 gen(seed);                                  // sampling.cpp:18-28
+    std::uniform_real_distribution<float> dis(0, 1);
+    std::vector<float> buf(buffer_size), cdf(buffer_size);
+    std::vector<Arc> work;
+    for (long p = 0; p < (long)B * M; p++) {
+        const float* a = shapes + 3 * p;
+        const float* e = epsilons + 2 * p;
+        float* eta = etas + (long)N * p;
+        float* omega = omegas + (long)N * p;
+        host_buffer(a[0], a[2], e[0], PI_F / 2, -(PI_F / 2), buf.data(), buffer_size, work);
+        float c = 0.001f;                                    // sampling.cpp:137-147
+        cdf[0] = c;
+        for (int i = 1; i < buffer_size; i++) {
+            c = c + 0.001f + (a[0] + a[1]) * fexp(cosf_(buf[i]), e[0]);
+            cdf[i] = c;
+        }
+        for (int i = 0; i < buffer_size; i++) cdf[i] = cdf[i] / c;
+        for (int i = 0; i < N; i++) {                        // first entry not below the draw (sampling.cpp:150-153)
+            const float r = dis(gen);
+            int lo = 0, hi = buffer_size;
+            while (lo < hi) {
+                int mid = lo + ((hi - lo) >> 1);
+                if (cdf[mid] < r) lo = mid + 1; else hi = mid;
+            }
+            eta[i] = buf[lo < buffer_size ? lo : buffer_size - 1];
+        }
+        host_buffer(a[0], a[1], e[1], PI_F, -PI_F, buf.data(), buffer_size, work);
+        for (int i = 0; i < N; i++) omega[i] = buf[(int)(dis(gen) * (float)buffer_size)];   // sampling.cpp:210-212
+    }
+}
+
+// the call the reference's binding makes (_sampler.pyx:415-441: B = M = 1 per optimiser step, buffer 201, seed 0)
 extern "C" int odam_sq_sample(const float* a, const float* e, float* etas, float* omegas) {
     if (!a || !e || !etas || !omegas) return odam_fail(ODAM_E_INVALID, "odam_sq_sample: null pointer");
-    static const std::vector<float> draws = sampler_draws();
-    float buf[BUF], cdf[BUF];
-    host_buffer(a[0], a[2], e[0], PI_F / 2, -(PI_F / 2), buf);
-    float c = 0.001f;
-    cdf[0] = c;
-    for (int i = 1; i < BUF; i++) {
-        c = c + 0.001f + (a[0] + a[1]) * fexp(cosf_(buf[i]), e[0]);
-        cdf[i] = c;
-    }
-    for (int i = 0; i < BUF; i++) cdf[i] = cdf[i] / c;
-    for (int i = 0; i < N_PTS; i++) {
-        int lo = 0, hi = BUF;
-        while (lo < hi) {
-            int mid = lo + ((hi - lo) >> 1);
-            if (cdf[mid] < draws[i]) lo = mid + 1; else hi = mid;
-        }
-        etas[i] = buf[lo];
-    }
-    host_buffer(a[0], a[1], e[1], PI_F, -PI_F, buf);
-    for (int i = 0; i < N_PTS; i++) omegas[i] = buf[(int)(draws[N_PTS + i] * (float)BUF)];
+    float aa[3] = {a[0], a[1], a[2]}, ee[2] = {e[0], e[1]};
+    sample_on_batch(aa, ee, etas, omegas, 1, 1, N_PTS, BUF, 0);
     return ODAM_OK;
 }

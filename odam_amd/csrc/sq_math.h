@@ -11,6 +11,25 @@
 // against the host libm on the CPU build of this very header.
 //
 // Everything is written with explicit operation order; compile with -ffp-contract=off.
+//
+// Provenance of the algorithms and constants (polynomial coefficients, table construction, range reduction): the
+// single-precision routines of Arm Optimized Routines (sinf, cosf, powf, expf, logf), which glibc adopted in 2.28.
+// Upstream notice of that project:
+//
+//   Copyright (c) 1999-2019, Arm Limited.
+//   SPDX-License-Identifier: MIT
+//
+//   Permission is hereby granted, free of charge, to any person obtaining a copy of this software and associated
+//   documentation files (the "Software"), to deal in the Software without restriction, including without limitation
+//   the rights to use, copy, modify, merge, publish, distribute, sublicense, and/or sell copies of the Software, and to
+//   permit persons to whom the Software is furnished to do so, subject to the following conditions:
+//   The above copyright notice and this permission notice shall be included in all copies or substantial portions of
+//   the Software.
+//   THE SOFTWARE IS PROVIDED "AS IS", WITHOUT WARRANTY OF ANY KIND, EXPRESS OR IMPLIED, INCLUDING BUT NOT LIMITED TO
+//   THE WARRANTIES OF MERCHANTABILITY, FITNESS FOR A PARTICULAR PURPOSE AND NONINFRINGEMENT. IN NO EVENT SHALL THE
+//   AUTHORS OR COPYRIGHT HOLDERS BE LIABLE FOR ANY CLAIM, DAMAGES OR OTHER LIABILITY, WHETHER IN AN ACTION OF CONTRACT,
+//   TORT OR OTHERWISE, ARISING FROM, OUT OF OR IN CONNECTION WITH THE SOFTWARE OR THE USE OR OTHER DEALINGS IN THE
+//   SOFTWARE.
 #pragma once
 #include <stdint.h>
 

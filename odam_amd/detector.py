@@ -64,7 +64,13 @@ class Detector:
 
     # ---- nn.Module-like surface used by run_processor.py:30-34 -------------------------------------
     def to(self, device):
-        self.device = torch.device("cuda:0" if str(device) == "cuda" else device)
+        new = torch.device("cuda:0" if str(device) == "cuda" else device)
+        if new != self.device:
+            self.close()          # handles, streams and scratch belong to the old device
+            for name in ("_streams", "_mscratch", "_xform", "_stage", "_copy_stream", "_pinned"):
+                if hasattr(self, name):
+                    setattr(self, name, None)
+        self.device = new
         return self
 
     def cuda(self):
@@ -341,7 +347,7 @@ class Detector:
                 events.append((c0, c1, ev))
         for c0, c1, ev in events:
             ev.synchronize()
-            yield c0, host[c0:c1].numpy()
+            yield c0, host[c0:c1].numpy().copy()   # the pinned buffer is reused by the next call: rows leave as a copy
 
     def profile(self, H, W, on):
         _lib.check(_lib.lib().odam_detr_profile_enable(self._handle(H, W), ctypes.c_int(int(on))), "profile_enable")

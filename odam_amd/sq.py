@@ -8,6 +8,7 @@ Mirrors the pieces of the reference (likojack/ODAM) that sit around SuperQuadric
 import ctypes
 import os
 import pickle
+import threading
 
 import numpy as np
 import torch
@@ -75,6 +76,13 @@ class SqFitter:
             _lib.check(L.odam_sq_create(ctypes.c_int(self.max_iters), ctypes.byref(h)), "odam_sq_create")
         self._h = h
         self._prior = None
+        # The native handle serves ONE launch at a time (include/odam_sq.h): its view-split exchange buffer is per
+        # handle.  The lock serialises host threads; launches from different streams are additionally ordered by an
+        # event so that a second fit cannot start writing exchange slots while the first still polls them.
+        self._lock = threading.Lock()
+        self._last = None          # (stream id, event) of the most recent launch
+        with torch.cuda.device(self.device):
+            self.n_cu = int(torch.cuda.get_device_properties(self.device).multi_processor_count)
 
     def close(self):
         if getattr(self, "_h", None):
@@ -123,7 +131,7 @@ class SqFitter:
         groups = [np.flatnonzero(~big)] if (~big).any() else []
         for k in sorted(set(need[big].tolist())):
             idx = np.flatnonzero(need == k)
-            per = max(8, (256 // k) // 8 * 8)                  # padded object count x k <= 256 CUs
+            per = max(8, (self.n_cu // k) // 8 * 8)            # padded object count x k <= number of CUs
             groups += [idx[i:i + per] for i in range(0, len(idx), per)]
         outs = {}
         for g in groups:
@@ -169,14 +177,20 @@ class SqFitter:
         out_pts = torch.empty(n, N_POINTS, 3, device=dev, dtype=torch.float32) if want_points else None
         loss = torch.empty(n, n_iters, device=dev, dtype=torch.float32) if want_loss else None
         traj = torch.empty(n, n_iters, 9, device=dev, dtype=torch.float32) if want_traj else None
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), self._lock:
+            cur = torch.cuda.current_stream(dev)
+            stream = cur.cuda_stream
+            if self._last is not None and self._last[0] != stream:
+                cur.wait_event(self._last[1])     # the handle's previous launch ran on another stream: order behind it
             _lib.check(_lib.lib().odam_sq_fit_batch(
                 self._h, ctypes.c_int(n), _lib.ptr(d_p0), _lib.ptr(d_cls), _lib.ptr(d_off), _lib.ptr(d_P),
                 _lib.ptr(d_t), _lib.ptr(d_m), _lib.ptr(self._prior_dev()), ctypes.c_int(int(n_iters)),
                 ctypes.c_int(REPRESENTATIONS[representation]), ctypes.c_int(int(vc.max())),
                 _lib.ptr(out_p), _lib.ptr(out_pts), _lib.ptr(loss), _lib.ptr(traj),
                 ctypes.c_void_p(stream)), "odam_sq_fit_batch")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._last = (stream, ev)
         return {"params": out_p, "points": out_pts, "loss": loss, "traj": traj}
 
     def points(self, params):
@@ -186,10 +200,16 @@ class SqFitter:
             device=dev, dtype=torch.float32).reshape(-1, 9).contiguous()
         n = d_p.shape[0]
         out = torch.empty(n, N_POINTS, 3, device=dev, dtype=torch.float32)
-        stream = torch.cuda.current_stream(dev).cuda_stream
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), self._lock:
+            cur = torch.cuda.current_stream(dev)
+            stream = cur.cuda_stream
+            if self._last is not None and self._last[0] != stream:
+                cur.wait_event(self._last[1])
             _lib.check(_lib.lib().odam_sq_points_batch(self._h, ctypes.c_int(n), _lib.ptr(d_p), _lib.ptr(out),
                                                        ctypes.c_void_p(stream)), "odam_sq_points_batch")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            self._last = (stream, ev)
         return out
 
 
