@@ -110,6 +110,9 @@ int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const float* scal
 int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* scale, const float* bias,
                              const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, int Kpad, int relu, int out_f32, int k_order, void* stream);
+/* which layers the bf16-native 256-row schedule of the contraction kernel takes: 0 none, 1 those large enough to fill
+ * the device (default), 2 every eligible layer (parity tests on small shapes).  Process-wide; also ODAM_CG_BIG. */
+int odam_op_conv_bf16_mode(int mode);
 int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                       int B, int H, int Lq, int Lk, void* stream);
 int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y, int M,

@@ -49,4 +49,8 @@ struct ConvGemmArgs {
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 
+// experiments / tests: 0 = never use the bf16-native 256-row kernel, 1 = when the problem is large enough (default),
+// 2 = whenever the layer is eligible (any size).  Also read once from ODAM_CG_BIG.
+void set_big_mode(int mode);
+
 }  // namespace odam_cg

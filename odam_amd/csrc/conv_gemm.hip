@@ -39,6 +39,182 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, unsigne
                  : "memory");
 }
 
+// ---- epilogue shared by the kernels below: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------
+// acc[i][j] is the wave's (i, j)-th 32x32 accumulator tile of its (BM / WM) x (BN / WN) sub-tile; `smem` (at least
+// WM * WN * 32 * (BN / WN) floats, free after the K loop) is used to turn the sub-tile for wide stores.
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool BF16>
+__device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[TM][TN], float* smem, int smem_floats,
+                                         int m0, int n0, int wm, int wn, int wave, int lane) {
+    // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
+    // bf16 mode: residual and output are bf16 unless out_f32 asks for an fp32 result (the prediction heads).
+    const int half = lane >> 5;
+    const bool res_f32 = !BF16;
+    const bool out_f32 = !BF16 || a.out_f32;
+    auto load_res1 = [&](size_t idx) -> float {
+        return res_f32 ? reinterpret_cast<const float*>(a.res)[idx]
+                       : bf2f(reinterpret_cast<const unsigned short*>(a.res)[idx]);
+    };
+    auto store1 = [&](size_t idx, float v) {
+        if (out_f32) reinterpret_cast<float*>(a.C)[idx] = v;
+        else reinterpret_cast<unsigned short*>(a.C)[idx] = f2bf(v);
+    };
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;   // this wave's sub-tile
+    if constexpr (BF16) {
+        if (!a.out_f32 && (a.Cout & 7) == 0 && (a.ldc & 7) == 0) {
+            // bf16 output: 8 channels per lane, so that residual loads and stores are 16 bytes per lane (the 8-byte form
+            // of the path below moves bytes at 0.55-0.7 of the rate: the wide expand + residual layers are HBM-bound)
+            float* Ep = smem + wave * (32 * WCOLS);
+            constexpr int LPR = WCOLS / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+            const int c8e = (lane % LPR) * 8;
+            const int n = n0 + wn * WCOLS + c8e;
+            const bool n_ok = n < a.Cout;
+            float sc[8], bi[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) { sc[c] = (n_ok && a.scale) ? a.scale[n + c] : 1.f; bi[c] = (n_ok && a.bias) ? a.bias[n + c] : 0.f; }
+            const unsigned short* resp = reinterpret_cast<const unsigned short*>(a.res);
+            unsigned short* outp = reinterpret_cast<unsigned short*>(a.C);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                uint4 rv[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
+                    rv[it] = uint4{0u, 0u, 0u, 0u};
+                    if (a.res && n_ok && m < a.M) rv[it] = *reinterpret_cast<const uint4*>(resp + (size_t)m * a.ldc + n);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * WCOLS + j * 32 + (lane & 31)] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int row = it * RPI + lane / LPR;
+                    const int m = m0 + wm * WROWS + i * 32 + row;
+                    const float4 v0 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c8e]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c8e + 4]);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    const unsigned rw[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+                    unsigned ow[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        float lo = v[2 * c] * sc[2 * c] + bi[2 * c], hi = v[2 * c + 1] * sc[2 * c + 1] + bi[2 * c + 1];
+                        lo += __builtin_bit_cast(float, rw[c] << 16);
+                        hi += __builtin_bit_cast(float, rw[c] & 0xffff0000u);
+                        if (a.relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+                        ow[c] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                    }
+                    if (n_ok && m < a.M) *reinterpret_cast<uint4*>(outp + (size_t)m * a.ldc + n) = uint4{ow[0], ow[1], ow[2], ow[3]};
+                }
+            }
+            return;
+        }
+    }
+    if ((a.Cout & 3) == 0 && (a.ldc & 3) == 0) {
+        // Wide path: the accumulator layout (one column per lane) would give 4-byte accesses; the sub-tile is
+        // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
+        // 16-byte (fp32) / 8-byte (bf16) residual loads and stores, 256 / 128 contiguous bytes per 16 lanes.
+        // Unpadded rows: a wave writes 32 consecutive floats of one row per half (ds_write_b32: conflict-free), and
+        // the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) land on 16 distinct 16-byte slots for both
+        // 128-byte and 256-byte rows.
+        constexpr int EP_LD = WCOLS;
+        (void)smem_floats;
+        float* Ep = smem + wave * (32 * EP_LD);     // one 32-row slab per wave, reused for each of its TM row tiles
+        constexpr int LPR = WCOLS / 4;              // lanes per row
+        constexpr int RPI = 64 / LPR;               // rows per wave-instruction
+        constexpr int NIT = 32 / RPI;
+        const int c4e = (lane % LPR) * 4;
+        const int n = n0 + wn * WCOLS + c4e;
+        const bool n_ok = n < a.Cout;               // Cout % 4 == 0: the four channels are in or out together
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+        if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            float4 rv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {   // residual rows of this slab: issued before the LDS round trip
+                const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
+                rv[it] = float4{0.f, 0.f, 0.f, 0.f};
+                if (a.res && n_ok && m < a.M) {
+                    const size_t idx = (size_t)m * a.ldc + n;
+                    if (res_f32) {
+                        rv[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + idx);
+                    } else {
+                        const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(a.res) + idx);
+                        rv[it] = float4{bf2f(u.x), bf2f(u.y), bf2f(u.z), bf2f(u.w)};
+                    }
+                }
+            }
+            // The slab is private to this wavefront and a wavefront's LDS operations execute in order, so the
+            // transposition needs no workgroup barrier (the K loop ended with one): waves store as soon as they are done.
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int row = it * RPI + lane / LPR;
+                const int m = m0 + wm * WROWS + i * 32 + row;
+                const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
+                float4 o;
+                o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
+                o.x += rv[it].x; o.y += rv[it].y; o.z += rv[it].z; o.w += rv[it].w;
+                if (a.relu) {
+                    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                    o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                }
+                if (n_ok && m < a.M && (!(CG_ABLATE & 8) || o.x == 12345.678f)) {   // 8: (almost) never store
+                    const size_t idx = (size_t)m * a.ldc + n;
+                    if (out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + idx) = o;
+                    } else {
+                        ushort4 u = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+                        *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + idx) = u;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // Narrow path (channel counts that are not a multiple of 4: the prediction heads): residual values of a
+    // whole 32x32 tile are fetched first, then combined and stored.
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        const bool n_ok = n < a.Cout;
+        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
+        const float bi = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mb = m0 + wm * (BM / WM) + i * 32 + 4 * half;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                rv[r] = (a.res && n_ok && m < a.M) ? load_res1((size_t)m * a.ldc + n) : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * sc + bi;
+                v += rv[r];
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                if (n_ok && m < a.M) store1((size_t)m * a.ldc + n, v);
+            }
+        }
+    }
+}
+
 // NST: LDS stages.  2 = one tile in flight under the tile being multiplied (two workgroups per CU hide the rest).
 // 4 (UT only; small, latency-bound problems that leave most CUs with one workgroup): three tiles in flight, retired
 // with a counted s_waitcnt so the DMA queue stays full across the per-tile barrier.
@@ -313,119 +489,211 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         __syncthreads();   // the last stage is fully read before the epilogue reuses the tile buffers
     }
 
-    // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
-    // bf16 mode: residual and output are bf16 unless out_f32 asks for an fp32 result (the prediction heads).
-    const int half = lane >> 5;
-    const bool res_f32 = !BF16;
-    const bool out_f32 = !BF16 || a.out_f32;
-    auto load_res1 = [&](size_t idx) -> float {
-        return res_f32 ? reinterpret_cast<const float*>(a.res)[idx]
-                       : bf2f(reinterpret_cast<const unsigned short*>(a.res)[idx]);
-    };
-    auto store1 = [&](size_t idx, float v) {
-        if (out_f32) reinterpret_cast<float*>(a.C)[idx] = v;
-        else reinterpret_cast<unsigned short*>(a.C)[idx] = f2bf(v);
-    };
-    constexpr int WROWS = BM / WM, WCOLS = BN / WN;   // this wave's sub-tile
-    if ((a.Cout & 3) == 0 && (a.ldc & 3) == 0) {
-        // Wide path: the accumulator layout (one column per lane) would give 4-byte accesses; the sub-tile is
-        // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
-        // 16-byte (fp32) / 8-byte (bf16) residual loads and stores, 256 / 128 contiguous bytes per 16 lanes.
-        // Unpadded rows: a wave writes 32 consecutive floats of one row per half (ds_write_b32: conflict-free), and
-        // the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) land on 16 distinct 16-byte slots for both
-        // 128-byte and 256-byte rows.
-        constexpr int EP_LD = WCOLS;
-        static_assert(WM * WN * 32 * EP_LD <= NST * (BM + BN) * LDS_LD, "epilogue staging fits the tile buffers");
-        float* Ep = smem + wave * (32 * EP_LD);     // one 32-row slab per wave, reused for each of its TM row tiles
-        constexpr int LPR = WCOLS / 4;              // lanes per row
-        constexpr int RPI = 64 / LPR;               // rows per wave-instruction
-        constexpr int NIT = 32 / RPI;
-        const int c4e = (lane % LPR) * 4;
-        const int n = n0 + wn * WCOLS + c4e;
-        const bool n_ok = n < a.Cout;               // Cout % 4 == 0: the four channels are in or out together
-        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
-        if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            float4 rv[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {   // residual rows of this slab: issued before the LDS round trip
-                const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
-                rv[it] = float4{0.f, 0.f, 0.f, 0.f};
-                if (a.res && n_ok && m < a.M) {
-                    const size_t idx = (size_t)m * a.ldc + n;
-                    if (res_f32) {
-                        rv[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + idx);
-                    } else {
-                        const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(a.res) + idx);
-                        rv[it] = float4{bf2f(u.x), bf2f(u.y), bf2f(u.z), bf2f(u.w)};
-                    }
-                }
-            }
-            // The slab is private to this wavefront and a wavefront's LDS operations execute in order, so the
-            // transposition needs no workgroup barrier (the K loop ended with one): waves store as soon as they are done.
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < TN; j++)
-#pragma unroll
-                for (int r = 0; r < 16; r++)
-                    Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int row = it * RPI + lane / LPR;
-                const int m = m0 + wm * WROWS + i * 32 + row;
-                const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
-                float4 o;
-                o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
-                o.x += rv[it].x; o.y += rv[it].y; o.z += rv[it].z; o.w += rv[it].w;
-                if (a.relu) {
-                    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-                    o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
-                }
-                if (n_ok && m < a.M && (!(CG_ABLATE & 8) || o.x == 12345.678f)) {   // 8: (almost) never store
-                    const size_t idx = (size_t)m * a.ldc + n;
-                    if (out_f32) {
-                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + idx) = o;
-                    } else {
-                        ushort4 u = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
-                        *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + idx) = u;
-                    }
-                }
-            }
-        }
-        return;
+    static_assert(WM * WN * 32 * (BN / WN) <= NST * (BM + BN) * LDS_LD, "epilogue staging fits the tile buffers");
+    epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, (int)sizeof(smem) / 4, m0, n0, wm, wn, wave, lane);
+}
+
+
+// ---- bf16-native schedule (BASELINE config 4) ---------------------------------------------------------------------
+// The kernel above was laid out for the fp32 matrix instruction (64 cycles per 32x32x2 step): on v_mfma_f32_32x32x16_bf16
+// the same tile spends 8x less time in the matrix pipe per k-tile while its LDS fragment reads (12 ds_read_b128 per 8
+// MFMAs per wave), DMA issue and barrier stay -- it ends LDS-bound at ~0.14 of the bf16 peak.  This kernel is sized for
+// the bf16 rate instead:
+//   * 256 x BN output tile (BN = 256 or 128), eight waves, ONE workgroup per CU; a wave owns 128x64 (BN = 256) or 64x64
+//     (BN = 128) of it, i.e. 0.75 / 1.0 fragment reads per MFMA instead of 1.5, and a quarter / half of the DMA
+//     instructions per MFMA;
+//   * k-tile of 32 bf16 (64-byte LDS rows) in an NST-deep ring (4 x 32 KiB for BN = 256): NST - 1 tiles are in flight
+//     by LDS-DMA at any time, retired with a counted s_waitcnt -- vmcnt never drains inside the loop -- and one raw
+//     s_barrier per k-tile (16 / 8 MFMAs per wave between barriers);
+//   * 64-byte rows: chunk c of row r sits at c ^ ((r >> 2) & 3) -- the 16-lane groups of ds_read_b128
+//     ({0-3,12-15,20-27}, ...) then touch rows whose (r >> 2) & 3 are all different inside each set of rows that share
+//     bank range (r & 3), i.e. 16 distinct 16-byte slots: conflict-free; the DMA writes lane-linearly, so the
+//     permutation is applied to its source address (lane l -> row l >> 2, chunk (l & 3) ^ ((l >> 4) & 3)).
+// Gather, epilogue, XCD-aware tile order and numerics (fp32 accumulate, k-ordered inside a k-step) are the ones above.
+template <int BN, int NST>
+__global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(ConvGemmArgs a) {
+    using T = unsigned short;
+    constexpr int BM = 256, BKE = 32, NTH = 512;
+    constexpr int WM = BN == 256 ? 2 : 4, WN = BN == 256 ? 4 : 2;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RPP = NTH / 4;            // 128 tile rows per DMA pass (4 chunks of 16 bytes per row)
+    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+    constexpr int ROWB = 64;                // bytes per LDS row
+    constexpr int STAGE = (BM + BN) * ROWB; // bytes per ring stage
+    constexpr int LPT = A_LD + B_LD;        // DMA instructions per thread per tile
+    extern __shared__ __align__(16) float smem[];   // NST * STAGE bytes (dynamic: 96 / 128 KiB)
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const T* __restrict__ Ag = reinterpret_cast<const T*>(a.A);
+    const T* __restrict__ Wg = reinterpret_cast<const T*>(a.Wt);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int tiles_n = (a.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    // Narrow path (channel counts that are not a multiple of 4: the prediction heads): residual values of a
-    // whole 32x32 tile are fetched first, then combined and stored.
+    const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- gather bookkeeping (uniform-tap path of the kernel above) -------------------------------------------------
+    const int c4 = tid & 3, r0 = tid >> 2;
+    const int hw = a.Ho * a.Wo;
+    const int lda = a.lda > 0 ? a.lda : a.Cin;
+    const bool plain = a.KH * a.KW == 1 && a.stride == 1 && a.pad == 0;
+    const int ntaps = a.KH * a.KW;
+    const int kw_inv = (65536 + a.KW - 1) / a.KW;
+    const int nt_inv = (65536 + ntaps - 1) / ntaps;
+    const int b0 = m0 / hw;
+    const int csrc = c4 ^ ((lane >> 4) & 3);
+    const int margin = (a.pad * a.W + a.pad) * lda;
+    const unsigned long long pa = (unsigned long long)(Ag + (size_t)b0 * a.H * a.W * lda - margin), pw = (unsigned long long)Wg;
+    const u32x4 a_rs4 = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    const u32x4 w_rs4 = u32x4{(unsigned)pw, (unsigned)(pw >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    unsigned a_voff[A_LD], a_mask[A_LD], w_voff[B_LD];
 #pragma unroll
-    for (int j = 0; j < TN; j++) {
-        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-        const bool n_ok = n < a.Cout;
-        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
-        const float bi = (a.bias && n_ok) ? a.bias[n] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-            const int mb = m0 + wm * (BM / WM) + i * 32 + 4 * half;
-            float rv[16];
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                rv[r] = (a.res && n_ok && m < a.M) ? load_res1((size_t)m * a.ldc + n) : 0.0f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int m = mb + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r] * sc + bi;
-                v += rv[r];
-                if (a.relu) v = v > 0.0f ? v : 0.0f;
-                if (n_ok && m < a.M) store1((size_t)m * a.ldc + n, v);
-            }
+    for (int i = 0; i < A_LD; i++) {
+        const int m = m0 + r0 + RPP * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        int base, iy0 = 0, ix0 = 0;
+        if (plain) {
+            base = mm * lda;
+        } else {
+            const int b = mm / hw, rem = mm - b * hw, oy = rem / a.Wo, ox = rem - oy * a.Wo;
+            iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
+            base = ((b * a.H + iy0) * a.W + ix0) * lda;
         }
+        a_voff[i] = (unsigned)(base - b0 * a.H * a.W * lda + margin + csrc * 8) * 2u;
+        unsigned mk = plain ? 1u : 0u;
+        for (int t = 0; t < (plain ? 0 : ntaps); t++) {
+            const int ky = (t * kw_inv) >> 16, kx = t - ky * a.KW;
+            if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W) mk |= 1u << t;
+        }
+        a_mask[i] = ok ? mk : 0u;
     }
+#pragma unroll
+    for (int i = 0; i < B_LD; i++) {
+        const int n = n0 + r0 + RPP * i;
+        w_voff[i] = n < a.Cout ? (unsigned)(n * a.Kpad + csrc * 8) * 2u : OOB_VOFF;
+    }
+    const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    auto load_tile = [&](int kt, int st) {
+        int tap, cbase;
+        if (a.k_order) {   // chunk-major K in units of 64 channels (conv_gemm.h): kt / 2 = chunk * ntaps + tap
+            const int k64 = kt >> 1, chunk = (k64 * nt_inv) >> 16;
+            tap = k64 - chunk * ntaps;
+            cbase = chunk * 64 + (kt & 1) * 32;
+        } else {
+            const int kb = kt * BKE;
+            tap = kb >> a.log2Cin;
+            cbase = kb & (a.Cin - 1);
+        }
+        const int ky = (tap * kw_inv) >> 16, kx = tap - ky * a.KW;
+        const int soff = ((ky * a.W + kx) * lda + cbase) * 2;
+        const unsigned sb = lds_base + (unsigned)(st * STAGE + wave_u * 16 * ROWB);
+#pragma unroll
+        for (int i = 0; i < A_LD; i++) {
+            const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB_VOFF;
+            lds_dma16(a_rs4, sb + (unsigned)(RPP * i * ROWB), vo, soff);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; i++)
+            lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), w_voff[i], kt * BKE * 2);
+    };
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+
+    // fragment addresses: lane (row = lane & 31, half = lane >> 5) reads chunk 2 s + half of its row for k-step s
+    const int frow = lane & 31;
+    const int fsw = (frow >> 2) & 3;
+    const char* lds_c = reinterpret_cast<const char*>(smem);
+    const int a_off = (wm * (BM / WM) + frow) * ROWB;
+    const int b_off = (BM + wn * (BN / WN) + frow) * ROWB;
+    int fq[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) fq[q] = ((2 * q + (lane >> 5)) ^ fsw) * 16;
+
+    auto mma_tile = [&](int st, auto&& issue_next) {
+        const char* Ab = lds_c + st * STAGE + a_off;
+        const char* Bb = lds_c + st * STAGE + b_off;
+        float4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[0]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[0]);
+        issue_next();
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[1]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[1]);
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
+                                                                        __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
+    };
+
+    const int nk = a.Kpad / BKE;
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; s0++)
+        if (s0 < nk) load_tile(s0, s0);
+    int st = 0, st_next = NST - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        // my DMAs retire in order: at most (NST - 2) tiles' worth outstanding = my part of tile kt has landed; the
+        // barrier extends that to every wave and says ring slot (kt - 1) % NST has been read by all (it is refilled next)
+        if (kt + NST - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        mma_tile(st, [&] { if (kt + NST - 1 < nk) load_tile(kt + NST - 1, st_next); });
+        st = st + 1 == NST ? 0 : st + 1;
+        st_next = st_next + 1 == NST ? 0 : st_next + 1;
+    }
+    __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
+    static_assert(WM * WN * 32 * (BN / WN) * 4 <= NST * STAGE, "epilogue staging fits the ring");
+    epilogue<BM, BN, WM, WN, TM, TN, true>(a, acc, smem, NST * STAGE / 4, m0, n0, wm, wn, wave, lane);
+}
+
+template <int BN, int NST>
+static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
+    constexpr int bytes = NST * (256 + BN) * 64;
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)conv_gemm_bf16_kernel<BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    }();
+    if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
+    const int tiles = ((a.M + 255) / 256) * ((a.Cout + BN - 1) / BN);
+    hipLaunchKernelGGL((conv_gemm_bf16_kernel<BN, NST>), dim3(tiles), dim3(512), bytes, stream, a);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+static int g_big_mode = getenv("ODAM_CG_BIG") ? atoi(getenv("ODAM_CG_BIG")) : 1;   // 0 off, 1 auto, 2 whenever eligible
+void set_big_mode(int mode) { g_big_mode = mode; }
+
+// the bf16-native kernel takes a layer when its gather is uniform-tap at k-tile 32 and the problem is large enough
+// to give every CU a 256-row tile with a K loop worth pipelining
+static bool big_eligible(const ConvGemmArgs& a, int bn) {
+    if (a.dtype != ODAM_CG_BF16 || a.Cin % 32 != 0 || a.KH * a.KW > 32 || a.Kpad % 32 != 0) return false;
+    if (a.k_order && a.Cin % 64 != 0) return false;
+    const long lda = a.lda > 0 ? a.lda : a.Cin;
+    const long span = (256L / ((long)a.Ho * a.Wo) + 2) * a.H * a.W * lda + (long)(a.pad * a.W + a.pad) * lda + a.Cin;
+    if (span * 2 >= 0x7fffffffL || (long)a.Cout * a.Kpad * 2 >= 0x7fffffffL) return false;
+    if (g_big_mode >= 2) return true;
+    const long tiles = (long)((a.M + 255) / 256) * ((a.Cout + bn - 1) / bn);
+    return a.Kpad >= 512 && tiles >= 192 && a.Cout >= bn;
 }
 
 template <int BM, int BN, int WM, int WN, int NST_UT = 2>
@@ -458,6 +726,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (a.k_order && (a.Cin % (8 * epc) != 0 || a.KH * a.KW > 32 || a.Kpad / (8 * epc) >= 2048))
         return odam_fail(1, "conv_gemm: k_order 1 needs Cin % k-tile == 0, at most 32 taps, fewer than 2048 k-tiles");
     if (a.M <= 0 || a.Cout <= 0) return 0;
+    if (g_big_mode) {
+        if (a.Cout % 256 == 0 || a.Cout >= 384) { if (big_eligible(a, 256)) return launch_big<256, 4>(a, stream); }
+        else if (a.Cout > 64 && g_big_mode >= 2 && big_eligible(a, 128)) return launch_big<128, 4>(a, stream);   // measured slower than the 128x128 tiles: tests only
+    }
     static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 7;  // 8-wave tiles (+2-3 %)
     static const int force = getenv("ODAM_CG_FORCE") ? atoi(getenv("ODAM_CG_FORCE")) : 0;   // experiments: pin one tile shape
     if (force == 1) return launch_cfg<128, 64, 4, 2>(a, stream);

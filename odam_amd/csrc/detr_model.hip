@@ -562,6 +562,13 @@ extern "C" int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, con
     return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream, 1, out_f32);
 }
 
+// experiment switch of the bf16-native contraction kernel (conv_gemm.h set_big_mode): 0 off, 1 auto, 2 whenever eligible
+extern "C" int odam_op_conv_bf16_mode(int mode) {
+    if (mode < 0 || mode > 2) return odam_fail(1, "odam_op_conv_bf16_mode: mode must be 0, 1 or 2");
+    odam_cg::set_big_mode(mode);
+    return 0;
+}
+
 extern "C" int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                                  int ldo, int B, int H, int Lq, int Lk, void* stream) {
     if (!Q || !K || !V || !O) return odam_fail(1, "odam_op_attention: null pointer");

@@ -91,17 +91,32 @@ def make_sq_problem(n_views, seed, K=K_SCANNET, img_w=IMG_W, img_h=IMG_H, noise_
     }
 
 
-def make_frames(n, h=IMG_H, w=IMG_W, seed=0):
-    """uint8 RGB frames: smooth low-frequency pattern + uniform noise (generator, one frame at a time)"""
+def make_frames(n, h=IMG_H, w=IMG_W, seed=0, sweep=1.0, noise=24):
+    """uint8 RGB frames: smooth low-frequency pattern + uniform noise (generator, one frame at a time).
+    `sweep`: fraction of a full period the pattern's phase moves over the n frames; `noise`: amplitude of the
+    per-pixel noise (a slowly moving, low-noise stream gives consecutive frames similar detections)"""
     rs = np.random.RandomState(seed)
     yy, xx = np.mgrid[0:h, 0:w]
     for i in range(n):
-        ph = 2 * np.pi * i / max(n, 1)
+        ph = 2 * np.pi * sweep * i / max(n, 1)
         base = np.stack([127 + 90 * np.sin(xx / 97.0 + ph) * np.cos(yy / 61.0),
                          127 + 90 * np.sin(xx / 53.0 - ph) * np.sin(yy / 89.0 + ph),
                          127 + 90 * np.cos(xx / 71.0 + yy / 43.0 + ph)], -1)
-        img = base + rs.randint(-24, 25, size=(h, w, 3))
+        img = base + rs.randint(-noise, noise + 1, size=(h, w, 3))
         yield np.clip(img, 0, 255).astype(np.uint8)
+
+
+def make_sequence(n=40, h=256, w=320, seed=0, sweep=0.08, noise=3):
+    """A short posed sequence for whole-pipeline tests: frames (slowly moving pattern), intrinsics for this size, and a
+    camera that moves a few centimetres per frame along an arc while looking at a fixed point."""
+    frames = list(make_frames(n, h, w, seed=seed, sweep=sweep, noise=noise))
+    K = np.array([[0.9 * w, 0.0, (w - 1) / 2.0], [0.0, 0.9 * w, (h - 1) / 2.0], [0.0, 0.0, 1.0]])
+    T_wcs = []
+    for i in range(n):
+        ang = 0.35 * i / max(n - 1, 1)
+        eye = np.array([3.0 * np.cos(ang), 3.0 * np.sin(ang), 1.3 + 0.05 * np.sin(3 * ang)])
+        T_wcs.append(look_at(eye, np.array([0.0, 0.0, 0.6])))
+    return {"frames": frames, "K": K, "T_wcs": np.asarray(T_wcs), "img_names": [3 * i + 1 for i in range(n)], "h": h, "w": w}
 
 
 def make_scene(n_frames, n_objects, seed=0, K=K_SCANNET, img_w=IMG_W, img_h=IMG_H, min_views=3,

@@ -172,12 +172,10 @@ def main():
 
 
 
-def gen_merge(out):
-    """optim_process -> merge_process of the reference on a scene whose tracks are fragmented (SURVEY 8f-4).
-    scikit-learn >= 1.2 renamed AgglomerativeClustering(affinity=) to metric=; the reference's call is adapted
-    by keyword only."""
+def patch_run_merge():
+    """the reference's run_merge module made runnable on this container's scikit-learn / numpy (keyword rename and
+    ragged-array spelling only)"""
     import sklearn.cluster as skc
-    from odam_amd import synth
     orig = skc.AgglomerativeClustering
 
     def compat(*a, affinity=None, **k):
@@ -202,6 +200,15 @@ def gen_merge(out):
                     out[i] = v
                 return out
     rm.np = _OldNumpy()
+    return rm
+
+
+def gen_merge(out):
+    """optim_process -> merge_process of the reference on a scene whose tracks are fragmented (SURVEY 8f-4).
+    scikit-learn >= 1.2 renamed AgglomerativeClustering(affinity=) to metric=; the reference's call is adapted
+    by keyword only."""
+    from odam_amd import synth
+    rm = patch_run_merge()
     scene = synth.make_scene(160, 6, seed=9, min_views=24, max_views=90)
     tracks = []
     for i, t in enumerate(scene["tracks"]):

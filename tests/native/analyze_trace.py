@@ -2,6 +2,7 @@
 import csv, sys
 path, B = sys.argv[1], int(sys.argv[2])
 nrep = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+BLOCKS = (3, 4, 23, 3) if (len(sys.argv) > 4 and sys.argv[4] == "resnet101") else (3, 4, 6, 3)
 rows = [r for r in csv.DictReader(open(path)) if "conv_gemm" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 n = len(rows) // nrep
@@ -11,7 +12,7 @@ H, W = 800, 1066
 seq = []
 H1, W1 = co(H, 7, 2, 3), co(W, 7, 2, 3); seq.append(("stem7x7", B * H1 * W1, 64, 147))
 h, w = co(H1, 3, 2, 1), co(W1, 3, 2, 1); inpl = 64
-for l, nb in enumerate((3, 4, 6, 3)):
+for l, nb in enumerate(BLOCKS):
     pl = 64 * 2 ** l
     for i in range(nb):
         s = 2 if (i == 0 and l > 0) else 1

@@ -340,6 +340,11 @@ def _to_bf16_bits(t):
     (1, 40, 53, 64, 64, 3, 1, 1, True, False),
     (2, 33, 41, 128, 128, 3, 2, 1, False, False),
     (1, 64, 80, 3, 64, 7, 2, 3, True, False),       # stem: Cin 3 -> 8, K 392 -> 448
+    (1, 30, 40, 512, 384, 1, 1, 0, True, True),     # ragged second 256-column tile
+    (1, 20, 27, 64, 256, 3, 1, 1, True, False),     # one 64-channel chunk, nine taps, ragged row tile
+    (1, 16, 16, 32, 128, 1, 1, 0, False, False),    # K = 32 padded to 64: fewer k-tiles than ring stages
+    (3, 25, 34, 1024, 256, 1, 1, 0, True, False),   # long K (32 k-tiles), ten row tiles
+    (2, 26, 35, 256, 256, 3, 2, 1, True, True),     # stride 2, odd size, two images per row tile
 ])
 def test_conv_gemm_bf16_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
     """bf16 operands are exact in fp32, so against a float conv on the bf16-rounded operands only the summation
@@ -412,10 +417,12 @@ def test_bf16_r101_full_size_close_to_fp32_oracle():
     det.close()
 
 
-@pytest.mark.parametrize("env", [{"ODAM_CG_NO_UT": "1"}, {"ODAM_CG_VARIANT": "0"}, {"ODAM_CG_FORCE": "2"}])
+@pytest.mark.parametrize("env", [{"ODAM_CG_NO_UT": "1"}, {"ODAM_CG_VARIANT": "0"}, {"ODAM_CG_FORCE": "2"}, {"ODAM_CG_BIG": "2"},
+                                 {"ODAM_CG_BIG": "0"}])
 def test_conv_gemm_alternative_paths(env):
-    """the register-staged gather (what layers too large for 31-bit buffer offsets fall back to), the 4-wave tiles
-    and the four-stage small-tile pipeline on every shape: same parity.  The switches are read once per process."""
+    """the register-staged gather (what layers too large for 31-bit buffer offsets fall back to), the 4-wave tiles,
+    the four-stage small-tile pipeline, and the bf16-native 256-row kernel forced onto / kept off every eligible shape:
+    same parity.  The switches are read once per process."""
     import os
     import subprocess
     import sys
