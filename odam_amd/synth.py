@@ -106,7 +106,7 @@ def make_frames(n, h=IMG_H, w=IMG_W, seed=0, sweep=1.0, noise=24):
         yield np.clip(img, 0, 255).astype(np.uint8)
 
 
-def make_sequence(n=40, h=256, w=320, seed=0, sweep=0.08, noise=3):
+def make_sequence(n=40, h=256, w=320, seed=0, sweep=0.02, noise=1):
     """A short posed sequence for whole-pipeline tests: frames (slowly moving pattern), intrinsics for this size, and a
     camera that moves a few centimetres per frame along an arc while looking at a fixed point."""
     frames = list(make_frames(n, h, w, seed=seed, sweep=sweep, noise=noise))

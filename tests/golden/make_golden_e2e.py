@@ -11,7 +11,9 @@ the detector, make_associator_state_dict for the associator -- the trained check
 Frames are 256x320 and the caller-supplied transform has size=256 (no resize), which keeps the CPU run short.
 
 Stored (tests/golden/e2e.npz): per-frame detection rows, the tracks after the 40 frames, fitted parameters / boxes of
-the first pass, the merged tracks, fitted parameters / boxes of the second pass.  Inputs are regenerated from seeds
+the first pass, the merged tracks, fitted parameters / boxes of the second pass; and, for both fit passes, the
+reference's own outputs when one world-position column of every track is scaled by (1 +- k 2^-23) (six runs each:
+its ulp-level self-sensitivity, the yardstick for the fitted parameters).  Inputs are regenerated from seeds
 (odam_amd.synth.make_sequence).  Run: python tests/golden/make_golden_e2e.py"""
 import os
 import sys
@@ -25,7 +27,33 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 SEQ = dict(n=40, h=256, w=320, seed=11)
-SCORE_THRESHOLD = 0.2      # the synthetic association network's match scores are low; the reference default 0.8 keeps none
+NUDGES = [(9, 1), (10, -1), (11, 1), (9, -2), (10, 2), (11, -2)]
+
+
+def _spread(job):
+    """one nudged optim_process of the reference over stored tracks"""
+    which, k = job
+    torch.set_num_threads(1)
+    import refenv
+    refenv.setup()
+    from make_golden import params_of
+    from src.scripts.run_multi_view import optim_process
+    from odam_amd import synth
+    z = np.load(os.path.join(HERE, "e2e.npz"))
+    seq = synth.make_sequence(**SEQ)
+    name, n = ("track", int(z["n_tracks"])) if which == 1 else ("merged", int(z["n_merged"]))
+    col, m = NUDGES[k]
+    tracks = []
+    for i in range(n):
+        t = z[f"{name}{i}"].copy()
+        t[:, col] *= 1.0 + m * 2.0 ** -23
+        tracks.append(t)
+    P_cws = [seq["K"] @ np.linalg.inv(T)[:3, :] for T in seq["T_wcs"]]
+    out = optim_process(tracks, seq["img_names"], list(seq["T_wcs"]), P_cws, SEQ["h"], SEQ["w"], seq["K"], "super_quadric",
+                        True, 200, 10)
+    return which, k, np.stack([params_of(q) for q in out["quadrics"]]), np.asarray(out["bboxes_qc"])
+
+SCORE_THRESHOLD = 0.8      # the reference default (processor.py:24)
 
 
 def main():
@@ -55,7 +83,7 @@ def main():
     assert not missing.unexpected_keys and all(k.startswith("backbone.0.body.fc") for k in missing.missing_keys), missing
     model.eval()
     net = Associator(CFG)
-    net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0), strict=True)
+    net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0, scene=True), strict=True)
     net.eval()
     fwd = net.forward
     net.forward = lambda data, thr, eval_only=False: fwd(data, thr, eval_only=eval_only, device="cpu")
@@ -93,6 +121,14 @@ def main():
         d[f"merged{i}"] = t
     for fid, r in dets.items():
         d[f"det{fid}"] = r
+    np.savez_compressed(os.path.join(HERE, "e2e.npz"), **d)
+    from multiprocessing import Pool
+    with Pool(6) as pool:
+        res = pool.map(_spread, [(w, k) for w in (1, 2) for k in range(len(NUDGES))], chunksize=1)
+    for w in (1, 2):
+        rs = sorted([r for r in res if r[0] == w], key=lambda r: r[1])
+        d[f"spread_params{w}"] = np.stack([r[2] for r in rs]); d[f"spread_bboxes_qc{w}"] = np.stack([r[3] for r in rs])
+    d["nudges"] = np.asarray(NUDGES, np.int32)
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **d)
     print("e2e golden:", len(tracks), "tracks (lengths", [len(t) for t in tracks], ") ->", len(merged_in), "merged (lengths",
           [len(t) for t in merged_in], "); classes", [int(np.median(t[:, 1])) for t in tracks])

@@ -8,12 +8,16 @@ are the per-channel mean / variance of its own activations; this script gives th
 property: layer by layer, running_mean / running_var := the statistics of the conv output on a few seeded synthetic
 frames (torch CPU).  The result is stored (float16, exactly representable on every box) as
 odam_amd/data/synth_calib_<backbone>_s<seed>.npz, so weights are identical wherever they are generated.
-Run: python tools/make_synth_calib.py [resnet50|resnet101] [seed]"""
+Second, the mean decoder output over queries and frames ("hs_mean") is stored: the prediction heads of the scene
+weights are centred on it (odam_amd/weights.py), so that class / box / depth outputs follow the differences between
+queries instead of their common component.  (Uses the CPU oracle's transformer, hence lives with the test tooling.)
+Run: python tests/golden/make_synth_calib.py [resnet50|resnet101] [seed]"""
 import os
 import sys
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "oracle"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -23,6 +27,7 @@ import torch.nn.functional as F  # noqa: E402
 def calibrate(backbone="resnet50", seed=0, n_frames=6, h=256, w=320):
     from odam_amd import weights, synth
     sd = weights.make_state_dict(backbone=backbone, seed=seed)
+    weights.scene_backbone_gains(sd)
     blocks = weights.RESNET_BLOCKS[backbone]
     frames = list(synth.make_frames(n_frames, h, w, seed=100 + seed))
     mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1); std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
@@ -49,6 +54,17 @@ def calibrate(backbone="resnet50", seed=0, n_frames=6, h=256, w=320):
                 o = bn(F.conv2d(o, sd[p + "conv3.weight"]), p + "bn3")
                 idt = bn(F.conv2d(x, sd[p + "downsample.0.weight"], None, s), p + "downsample.1") if i == 0 else x
                 x = F.relu(o + idt)
+        # decoder output statistics with the calibrated backbone and the scene transformer
+        import detr_oracle as O
+        full = dict(sd)
+        for k, v in out.items():
+            full[k] = torch.from_numpy(v.astype(np.float32))
+        weights.scene_transformer(full)
+        B, _, fh, fw = x.shape
+        src = F.conv2d(x, full["input_proj.weight"], full["input_proj.bias"])
+        hs, _ = O.transformer(src, O.position_embedding(fh, fw, batch=B), full["query_embed.weight"], full)
+        out["hs_mean"] = hs[-1].mean((0, 1)).half().numpy()
+        out["hs_std"] = np.float16(hs[-1].std(1).mean().item())
     return out
 
 
@@ -59,4 +75,4 @@ if __name__ == "__main__":
     res = calibrate(bbn, seed)
     path = os.path.join(REPO, "odam_amd", "data", f"synth_calib_{bbn}_s{seed}.npz")
     np.savez_compressed(path, **res)
-    print(path, os.path.getsize(path) // 1024, "KiB;", len(res) // 2, "batch-norm layers")
+    print(path, os.path.getsize(path) // 1024, "KiB;", (len(res) - 2) // 2, "batch-norm layers; query spread", float(res["hs_std"]))

@@ -89,8 +89,9 @@ def test_points_batch_bit_exact(fitter, oracle):
 
 
 def test_reference_golden_fits(fitter, oracle, golden):
-    """Reference-generated cases: the GPU equals the oracle bit for bit on all of them and meets the
-    1e-4 relative target against the reference's own final parameters where the oracle does."""
+    """Reference-generated cases: the GPU equals the oracle bit for bit on all of them and follows the reference's own
+    trajectory to 1e-5 over the first 40 steps.  Where the free-running fits END relative to the reference is measured
+    problem by problem against the reference's own ulp-level spread in tests/test_sq_survey.py (46 problems)."""
     z = golden("sq_steps.npz")
     for c in range(int(z["n_cases"])):
         d = {k[len(f"c{c}_"):]: z[k] for k in z.files if k.startswith(f"c{c}_")}
@@ -100,14 +101,13 @@ def test_reference_golden_fits(fitter, oracle, golden):
         op, _, _ = oracle.fit(d["p0"], d["P"], d["tgt"], d["mask"], cls)
         assert np.array_equal(_bits(gp), _bits(op))
         assert rel_err(out["traj"].cpu().numpy()[0][39], d["p_after"][39]) <= 1e-5
-        if c in (1, 2):
-            assert rel_err(gp, d["final_plain"]) <= 1e-4
 
 
 def test_reference_golden_fits_at_256_views(fitter, oracle, golden):
     """config 5's size: the reference's own 256-view fits.  GPU == oracle bit for bit; the free-running fit tracks
     the reference to 1e-5 over the first 10 steps (with 1024 (view, direction) winners per step the first ulp-level
-    tie that resolves differently comes at step 13 / 18) and ends within 1e-2 of it."""
+    tie that resolves differently comes at step 13 / 18: tests/test_sq_oracle.py::test_first_divergence_is_a_tie).  The
+    end state is bounded in tests/test_sq_survey.py (four 256-view problems among the 46)."""
     z = golden("sq_steps_full.npz")
     for c in range(int(z["n_cases"])):
         d = {k[len(f"c{c}_"):]: z[k] for k in z.files if k.startswith(f"c{c}_")}
@@ -117,7 +117,6 @@ def test_reference_golden_fits_at_256_views(fitter, oracle, golden):
         assert np.array_equal(_bits(out["params"].cpu().numpy()[0]), _bits(op))
         assert np.array_equal(_bits(out["traj"].cpu().numpy()[0]), _bits(otraj))
         assert rel_err(otraj[9], d["p_after"][9]) <= 1e-5, c
-        assert rel_err(op, d["final_plain"]) <= 1e-2, c
 
 
 def test_optim_process_on_gpu_vs_reference(golden):
@@ -127,11 +126,25 @@ def test_optim_process_on_gpu_vs_reference(golden):
     out = optim_process(tracks, [int(x) for x in z["img_names"]], z["T_wcs"], z["P_cws"], 480, 640, z["K"],
                         "super_quadric", True, 200, 10, return_params=True)
     assert np.allclose(np.asarray(out["bboxes_dl"]), z["bboxes_dl"], rtol=0, atol=1e-12)
-    errs = [rel_err(out["params"][i], z["params"][i]) for i in range(len(tracks)) if out["fitted"][i]]
-    assert sum(e <= 1e-4 for e in errs) >= len(errs) // 2, errs
-    for i in range(len(tracks)):
+    check_against_spread(out, z["params"], z["bboxes_qc"], golden("sq_optim_spread.npz"))
+
+
+def check_against_spread(out, ref_params, ref_qc, spread):
+    """fitted objects: deviation from the reference's parameters at most 3x the reference's own spread under ulp-level
+    nudges of its input (make_golden_optim_spread.py), or 1e-4 where it is reproducible; fitted box IoU >= 0.99 or no
+    worse than 3x the spread's loss; objects that are not fitted (fewer than 10 usable views) are exact."""
+    from odam_amd import merge
+    n = len(ref_params)
+    for i in range(n):
         if not out["fitted"][i]:
-            assert np.array_equal(out["params"][i], z["params"][i])
+            assert np.array_equal(out["params"][i], ref_params[i])
+            continue
+        e = rel_err(out["params"][i], ref_params[i])
+        s = max(rel_err(p[i], ref_params[i]) for p in spread["params"])
+        assert e <= max(1e-4, 3 * s), (i, e, s)
+        iou = merge.box3d_iou_pairs(np.asarray(out["bboxes_qc"][i])[None], ref_qc[i][None])[0][0]
+        siou = merge.box3d_iou_pairs(spread["bboxes_qc"][:, i], np.repeat(ref_qc[i][None], len(spread["bboxes_qc"]), 0))[0].min()
+        assert iou >= min(0.99, 1 - 3 * (1 - siou)), (i, iou, siou)
 
 
 def test_full_size_batch_properties(fitter, oracle):

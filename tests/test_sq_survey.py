@@ -1,0 +1,40 @@
+"""Final-parameter parity of the super-quadric fit as a measurement (see sq_survey_lib.py): the CPU oracle here, the
+gfx950 kernel under -m gpu (it must also equal the oracle bit for bit, so both see the same numbers)."""
+import os
+
+import numpy as np
+import pytest
+
+import sq_survey_lib as S
+from conftest import GOLDEN
+
+
+def _oracle_finals(z, oracle):
+    return np.stack([oracle.fit(z[f"c{i}_p0"], z[f"c{i}_P"], z[f"c{i}_tgt"], z[f"c{i}_mask"], int(z[f"c{i}_cls"]))[0]
+                     for i in range(int(z["n_cases"]))])
+
+
+def test_oracle_vs_reference_spread(oracle, golden):
+    z = golden("sq_survey.npz")
+    rows = S.survey_rows(z, _oracle_finals(z, oracle), oracle)
+    S.check(rows)
+    # the committed table is this very measurement
+    path = os.path.join(GOLDEN, "sq_survey_table.txt")
+    if os.environ.get("ODAM_WRITE_SURVEY_TABLE"):
+        open(path, "w").write(S.table(rows))
+    assert open(path).read() == S.table(rows)
+
+
+@pytest.mark.gpu
+def test_gpu_vs_reference_spread(oracle, golden):
+    from odam_amd import sq
+    z = golden("sq_survey.npz")
+    n = int(z["n_cases"])
+    f = sq.SqFitter("cuda:0", 200)
+    vc = [len(z[f"c{i}_tgt"]) for i in range(n)]
+    out = f.fit(np.stack([z[f"c{i}_p0"] for i in range(n)]), [int(z[f"c{i}_cls"]) for i in range(n)], vc,
+                np.concatenate([z[f"c{i}_P"] for i in range(n)]), np.concatenate([z[f"c{i}_tgt"] for i in range(n)]),
+                np.concatenate([z[f"c{i}_mask"] for i in range(n)]))["params"].cpu().numpy()
+    f.close()
+    assert np.array_equal(out.view(np.uint32), _oracle_finals(z, oracle).view(np.uint32))
+    S.check(S.survey_rows(z, out, oracle))
