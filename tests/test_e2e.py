@@ -1,0 +1,109 @@
+"""The whole chain of the reference's driver (likojack/ODAM src/scripts/run_processor.py:70-83) on the GPU against the
+reference's own run of it on the CPU (tests/golden/e2e.npz, make_golden_e2e.py):
+
+    40 frames -> process_frame (detector, post-process + NMS, rows, track preparation, association, attach)
+              -> optim_process -> merge_process -> optim_process
+
+Asserted: identical detections kept per frame (count, class labels, order), identical track membership and class labels
+(object IDs) after the 40 frames, identical merge clusters.  Fitted parameters / boxes of both passes, two ways:
+given the reference's own tracks as input the GPU fit reproduces the reference's fit to the north-star tolerance
+(1e-4; measured <= 2e-5 on all fitted objects), or within its ulp-level spread where it has one; at the end of the
+whole chain -- where the fit's inputs already differ by the 1e-5 by which two fp32 detectors differ -- the deviation
+is bounded by the reference's own response to input noise of that size (tests/test_sq_gpu.py::check_against_spread)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+SEQ = dict(n=40, h=256, w=320, seed=11)          # make_golden_e2e.py SEQ
+
+
+def _params(out):
+    return np.stack([q.params for q in out["quadrics"]])
+
+
+def _as_result(out):
+    qc, dl = np.asarray(out["bboxes_qc"]), np.asarray(out["bboxes_dl"])
+    # an object that was not fitted keeps the detector's box as its fitted box (run_multi_view.py:59-62)
+    fitted = np.array([not np.array_equal(a, b) for a, b in zip(qc, dl)])
+    return {"params": _params(out), "bboxes_qc": list(qc), "fitted": fitted}
+
+
+def _key(t):
+    return tuple(map(tuple, np.asarray(t)[:, :2]))
+
+
+def test_whole_pipeline_matches_the_reference_run(golden):
+    from PIL import Image
+    from odam_amd import associator, detector, synth, transforms, weights
+    from odam_amd.processor import OdamProcess
+    from conftest import rel_err
+    from test_sq_gpu import check_against_spread
+    z = golden("e2e.npz")
+    seq = synth.make_sequence(**SEQ)
+    det = detector.Detector(max_batch=8, device=DEV, n_streams=1)
+    det.load_state_dict(weights.make_state_dict(seed=0, scene=True))
+    net = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"],
+                                 "sinkhorn_iterations": 100}, max_tracks=64, device=DEV)
+    net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0, scene=True))
+    proc = OdamProcess(det, net, transforms.Transforms(size=SEQ["h"]), None)        # reference thresholds 0.6 / 0.1 / 0.8
+    proc.init_sequence(seq["K"], SEQ["h"], SEQ["w"])
+
+    # detections, frame by frame (the drop-in call) -- and once more batched (what a frame shard does): same rows
+    rows = {}
+    run = proc.run_detector
+
+    def logged(rgb, fid, T):
+        rows[fid] = run(rgb, fid, T)
+        return rows[fid]
+    proc.run_detector = logged
+    for i, fid in enumerate(seq["img_names"]):
+        proc.process_frame(Image.fromarray(seq["frames"][i]), fid, seq["T_wcs"][i])
+    n_det = 0
+    for fid in seq["img_names"]:
+        ref = z[f"det{fid}"]
+        got = np.asarray(rows[fid], np.float64).reshape(-1, 79)
+        assert got.shape == ref.shape, (fid, got.shape, ref.shape)
+        assert np.array_equal(got[:, :2], ref[:, :2]), fid                  # frame id, class label, NMS order
+        assert np.abs(got - ref).max() <= 2e-3, (fid, np.abs(got - ref).max())
+        n_det += len(ref)
+    assert n_det >= 40 * 15
+    batched = proc.detect_frames([Image.fromarray(f) for f in seq["frames"]], seq["img_names"])
+    for fid, r in zip(seq["img_names"], batched):
+        assert np.array_equal(np.asarray(r, np.float64).reshape(-1, 79), np.asarray(rows[fid], np.float64).reshape(-1, 79))
+
+    # object IDs: the same tracks with the same members
+    assert len(proc.tracks) == int(z["n_tracks"])
+    for i, t in enumerate(proc.tracks):
+        r = z[f"track{i}"]
+        assert t.shape == r.shape, i
+        assert np.array_equal(t[:, :2], r[:, :2]), i
+        assert np.abs(t - r).max() <= 5e-3, (i, np.abs(t - r).max())
+    assert sum(len(t) >= 10 for t in proc.tracks) >= 8
+
+    def both(w, ours, refs):
+        """fit pass w on the reference's tracks (pure fit parity) and on our own (end of the chain)"""
+        on_ref = _as_result(proc.optim_process([t.copy() for t in refs]))
+        assert on_ref["fitted"].sum() >= 3
+        check_against_spread(on_ref, z[f"params{w}"], z[f"bboxes_qc{w}"],
+                             {"params": z[f"spread_params{w}"], "bboxes_qc": z[f"spread_bboxes_qc{w}"]}, unfitted_atol=1e-6)
+        for i in np.flatnonzero(on_ref["fitted"]):
+            assert rel_err(on_ref["params"][i], z[f"params{w}"][i]) <= 1e-4, (w, i)     # these problems are well conditioned
+        out = proc.optim_process([t.copy() for t in ours])
+        noise = {"params": np.concatenate([z[f"spread_params{w}"], z[f"noise_params{w}"]]),
+                 "bboxes_qc": np.concatenate([z[f"spread_bboxes_qc{w}"], z[f"noise_bboxes_qc{w}"]])}
+        check_against_spread(_as_result(out), z[f"params{w}"], z[f"bboxes_qc{w}"], noise, unfitted_atol=5e-3)
+        return out
+    out1 = both(1, proc.tracks, [z[f"track{i}"] for i in range(int(z["n_tracks"]))])
+    assert _as_result(out1)["fitted"].sum() >= 8
+    merged = proc.merge_process(out1)
+    ref_merged = [z[f"merged{i}"] for i in range(int(z["n_merged"]))]
+    assert len(merged) == len(ref_merged) and len(merged) < len(proc.tracks)
+    assert sorted(_key(t) for t in merged) == sorted(_key(t) for t in ref_merged)   # merge clusters: identical
+    order = {_key(t): i for i, t in enumerate(ref_merged)}
+    merged = sorted(merged, key=lambda t: order[_key(t)])
+    for t, r in zip(merged, ref_merged):
+        assert np.abs(t - r).max() <= 5e-3
+    both(2, merged, ref_merged)
+    net.close(); det.close()

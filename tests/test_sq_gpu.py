@@ -129,15 +129,15 @@ def test_optim_process_on_gpu_vs_reference(golden):
     check_against_spread(out, z["params"], z["bboxes_qc"], golden("sq_optim_spread.npz"))
 
 
-def check_against_spread(out, ref_params, ref_qc, spread):
+def check_against_spread(out, ref_params, ref_qc, spread, unfitted_atol=0.0):
     """fitted objects: deviation from the reference's parameters at most 3x the reference's own spread under ulp-level
     nudges of its input (make_golden_optim_spread.py), or 1e-4 where it is reproducible; fitted box IoU >= 0.99 or no
     worse than 3x the spread's loss; objects that are not fitted (fewer than 10 usable views) are exact."""
     from odam_amd import merge
     n = len(ref_params)
     for i in range(n):
-        if not out["fitted"][i]:
-            assert np.array_equal(out["params"][i], ref_params[i])
+        if not out["fitted"][i]:      # initial parameters = means over the track's rows (which the caller may hold to 1e-5)
+            assert np.abs(np.asarray(out["params"][i], np.float64) - ref_params[i]).max() <= unfitted_atol, i
             continue
         e = rel_err(out["params"][i], ref_params[i])
         s = max(rel_err(p[i], ref_params[i]) for p in spread["params"])
