@@ -66,6 +66,20 @@ int odam_detr_feature_hw(const odam_detr* m, int* h, int* w);
 int odam_detr_forward(odam_detr* m, const float* img, int B, float* logits, float* boxes, float* angle,
                       float* offset, float* size, float* depth, float* obj_features, void* stream);
 
+/*
+ * The same forward over a batch of images of DIFFERENT sizes, zero-padded to the handle's img_h x img_w at the top-left
+ * as nested_tensor_from_tensor_list does (src/utils/misc.py:303-320):
+ *   key_mask [dev] [B][h*w] bytes, 1 = token lies in the padding (the image mask reduced to the feature grid by nearest
+ *            interpolation, backbone.py:79) -- such keys are excluded in encoder self-attention and decoder
+ *            cross-attention (key_padding_mask, transformer.py:157-160, 224-228);
+ *   pos      [dev] [B][h*w][hidden] float32: each image's own sine embedding (position_encoding.py:26-46 depends on the
+ *            mask through the cumulative sums and their normalisation).
+ * odam_amd/detector.py::Detector.forward_nested builds both exactly as the reference does.
+ */
+int odam_detr_forward_masked(odam_detr* m, const float* img, int B, const unsigned char* key_mask, const float* pos,
+                             float* logits, float* boxes, float* angle, float* offset, float* size, float* depth,
+                             float* obj_features, void* stream);
+
 /* optional taps for parity tests: layer4 feature map as NCHW [B,2048,h,w] and encoder memory [B,h*w,hidden]
  * of the most recent forward (either may be null) */
 int odam_detr_debug_read(odam_detr* m, int B, float* layer4_nchw, float* memory, void* stream);

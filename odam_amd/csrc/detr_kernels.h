@@ -9,8 +9,9 @@ namespace odam_dk {
 // Fused multi-head attention, head dim 32 (hidden 256 / 8 heads, transformer.py:138-139):
 //   O[b, q, h*32:(h+1)*32] = softmax_k( (Q[b,q,h] / sqrt(32)) . K[b,k,h] ) V[b,k,h]
 // Q/K/V/O are addressed as base + (b*L + row) * ld + h*32, so fused projection buffers work.
+// key_mask (nullable) [B][Lk]: non-zero = padded key, left out of the softmax (key_padding_mask, transformer.py:157-160).
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
-                     int B, int H, int Lq, int Lk, int dtype, hipStream_t stream);
+                     int B, int H, int Lq, int Lk, int dtype, hipStream_t stream, const unsigned char* key_mask = nullptr);
 
 // same kernel with head dimension 64, fp32 (associator GNN, 4 heads of 64; scores scaled by 1/8)
 int launch_attention_d64(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,

@@ -48,7 +48,10 @@ template <typename T, int D>
 __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q, int ldq,
                                                         const T* __restrict__ K, int ldk,
                                                         const T* __restrict__ V, int ldv,
-                                                        T* __restrict__ O, int ldo, int Lq, int Lk, float scale) {
+                                                        T* __restrict__ O, int ldo, int Lq, int Lk, float scale,
+                                                        const unsigned char* __restrict__ key_mask) {
+    // key_mask (nullable): [B][Lk], non-zero = padded key, excluded from the softmax (key_padding_mask of
+    // nn.MultiheadAttention as src/models/transformer.py:157-160, 224-228 pass it)
     constexpr int LD = D + 4;        // LDS row stride (floats)
     constexpr int HD = D / 2;        // channels of the QK^T reduction held by one lane half
     constexpr int NO = D / 32;       // 32-channel output tiles
@@ -129,12 +132,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q,
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.z, qreg[4 * g + 2], s, 0, 0, 0);
             s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf.w, qreg[4 * g + 3], s, 0, 0, 0);
         }
-        // mask keys beyond Lk (last tile only)
+        // mask keys beyond Lk (last tile only) and padded keys
         const int kbase = kt * ATT_KT;
         if (kbase + ATT_KT > Lk) {
 #pragma unroll
             for (int r = 0; r < 16; r++)
                 if (kbase + acc_row(r, half) >= Lk) s[r] = -1e30f;
+        }
+        if (key_mask) {
+            const unsigned char* mk = key_mask + (size_t)b * Lk + kbase;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int k = acc_row(r, half);
+                if (kbase + k < Lk && mk[k]) s[r] = -1e30f;
+            }
         }
         // online softmax over the key axis (registers + the other lane half)
         float mx = s[0];
@@ -185,11 +196,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q,
 }
 
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
-                     int B, int H, int Lq, int Lk, int dtype, hipStream_t stream) {
+                     int B, int H, int Lq, int Lk, int dtype, hipStream_t stream, const unsigned char* key_mask) {
     if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
     dim3 grid((Lq + 127) / 128, H, B);
     const float scale = (float)0.1767766952966369;   // sqrt(1/32) as torch computes it in float64, then float32
-#define ODAM_K(T, ...) hipLaunchKernelGGL((attention_kernel<T, 32>), grid, dim3(256), 0, stream, (const T*)Q, ldq, (const T*)K, ldk, (const T*)V, ldv, (T*)O, ldo, Lq, Lk, scale)
+#define ODAM_K(T, ...) hipLaunchKernelGGL((attention_kernel<T, 32>), grid, dim3(256), 0, stream, (const T*)Q, ldq, (const T*)K, ldk, (const T*)V, ldv, (T*)O, ldo, Lq, Lk, scale, key_mask)
     ODAM_DISPATCH(dtype, ODAM_K, 0);
 #undef ODAM_K
     ODAM_HIP(hipGetLastError());
@@ -202,7 +213,7 @@ int launch_attention_d64(const float* Q, int ldq, const float* K, int ldk, const
     if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
     dim3 grid((Lq + 127) / 128, H, B);
     hipLaunchKernelGGL((attention_kernel<float, 64>), grid, dim3(256), 0, stream, Q, ldq, K, ldk, V, ldv, O, ldo, Lq, Lk,
-                       0.125f);
+                       0.125f, (const unsigned char*)nullptr);
     ODAM_HIP(hipGetLastError());
     return 0;
 }

@@ -238,8 +238,8 @@ int lin_t(odam_detr* m, const Conv& c, const void* x, int M, const void* res, bo
     return conv_t(m, c, x, 1, 1, M, res, relu, y, st, out_f32);
 }
 int att_t(odam_detr* m, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
-          int B, int H, int Lq, int Lk, hipStream_t st) {
-    if (!m->profile) return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, m->dt, st);
+          int B, int H, int Lq, int Lk, hipStream_t st, const unsigned char* key_mask = nullptr) {
+    if (!m->profile) return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, m->dt, st, key_mask);
     if (m->aev_used + 2 > m->aev.size()) {
         for (int k = 0; k < 2; k++) {
             hipEvent_t e;
@@ -250,7 +250,7 @@ int att_t(odam_detr* m, const void* Q, int ldq, const void* K, int ldk, const vo
     }
     m->aev_flops[m->aev_used / 2] = 4.0 * B * H * (double)Lq * Lk * 32;   // QK^T + PV, 2 flop per MAC
     ODAM_HIP(hipEventRecord(m->aev[m->aev_used], st));
-    int rc = odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, m->dt, st);
+    int rc = odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, m->dt, st, key_mask);
     ODAM_HIP(hipEventRecord(m->aev[m->aev_used + 1], st));
     m->aev_used += 2;
     return rc;
@@ -428,8 +428,12 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
     return 0;
 }
 
-extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* logits, float* boxes, float* angle,
-                                 float* offset, float* size, float* depth, float* obj_features, void* stream) {
+// key_mask / pos_b: null for same-size batches (no padding: the mask is all false and one position table serves every
+// image).  Otherwise key_mask [B][L] marks padded tokens (backbone.py:79) and pos_b [B][L][E] is each image's own sine
+// embedding, which depends on its mask (position_encoding.py:26-46).
+static int forward_impl(odam_detr* m, const float* img, int B, const unsigned char* key_mask, const float* pos_b,
+                        float* logits, float* boxes, float* angle, float* offset, float* size, float* depth,
+                        float* obj_features, void* stream) {
     if (!m || !img || !logits || !boxes || !angle || !offset || !size || !depth)
         return odam_fail(1, "odam_detr_forward: null pointer");
     if (!m->finalized) return odam_fail(1, "odam_detr_forward: call odam_detr_finalize first");
@@ -469,17 +473,19 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
 
     // ---- input_proj + encoder (detr.py:70, transformer.py:154-167) -----------------------------
     RC(conv_t(m, m->input_proj, cur, B, H, W, nullptr, false, m->src, st));
-    RC(odam_dk::launch_add_pos(m->src, m->pos, L, m->srcpos, M, dt, st));
+    const float* pos = pos_b ? pos_b : m->pos;     // row r of the batch reads pos[r % Lp]
+    const int Lp = pos_b ? M : L;
+    RC(odam_dk::launch_add_pos(m->src, pos, Lp, m->srcpos, M, dt, st));
     for (size_t i = 0; i < m->enc.size(); i++) {
         const EncLayer& e = m->enc[i];
         RC(lin_t(m, e.qk, m->srcpos, M, nullptr, false, m->qk, st));
         RC(lin_t(m, e.v, m->src, M, nullptr, false, m->v, st));
-        RC(att_t(m, m->qk, 2 * E, off(m->qk, E), 2 * E, m->v, E, m->att, E, B, Hh, L, L, st));
+        RC(att_t(m, m->qk, 2 * E, off(m->qk, E), 2 * E, m->v, E, m->att, E, B, Hh, L, L, st, key_mask));
         RC(lin_t(m, e.out, m->att, M, m->src, false, m->tmp, st));
         RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n1.g, e.n1.b, m->src, nullptr, L, nullptr, M, dt, st));
         RC(lin_t(m, e.l1, m->src, M, nullptr, true, m->ffn, st));
         RC(lin_t(m, e.l2, m->ffn, M, m->src, false, m->tmp, st));
-        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n2.g, e.n2.b, m->src, m->pos, L, m->srcpos, M, dt, st));
+        RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n2.g, e.n2.b, m->src, pos, Lp, m->srcpos, M, dt, st));
     }
     // memory = src, memory + pos = srcpos
     RC(lin_t(m, m->cross_k_all, m->srcpos, M, nullptr, false, m->kc, st));
@@ -497,7 +503,7 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
         RC(lin_t(m, d.out, m->datt, Mq, m->tgt, false, m->dtmp, st));
         RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n1.g, d.n1.b, m->tgt, m->query_pos, Q, m->tgtpos, Mq, dt, st));
         RC(lin_t(m, d.cq, m->tgtpos, Mq, nullptr, false, m->dq, st));
-        RC(att_t(m, m->dq, E, off(m->kc, i * E), ldkv, off(m->vc, i * E), ldkv, m->datt, E, B, Hh, Q, L, st));
+        RC(att_t(m, m->dq, E, off(m->kc, i * E), ldkv, off(m->vc, i * E), ldkv, m->datt, E, B, Hh, Q, L, st, key_mask));
         RC(lin_t(m, d.cout, m->datt, Mq, m->tgt, false, m->dtmp, st));
         RC(odam_dk::launch_add_layernorm(m->dtmp, nullptr, d.n2.g, d.n2.b, m->tgt, nullptr, Q, nullptr, Mq, dt, st));
         RC(lin_t(m, d.l1, m->tgt, Mq, nullptr, true, m->dffn, st));
@@ -519,6 +525,18 @@ extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* l
     }
     RC(odam_dk::launch_sigmoid(boxes, Mq * 4, st));
     return 0;
+}
+
+extern "C" int odam_detr_forward(odam_detr* m, const float* img, int B, float* logits, float* boxes, float* angle,
+                                 float* offset, float* size, float* depth, float* obj_features, void* stream) {
+    return forward_impl(m, img, B, nullptr, nullptr, logits, boxes, angle, offset, size, depth, obj_features, stream);
+}
+
+extern "C" int odam_detr_forward_masked(odam_detr* m, const float* img, int B, const unsigned char* key_mask,
+                                        const float* pos, float* logits, float* boxes, float* angle, float* offset,
+                                        float* size, float* depth, float* obj_features, void* stream) {
+    if (!key_mask || !pos) return odam_fail(1, "odam_detr_forward_masked: null mask / position table");
+    return forward_impl(m, img, B, key_mask, pos, logits, boxes, angle, offset, size, depth, obj_features, stream);
 }
 
 extern "C" int odam_detr_debug_read(odam_detr* m, int B, float* layer4_nchw, float* memory, void* stream) {

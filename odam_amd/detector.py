@@ -22,10 +22,11 @@ class _Cfg(ctypes.Structure):
                 ("max_batch", ctypes.c_int), ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("dtype", ctypes.c_int)]
 
 
-def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000):
-    """PositionEmbeddingSine(128, normalize=True) for an unpadded h x w grid -> [h*w, 256] float32
-    (position_encoding.py:26-46; torch CPU ops, so the table equals the reference's bit for bit)."""
-    not_mask = torch.ones(1, h, w, dtype=torch.bool)
+def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000, mask=None):
+    """PositionEmbeddingSine(128, normalize=True) for an h x w grid -> [h*w, 256] float32
+    (position_encoding.py:26-46; torch CPU ops, so the table equals the reference's bit for bit).  `mask` [h,w] bool
+    (True = padding) for an image padded inside a mixed-size batch; None = no padding."""
+    not_mask = torch.ones(1, h, w, dtype=torch.bool) if mask is None else ~mask.reshape(1, h, w)
     y_embed = not_mask.cumsum(1, dtype=torch.float32)
     x_embed = not_mask.cumsum(2, dtype=torch.float32)
     eps, scale = 1e-6, 2 * math.pi
@@ -138,9 +139,53 @@ class Detector:
                        f"odam_detr_set_weight({name})")
         _lib.check(L.odam_detr_finalize(h), "odam_detr_finalize")
 
+    # ---- DETR.forward over images of different sizes (detr.py:64-65 -> misc.py:303-320) ----------------------
+    def forward_nested(self, images):
+        """list of [3,H_i,W_i] tensors -> the DETR output dict, as the reference computes it for a NestedTensor: images
+        zero-padded at the top-left to the batch maximum, padding mask reduced to the token grid by nearest
+        interpolation (backbone.py:79), per-image sine embedding from that mask, padded tokens excluded as attention
+        keys in the encoder and in the decoder's cross-attention."""
+        import torch.nn.functional as F
+        imgs = [t.to(torch.float32) for t in images]
+        B = len(imgs)
+        if B > self.max_batch:
+            raise _lib.OdamError("forward_nested: more images than max_batch")
+        H, W = max(t.shape[1] for t in imgs), max(t.shape[2] for t in imgs)
+        x = torch.zeros(B, 3, H, W, dtype=torch.float32)
+        mask = torch.ones(B, H, W, dtype=torch.bool)
+        for i, t in enumerate(imgs):
+            x[i, :, :t.shape[1], :t.shape[2]] = t.cpu()
+            mask[i, :t.shape[1], :t.shape[2]] = False
+        h = self._handle(H, W)
+        L = _lib.lib()
+        fh, fw = ctypes.c_int(), ctypes.c_int()
+        _lib.check(L.odam_detr_feature_hw(h, ctypes.byref(fh), ctypes.byref(fw)), "odam_detr_feature_hw")
+        fh, fw = fh.value, fw.value
+        m = F.interpolate(mask[None].float(), size=(fh, fw)).to(torch.bool)[0]            # backbone.py:79
+        a = self.arch
+        pos = torch.stack([sine_position_embedding(fh, fw, a["hidden_dim"] // 2, mask=m[i]) for i in range(B)])
+        dev = self.device
+        d_x, d_m, d_pos = x.to(dev), m.reshape(B, fh * fw).to(torch.uint8).to(dev).contiguous(), pos.to(dev).contiguous()
+        Q = a["num_queries"]
+        mk = lambda n: torch.empty(B, Q, n, device=dev, dtype=torch.float32)
+        out = {"pred_logits": mk(a["num_classes1"]), "pred_boxes": mk(4), "pred_angle": mk(a["angle_bins"]),
+               "pred_offset": mk(2), "pred_size": mk(3), "pred_depth": mk(1), "pred_obj_features": mk(a["hidden_dim"])}
+        with torch.cuda.device(dev):
+            _lib.check(L.odam_detr_forward_masked(h, _lib.ptr(d_x), ctypes.c_int(B), _lib.ptr(d_m), _lib.ptr(d_pos),
+                                                  _lib.ptr(out["pred_logits"]), _lib.ptr(out["pred_boxes"]),
+                                                  _lib.ptr(out["pred_angle"]), _lib.ptr(out["pred_offset"]),
+                                                  _lib.ptr(out["pred_size"]), _lib.ptr(out["pred_depth"]),
+                                                  _lib.ptr(out["pred_obj_features"]),
+                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                       "odam_detr_forward_masked")
+        out["_hw"] = (H, W)
+        return out
+
     # ---- DETR.forward (detr.py:49-94) ---------------------------------------------------------------
     def __call__(self, samples):
         if isinstance(samples, (list, tuple)):
+            if len({tuple(t.shape) for t in samples}) > 1:
+                return self.forward_nested(samples)
             samples = torch.stack(list(samples))
         x = samples.to(self.device, torch.float32).contiguous()
         B, C, H, W = x.shape

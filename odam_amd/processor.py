@@ -100,26 +100,36 @@ class OdamProcess:
 
     # ---- detection (processor.py:259-289) ----------------------------------------------------------
     def detect_frames(self, rgbs, frame_ids):
-        """Batched, stateless run_detector over several frames: list (per frame) of lists of 79-float rows."""
-        sizes = {tuple(rgb.size) if hasattr(rgb, "size") and not isinstance(rgb, np.ndarray) else rgb.shape[1::-1]
-                 for rgb in rgbs}
-        assert len(sizes) == 1, "frames of one batch must have one size"
-        img_size = sizes.pop()
+        """Batched, stateless run_detector over several frames: list (per frame) of lists of 79-float rows.
+        Frames of one size go through the detector in batches of max_batch; frames of DIFFERENT sizes are batched the
+        way the reference's DETR.forward batches a list of tensors (padded NestedTensor with a key-padding mask,
+        misc.py:303-320) and post-processed each with its own size."""
+        size_of = lambda rgb: tuple(rgb.size) if hasattr(rgb, "size") and not isinstance(rgb, np.ndarray) else rgb.shape[1::-1]
+        sizes = [size_of(rgb) for rgb in rgbs]
         out = []
         mb = getattr(self.detector, "max_batch", 1)
         on_device = getattr(self.transforms, "on_device", False)
         if on_device:
             self.detector.resize = (self.transforms.size, self.transforms.max_size)
         for b0 in range(0, len(rgbs), mb):
+            chunk = rgbs[b0:b0 + mb]
+            if len(set(sizes[b0:b0 + mb])) > 1:
+                xs = [self.transforms(rgb, None)[0] for rgb in chunk]
+                pred = self.detector.forward_nested(xs)
+                for b in range(len(chunk)):
+                    one = {k: (v[b:b + 1] if torch.is_tensor(v) else v) for k, v in pred.items()}
+                    objs = self.detector.postprocess(one, sizes[b0 + b], float(self.detect_threshold), self.sequence_meta.K)
+                    out.append(detection_rows(objs, 0, frame_ids[b0 + b], self.sequence_meta.img_w, self.sequence_meta.img_h))
+                continue
             if on_device:   # raw uint8 frames up, transform + forward on the GPU
-                raw = np.stack([np.asarray(rgb, np.uint8) for rgb in rgbs[b0:b0 + mb]])
+                raw = np.stack([np.asarray(rgb, np.uint8) for rgb in chunk])
                 pred = self.detector.forward_u8(torch.from_numpy(raw).to(self.detector.device))
                 nb = raw.shape[0]
             else:
-                x = torch.stack([self.transforms(rgb, None)[0] for rgb in rgbs[b0:b0 + mb]])
+                x = torch.stack([self.transforms(rgb, None)[0] for rgb in chunk])
                 pred = self.detector(x)
                 nb = x.shape[0]
-            objs = self.detector.postprocess(pred, img_size, float(self.detect_threshold), self.sequence_meta.K)
+            objs = self.detector.postprocess(pred, sizes[b0], float(self.detect_threshold), self.sequence_meta.K)
             for b in range(nb):
                 out.append(detection_rows(objs, b, frame_ids[b0 + b], self.sequence_meta.img_w,
                                           self.sequence_meta.img_h))

@@ -131,6 +131,8 @@ def main():
     for fid, r in dets.items():
         d[f"det{fid}"] = r
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **d)
+    print("e2e golden:", len(tracks), "tracks (lengths", [len(t) for t in tracks], ") ->", len(merged_in), "merged (lengths",
+          [len(t) for t in merged_in], "); classes", [int(np.median(t[:, 1])) for t in tracks])
     spreads()
 
 
@@ -146,8 +148,7 @@ def spreads():
         d[f"noise_params{w}"] = np.stack([r[2] for r in rs[nn:]]); d[f"noise_bboxes_qc{w}"] = np.stack([r[3] for r in rs[nn:]])
     d["nudges"] = np.asarray(NUDGES, np.int32); d["noise"] = np.float64(NOISE)
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **d)
-    print("e2e golden:", len(tracks), "tracks (lengths", [len(t) for t in tracks], ") ->", len(merged_in), "merged (lengths",
-          [len(t) for t in merged_in], "); classes", [int(np.median(t[:, 1])) for t in tracks])
+
 
 
 if __name__ == "__main__":

@@ -431,3 +431,26 @@ def test_conv_gemm_alternative_paths(env):
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", "conv_gemm_vs_torch or conv_gemm_bf16"],
                        env={**os.environ, **env, "ODAM_NESTED": "1"}, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_mixed_size_batch_vs_reference(golden):
+    """Three images of different sizes in one call: the reference's NestedTensor path (zero padding to the batch
+    maximum, mask -> token grid, per-image sine embedding, key_padding_mask in encoder self- and decoder
+    cross-attention; misc.py:303-320, backbone.py:79, transformer.py:157-160) against its own run (detr_mixed.npz)."""
+    from odam_amd import detector, weights
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden_detr_mixed import images
+    z = golden("detr_mixed.npz")
+    det = detector.Detector(max_batch=4, device=DEV, n_streams=1)
+    det.load_state_dict(weights.make_state_dict(seed=0, scene=True))
+    out = det(images())                              # a list of different shapes -> forward_nested
+    for k in KEYS:
+        if k in z.files:
+            err = (out[k].cpu() - torch.from_numpy(z[k])).abs().max().item()
+            assert err <= 5e-4 * max(1.0, np.abs(z[k]).max()), (k, err)
+    assert torch.equal(out["pred_logits"].cpu().argmax(-1), torch.from_numpy(z["pred_logits"]).argmax(-1))
+    # the padding is not a no-op: image 0 alone gives different logits, and we reproduce those too
+    alone = det(images()[0][None])["pred_logits"].cpu().numpy()
+    assert np.abs(alone - z["alone_logits0"]).max() <= 5e-4 * np.abs(z["alone_logits0"]).max()
+    assert np.abs(z["pred_logits"][0] - z["alone_logits0"][0]).max() > 0.1
+    det.close()
