@@ -27,7 +27,7 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 from odam_amd import detector as det_mod, multi_view, parallel, sq, synth, transforms, weights  # noqa: E402
-from odam_amd.processor import detection_rows  # noqa: E402
+from odam_amd.processor import detection_array  # noqa: E402
 
 FLOPS_PER_FRAME_R50 = 163.1e9   # SURVEY.md section 2.2 / BASELINE.md (2 x MAC, 800x1066 input)
 PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
@@ -47,14 +47,15 @@ def pmc_summary():
         return {}
 
 
-def build_frames(n_local, device, seed):
-    """resident raw frames: 32 distinct synthetic 640x480 uint8 RGB frames tiled to n_local with a per-frame intensity
-    offset, [n_local,480,640,3] in HBM.  The reference's transform (PIL-bilinear resize to 800x1066, /255, ImageNet
-    normalisation; transforms.py:281-290) runs on the device inside the timed step."""
-    base = np.stack(list(synth.make_frames(min(32, n_local), seed=seed)))
-    out = np.empty((n_local,) + base.shape[1:], np.uint8)
-    for i in range(n_local):
-        out[i] = np.clip(base[i % len(base)].astype(np.int16) + (i // len(base)) % 7, 0, 255).astype(np.uint8)
+def build_frames(f0, f1, device, seed=0):
+    """resident raw frames f0 .. f1-1 of the scene: 32 distinct synthetic 640x480 uint8 RGB frames repeated with a
+    per-repeat intensity offset (frame i = base[i % 32] + (i // 32) % 7, the same on every rank), [f1-f0,480,640,3] in
+    HBM.  The reference's transform (PIL-bilinear resize to 800x1066, /255, ImageNet normalisation;
+    transforms.py:281-290) runs on the device inside the timed step."""
+    base = np.stack(list(synth.make_frames(32, seed=seed)))
+    out = np.empty((f1 - f0,) + base.shape[1:], np.uint8)
+    for k, i in enumerate(range(f0, f1)):
+        out[k] = np.clip(base[i % 32].astype(np.int16) + (i // 32) % 7, 0, 255).astype(np.uint8)
     return torch.from_numpy(out).to(device)
 
 
@@ -73,6 +74,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo + "
                     "--one-device let several ranks share one GPU for a functional check of the N > 1 path")
     ap.add_argument("--one-device", action="store_true")
+    ap.add_argument("--force-collectives", action="store_true", help="initialise the process group and run both "
+                    "all-gathers even in a world of one (RCCL call path on a single GPU)")
+    ap.add_argument("--dump", default="", help="rank 0 writes the gathered detections and fitted rows of the last step here (.npz)")
     args = ap.parse_args()
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
@@ -81,8 +85,10 @@ def main():
     if args.one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if ws > 1:
+    if ws > 1 or args.force_collectives:
         import torch.distributed as dist
+        if ws == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // ws)))   # ranks share the host cores
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device(f"cuda:{local_rank}"))
@@ -107,7 +113,7 @@ def main():
     # host side of the step (threshold, NMS, row packing) runs at the load a trained detector gives it
     detector.load_state_dict(weights.make_state_dict(seed=0, scene=True))
     fitter = sq.SqFitter(device, 200)
-    frames = build_frames(f1 - f0, device, seed=rank)
+    frames = build_frames(f0, f1, device)
     H, W = transforms.target_size(frames.shape[2], frames.shape[1])   # 800 x 1066
 
     # SQ problems decoupled from the (random-weight) detector output so the fit runs at the stated sizes
@@ -118,6 +124,7 @@ def main():
     frame_ids = scene["img_names"]
 
     det_ms = []
+    last = {}
 
     def step(profile=False):
         per_frame = []
@@ -127,12 +134,13 @@ def main():
             for i in range(rows16.shape[0]):   # host: threshold + NMS + 79-column rows, overlapped with the GPU
                 sel = detector.select(rows16[i], 0.6, True, 30)
                 objs = {k: [v] for k, v in sel.items()}
-                per_frame.append(detection_rows(objs, 0, frame_ids[f0 + c0 + i], synth.IMG_W, synth.IMG_H))
+                per_frame.append(detection_array(objs, 0, frame_ids[f0 + c0 + i], synth.IMG_W, synth.IMG_H))
         e1.record()          # after the last chunk's copy on the issuing stream: end of the detection phase
         det_ms.append((e0, e1))
         blk, cnt = parallel.pack_detections(per_frame)
-        blk, cnt = parallel.allgather_detections(blk, cnt, N, coll_dev)
+        blk, cnt = parallel.allgather_detections(blk, cnt, N, coll_dev, force=args.force_collectives)
         n_det = int(cnt.sum())
+        last["blk"], last["cnt"] = blk, cnt
         fitted = None
         for _ in range(2):  # optim -> (merge) -> optim
             out = multi_view.optim_process([tracks[i] for i in mine], frame_ids, scene["T_wcs"], scene["P_cws"],
@@ -141,7 +149,7 @@ def main():
             local = np.concatenate([out["params"].reshape(len(mine), 9),
                                     np.asarray(out["bboxes_qc"], np.float32).reshape(len(mine), 24)], 1) \
                 if mine else np.zeros((0, 33), np.float32)
-            fitted = parallel.allgather_rows(local, len(tracks), owners, coll_dev)
+            fitted = parallel.allgather_rows(local, len(tracks), owners, coll_dev, force=args.force_collectives)
         return n_det, fitted
 
     def sync():
@@ -168,6 +176,8 @@ def main():
     n_launch, conv_ms, conv_flops = detector.profile_read(H, W)
     att_n, att_ms, att_flops = detector.profile_read_attention(H, W)
     detector.profile(H, W, False)
+    if args.dump and rank == 0:
+        np.savez(args.dump, blk=last["blk"], cnt=last["cnt"], fitted=fitted)
     if ws > 1:
         t = torch.tensor([dt], device=device if args.backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -282,7 +292,7 @@ def main():
         result["cpu_baseline"] = cpu_baseline(scene, tracks, N)
     if rank == 0:
         print(json.dumps(result))
-    if ws > 1:
+    if ws > 1 or args.force_collectives:
         torch.distributed.destroy_process_group()
 
 
@@ -306,7 +316,7 @@ def config4_block(device, args, pmc):
         for c0, rows16 in det.detect_resident_chunks(frames, (800, 600), K, chunk=4 * B):
             for i in range(rows16.shape[0]):
                 sel = det.select(rows16[i], 0.6, True, 30)
-                n += len(detection_rows({k: [v] for k, v in sel.items()}, 0, c0 + i, 800, 600))
+                n += len(detection_array({k: [v] for k, v in sel.items()}, 0, c0 + i, 800, 600))
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(2):
@@ -356,7 +366,7 @@ def cpu_baseline(scene, tracks, N):
     ncpu = os.cpu_count() or 8
     sweep = {}
     keep = torch.get_num_threads()
-    for nt in sorted({n for n in (8, 16, 32, 64, ncpu) if n <= ncpu}):
+    for nt in sorted({n for n in (8, 16, 32, min(64, ncpu)) if n <= ncpu}):   # beyond 64 threads the box only gets slower (256: 0.01 frames/s)
         torch.set_num_threads(nt)
         detr_oracle.detr_forward(sd, imgs[0])          # warm-up at this thread count
         s = time.perf_counter()

@@ -1,6 +1,8 @@
 // detr_kernels.hip -- see detr_kernels.h
 #include "detr_kernels.h"
 
+#include <cstdlib>
+
 #include "odam_err.h"
 
 namespace odam_dk {
@@ -195,11 +197,159 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q,
     }
 }
 
+// =================================================================================================
+// Fused attention on the bf16 matrix instruction (bf16 mode, BASELINE config 4), d_head = 32.
+// Same dataflow as above with v_mfma_f32_32x32x16_bf16: per 64-key tile 4 MFMAs give S^T = K . Q^T (two 32-key blocks x
+// two 16-channel k-steps) and 4 more O^T += V^T . P^T -- 8 x 32 cycles instead of 64 x 64.  P stays in registers: the
+// S^T accumulator (query on the lane, key in the register) converted pairwise to bf16 IS the B operand of the PV
+// product; its k order inside a 16-key step is 16 s + 8 (j >> 2) + 4 half + (j & 3), so the A operand (V^T) is read
+// from an LDS image [channel][key] as two 4-key groups per step.  Softmax in fp32 with exp2 (scale * log2 e folded in).
+// LDS: K tile [64 keys][64 B] with the 16-byte chunk c of key r at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128, as
+// in conv_gemm's bf16 kernel); V^T tile [32 channels][64 keys + 4 pad] (136-byte rows: the 32 lanes' 8-byte reads fall
+// on 64 distinct banks).
+// =================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __restrict__ Q, int ldq,
+                                                             const bf16_t* __restrict__ K, int ldk,
+                                                             const bf16_t* __restrict__ V, int ldv,
+                                                             bf16_t* __restrict__ O, int ldo, int Lq, int Lk, float c_log2,
+                                                             const unsigned char* __restrict__ key_mask) {
+    constexpr int KT = 64, D = 32, VLD = KT + 4;
+    __shared__ __align__(16) uint4 Ks[2][KT * 4];
+    __shared__ __align__(16) unsigned short Vt[2][D][VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const bf16_t* Qb = Q + (size_t)b * Lq * ldq + h * D;
+    const bf16_t* Kb = K + (size_t)b * Lk * ldk + h * D;
+    const bf16_t* Vb = V + (size_t)b * Lk * ldv + h * D;
+
+    uint4 qf[2];     // B operand of S^T = K . Q^T: lane (query col, half) holds Q[q][16 s + 8 half .. + 7]
+    {
+        const int q = q0 + col;
+#pragma unroll
+        for (int st = 0; st < 2; st++)
+            qf[st] = (q < Lq) ? *reinterpret_cast<const uint4*>(Qb + (size_t)q * ldq + 16 * st + 8 * half) : uint4{0u, 0u, 0u, 0u};
+    }
+    const int lk = tid >> 2, lc = tid & 3;          // loader: key row of the tile, 8-channel chunk
+    auto load_kv = [&](int kt, uint4& kr, uint4& vr) {
+        const int key = kt * KT + lk;
+        if (key < Lk) {
+            kr = *reinterpret_cast<const uint4*>(Kb + (size_t)key * ldk + lc * 8);
+            vr = *reinterpret_cast<const uint4*>(Vb + (size_t)key * ldv + lc * 8);
+        } else {
+            kr = uint4{0u, 0u, 0u, 0u}; vr = uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_kv = [&](int buf, const uint4& kr, const uint4& vr) {
+        Ks[buf][lk * 4 + (lc ^ ((lk >> 2) & 3))] = kr;
+        const unsigned w[4] = {vr.x, vr.y, vr.z, vr.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            Vt[buf][lc * 8 + 2 * e][lk] = (unsigned short)(w[e] & 0xffffu);
+            Vt[buf][lc * 8 + 2 * e + 1][lk] = (unsigned short)(w[e] >> 16);
+        }
+    };
+
+    floatx16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[r] = 0.0f;
+    float m_run = -1e30f, l_run = 0.0f;
+    const int ntiles = (Lk + KT - 1) / KT;
+    uint4 kr, vr;
+    load_kv(0, kr, vr);
+    store_kv(0, kr, vr);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) load_kv(kt + 1, kr, vr);
+        floatx16 s[2];
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[jh][r] = 0.0f;
+            const int key = jh * 32 + col;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const uint4 kf = Ks[cur][key * 4 + ((2 * st + half) ^ ((key >> 2) & 3))];
+                s[jh] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, kf), __builtin_bit_cast(bf16x8_t, qf[st]),
+                                                                s[jh], 0, 0, 0);
+            }
+        }
+        const int kbase = kt * KT;
+        if (kbase + KT > Lk || key_mask) {
+            const unsigned char* mk = key_mask ? key_mask + (size_t)b * Lk + kbase : nullptr;
+#pragma unroll
+            for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int k = jh * 32 + acc_row(r, half);
+                    if (kbase + k >= Lk || (mk && mk[k])) s[jh][r] = -1e30f;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[jh][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_log2);
+        const float mc = m_new * c_log2;
+        float psum = 0.0f;
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                s[jh][r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[jh][r], c_log2, -mc));
+                psum += s[jh][r];
+            }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[r] *= alpha;
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                unsigned pw[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    pw[e] = (unsigned)f2bf(s[jh][8 * st + 2 * e]) | ((unsigned)f2bf(s[jh][8 * st + 2 * e + 1]) << 16);
+                const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[cur][col][jh * 32 + 16 * st + 4 * half]);
+                const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[cur][col][jh * 32 + 16 * st + 8 + 4 * half]);
+                const uint4 vf = uint4{lo.x, lo.y, hi.x, hi.y};
+                oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
+                                                               __builtin_bit_cast(bf16x8_t, uint4{pw[0], pw[1], pw[2], pw[3]}), oacc, 0, 0, 0);
+            }
+        if (kt + 1 < ntiles) store_kv(cur ^ 1, kr, vr);
+        __syncthreads();
+    }
+    const int q = q0 + col;
+    if (q < Lq) {
+        const float inv = 1.0f / l_run;
+        bf16_t* Ob = O + ((size_t)b * Lq + q) * ldo + h * D;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            st4(Ob + 8 * g + 4 * half, float4{oacc[4 * g + 0] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv});
+    }
+}
+
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                      int B, int H, int Lq, int Lk, int dtype, hipStream_t stream, const unsigned char* key_mask) {
     if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
     dim3 grid((Lq + 127) / 128, H, B);
     const float scale = (float)0.1767766952966369;   // sqrt(1/32) as torch computes it in float64, then float32
+    static const bool bf16_mfma = getenv("ODAM_ATT_FP32") == nullptr;   // experiments: keep bf16 mode on the fp32 kernel
+    if (dtype == 1 && bf16_mfma && (ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0) {
+        hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
+                           (const bf16_t*)V, ldv, (bf16_t*)O, ldo, Lq, Lk, scale * 1.44269504088896341f, key_mask);
+        ODAM_HIP(hipGetLastError());
+        return 0;
+    }
 #define ODAM_K(T, ...) hipLaunchKernelGGL((attention_kernel<T, 32>), grid, dim3(256), 0, stream, (const T*)Q, ldq, (const T*)K, ldk, (const T*)V, ldv, (T*)O, ldo, Lq, Lk, scale, key_mask)
     ODAM_DISPATCH(dtype, ODAM_K, 0);
 #undef ODAM_K

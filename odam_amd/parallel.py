@@ -36,11 +36,11 @@ def pack_detections(per_frame_rows):
     F = len(per_frame_rows)
     blk = np.full((F, MAX_DETS, DET_COLS), -1.0, np.float32)
     cnt = np.zeros(F, np.int32)
-    for f, rows in enumerate(per_frame_rows):
+    for f, rows in enumerate(per_frame_rows):     # rows: list of 79-float lists, or an [n, 79] array
         n = min(len(rows), MAX_DETS)
         cnt[f] = n
         if n:
-            blk[f, :n] = np.asarray(rows, np.float64)[:n, :DET_COLS]
+            blk[f, :n] = (rows if isinstance(rows, np.ndarray) else np.asarray(rows, np.float64))[:n, :DET_COLS]
     return blk, cnt
 
 
@@ -55,28 +55,31 @@ def unpack_detections(blk, cnt):
     return out
 
 
-def allgather_detections(blk, cnt, n_frames, device=None):
+def allgather_detections(blk, cnt, n_frames, device=None, force=False):
     """Collective #1.  Every rank passes its block for frame_shard(n_frames, rank, world); returns the
-    blocks of the whole scene in frame order on every rank."""
+    blocks of the whole scene in frame order on every rank.  One message per rank: the block and its per-frame counts
+    travel in ONE float32 tensor [F_pad, 30 * 15 + 1] (the count in the last column; exact, it is <= 30) -- one upload,
+    one all_gather_into_tensor, one download.  `force`: run the collective even in a world of one (exercises the RCCL
+    call path on a single GPU)."""
     rank, ws = world()
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return blk, cnt
     dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
     per = -(-n_frames // ws)  # padded shard length so all_gather_into_tensor sees equal shapes
-    pb = torch.full((per, MAX_DETS, DET_COLS), -1.0, dtype=torch.float32, device=dev)
-    pc = torch.zeros(per, dtype=torch.int32, device=dev)
-    pb[:len(cnt)] = torch.from_numpy(blk).to(dev)
-    pc[:len(cnt)] = torch.from_numpy(cnt).to(dev)
-    gb = torch.empty((ws * per, MAX_DETS, DET_COLS), dtype=torch.float32, device=dev)
-    gc = torch.empty(ws * per, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(gb, pb)
-    dist.all_gather_into_tensor(gc, pc)
-    gb, gc = gb.cpu().numpy(), gc.cpu().numpy()
+    W = MAX_DETS * DET_COLS
+    host = np.full((per, W + 1), -1.0, np.float32)
+    host[:, W] = 0.0
+    host[:len(cnt), :W] = blk.reshape(len(cnt), W)
+    host[:len(cnt), W] = cnt
+    mine = torch.from_numpy(host).to(dev)
+    allr = torch.empty((ws * per, W + 1), dtype=torch.float32, device=dev)
+    dist.all_gather_into_tensor(allr, mine)
+    g = allr.cpu().numpy()
     ob, oc = [], []
     for r in range(ws):
         s, e = frame_shard(n_frames, r, ws)
-        ob.append(gb[r * per: r * per + (e - s)])
-        oc.append(gc[r * per: r * per + (e - s)])
+        ob.append(g[r * per: r * per + (e - s), :W].reshape(e - s, MAX_DETS, DET_COLS))
+        oc.append(g[r * per: r * per + (e - s), W].astype(np.int32))
     return np.concatenate(ob), np.concatenate(oc)
 
 
@@ -86,12 +89,12 @@ def object_shard(view_counts, rank, world_size):
     return [int(i) for i in order[rank::world_size]]
 
 
-def allgather_rows(local, n_total, owner_lists, device=None):
+def allgather_rows(local, n_total, owner_lists, device=None, force=False):
     """Collective #2.  `local` float32[n_local, ...] rows for owner_lists[rank] (same trailing shape on all
     ranks) -> float32[n_total, ...] in object order on every rank."""
     rank, ws = world()
     local = np.ascontiguousarray(local, np.float32)
-    if ws == 1:
+    if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
         out = np.zeros((n_total,) + local.shape[1:], np.float32)
         out[owner_lists[0]] = local
         return out

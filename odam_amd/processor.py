@@ -49,21 +49,32 @@ def get_cam_azi(T_wc):  # scannet_utils.py:213-222
     return np.arctan2(o[1], o[0])
 
 
+def detection_array(out_objects, b, frame_id, seq_w, seq_h):
+    """processor.py:269-288 for one frame, all detections at once: [n, 79] float64.  Same arithmetic as the reference's
+    per-detection loop (float32 boxes divided in place by the sequence size, float32 angle -> sin / cos, every value
+    widened to float64, 64 code columns of -1)."""
+    bb = out_objects["bboxes"][b]
+    n = len(bb)
+    rows = np.full((n, 79), -1.0)
+    if n == 0:
+        return rows
+    angles = np.asarray(out_objects["angles"][b]) / 180. * np.pi
+    bb[:, :, 0] /= seq_w
+    bb[:, :, 1] /= seq_h
+    rows[:, 0] = frame_id
+    rows[:, 1] = out_objects["classes"][b]
+    rows[:, 2:6] = bb.reshape(n, 4)
+    rows[:, 6:9] = out_objects["dimensions"][b]
+    rows[:, 9:12] = out_objects["translates"][b]
+    rows[:, 12] = np.sin(angles)
+    rows[:, 13] = np.cos(angles)
+    rows[:, 14] = out_objects["scores"][b]
+    return rows
+
+
 def detection_rows(out_objects, b, frame_id, seq_w, seq_h):
     """processor.py:269-288: one frame's post-processed detections -> list of 79-float rows."""
-    n = len(out_objects["bboxes"][b])
-    angles = np.asarray(out_objects["angles"][b]) / 180. * np.pi
-    rows = []
-    for i in range(n):
-        sin_azi, cos_azi = np.sin(angles[i]), np.cos(angles[i])
-        bb = out_objects["bboxes"][b][i]
-        bb[:, 0] /= seq_w
-        bb[:, 1] /= seq_h
-        d, t = out_objects["dimensions"][b][i], out_objects["translates"][b][i]
-        obj = [frame_id, out_objects["classes"][b][i], bb[0, 0], bb[0, 1], bb[1, 0], bb[1, 1], d[0], d[1], d[2],
-               t[0], t[1], t[2], sin_azi, cos_azi, out_objects["scores"][b][i]]
-        rows.append([float(f) for f in obj] + (np.zeros(64) - 1).tolist())
-    return rows
+    return detection_array(out_objects, b, frame_id, seq_w, seq_h).tolist()
 
 
 class OdamProcess:

@@ -129,22 +129,33 @@ def test_optim_process_on_gpu_vs_reference(golden):
     check_against_spread(out, z["params"], z["bboxes_qc"], golden("sq_optim_spread.npz"))
 
 
-def check_against_spread(out, ref_params, ref_qc, spread, unfitted_atol=0.0):
-    """fitted objects: deviation from the reference's parameters at most 3x the reference's own spread under ulp-level
-    nudges of its input (make_golden_optim_spread.py), or 1e-4 where it is reproducible; fitted box IoU >= 0.99 or no
-    worse than 3x the spread's loss; objects that are not fitted (fewer than 10 usable views) are exact."""
+def check_against_spread(out, ref_params, ref_qc, spread, unfitted_atol=0.0, allow_frac=0.0):
+    """fitted objects: deviation from the reference's parameters at most 3x the reference's own spread under small
+    perturbations of its input (six or twelve runs stored with the golden), or 1e-4 where it is reproducible; fitted box
+    IoU >= 0.99 or no worse than 3x the spread's loss.  `allow_frac`: share of the fitted objects that may leave the
+    parameter bound (a handful of sampled perturbations does not exhaust what a last-bit difference can trigger:
+    tests/test_sq_survey.py finds 13 % of 46 problems outside the max of ten) -- their boxes must still agree to
+    IoU >= 0.97.  Objects that are not fitted (fewer than 10 usable views) keep their initial parameters."""
     from odam_amd import merge
     n = len(ref_params)
+    bad, n_fit = [], 0
     for i in range(n):
         if not out["fitted"][i]:      # initial parameters = means over the track's rows (which the caller may hold to 1e-5)
             assert np.abs(np.asarray(out["params"][i], np.float64) - ref_params[i]).max() <= unfitted_atol, i
             continue
+        n_fit += 1
         e = rel_err(out["params"][i], ref_params[i])
         s = max(rel_err(p[i], ref_params[i]) for p in spread["params"])
-        assert e <= max(1e-4, 3 * s), (i, e, s)
         iou = merge.box3d_iou_pairs(np.asarray(out["bboxes_qc"][i])[None], ref_qc[i][None])[0][0]
         siou = merge.box3d_iou_pairs(spread["bboxes_qc"][:, i], np.repeat(ref_qc[i][None], len(spread["bboxes_qc"]), 0))[0].min()
-        assert iou >= min(0.99, 1 - 3 * (1 - siou)), (i, iou, siou)
+        if e > max(1e-4, 3 * s):
+            bad.append((i, e, s, iou))
+            assert iou >= 0.97, (i, e, s, iou)
+        else:
+            assert iou >= min(0.99, 1 - 3 * (1 - siou)), (i, iou, siou)
+    assert len(bad) <= allow_frac * n_fit, bad
+    return bad
+
 
 
 def test_full_size_batch_properties(fitter, oracle):
