@@ -26,7 +26,10 @@ int odam_assoc_set_weight(odam_assoc* m, const char* name, const float* data, co
 int odam_assoc_finalize(odam_assoc* m);
 
 /* tracks [dev][T,79,100] and detections [dev][79,30] in the associator's input layout (channel 0 = frame index,
- * -1 padding; processor.py:49-68, 155-179); Z_out [dev][(T+1),(n_det+1)] = log assignment incl. dustbins. */
+ * -1 padding; processor.py:49-68, 155-179); Z_out [dev][(T+1),(n_det+1)] = log assignment incl. dustbins.
+ * The ~65 launches of one forward are captured into a hipGraph the first time a track count T is seen and replayed
+ * afterwards (inputs / result pass through buffers of the handle; stream-ordered, no host synchronisation);
+ * ODAM_ASSOC_GRAPH=0 issues the launches one by one instead.  One handle serves one stream at a time. */
 int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, float* Z_out,
                        void* stream);
 

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libodam_amd.so")
+LIB_PATH = os.environ.get("ODAM_AMD_LIB") or os.path.join(_HERE, "libodam_amd.so")   # the override is for A/B builds of the library
 _lib = None
 
 c_float_p = ctypes.POINTER(ctypes.c_float)

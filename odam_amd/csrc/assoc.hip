@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -74,8 +75,10 @@ __device__ __forceinline__ float group_sum(float v) {
 }
 
 __global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict__ scores, int lds, int m, int n,
-                                                         float alpha, int iters, float* __restrict__ out) {
+                                                         float alpha, int iters, float* __restrict__ out,
+                                                         const int* __restrict__ n_dev) {
     extern __shared__ float sm[];
+    if (n_dev) n = *n_dev;      // replayed from a captured graph: the number of detections of THIS frame lives in memory
     const int M1 = m + 1, N1 = n + 1;
     float* Z = sm;                 // [M1][N1]
     float* u = Z + M1 * N1;        // [M1]
@@ -152,6 +155,14 @@ struct odam_assoc {
     float *feat = nullptr, *h256 = nullptr, *catT = nullptr, *kv = nullptr, *att = nullptr, *h512 = nullptr;
     float *kvX = nullptr, *attX = nullptr, *hX = nullptr;
     float *catTr = nullptr, *featD = nullptr, *mT = nullptr, *scores = nullptr;
+    // graph replay (one captured launch sequence per track count): inputs and the result go through fixed buffers
+    float *in_tracks = nullptr, *in_det = nullptr, *out_Z = nullptr;
+    int* d_ndet = nullptr;
+    int* h_ndet = nullptr;               // pinned ring: the detection count of a frame until its upload has run
+    unsigned ring = 0;
+    std::map<int, hipGraphExec_t> graphs;
+    hipStream_t cap_stream = nullptr;
+    bool use_graph = true;
 
     int alloc(float** p, size_t n) {
         ODAM_HIP(hipMalloc((void**)p, n * sizeof(float)));
@@ -254,6 +265,9 @@ extern "C" int odam_assoc_create(int max_tracks, int n_self_layers, const int* g
 
 extern "C" int odam_assoc_destroy(odam_assoc* m) {
     if (!m) return 0;
+    for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
+    if (m->h_ndet) (void)hipHostFree(m->h_ndet);
+    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
     return 0;
@@ -306,17 +320,20 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     RC(m->alloc(&m->hX, (T + ND) * 512));
     RC(m->alloc(&m->mT, (T + ND) * D)); RC(m->alloc(&m->scores, T * 32));
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    RC(m->alloc(&m->in_tracks, T * NF * NT)); RC(m->alloc(&m->in_det, (size_t)NF * ND)); RC(m->alloc(&m->out_Z, (T + 1) * (ND + 1)));
+    float* nd = nullptr;
+    RC(m->alloc(&nd, 1));
+    m->d_ndet = reinterpret_cast<int*>(nd);
+    ODAM_HIP(hipHostMalloc((void**)&m->h_ndet, 64 * sizeof(int), hipHostMallocDefault));
+    m->use_graph = getenv("ODAM_ASSOC_GRAPH") != nullptr && atoi(getenv("ODAM_ASSOC_GRAPH")) != 0;   // measured: no gain (the sequence is bound by ~65 dependent kernels of ~10 us on the device, not by host launches)
     m->host.clear();
     m->finalized = true;
     return 0;
 }
 
-extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det,
-                                  float* Z_out, void* stream) {
-    if (!m || !tracks || !detections || !Z_out) return odam_fail(1, "odam_assoc_forward: null pointer");
-    if (!m->finalized) return odam_fail(1, "odam_assoc_forward: call odam_assoc_finalize first");
-    if (T < 1 || T > m->max_tracks || n_det < 1 || n_det > ND) return odam_fail(3, "odam_assoc_forward: T / n_det out of range");
-    hipStream_t st = (hipStream_t)stream;
+// the launch sequence of one forward: ~65 kernels, every one a memory round trip long at these sizes (<= 70 rows)
+static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, const int* n_dev,
+                           float* Z_out, hipStream_t st) {
     const int N = T * NT;
     // encoder + frame-index encoding (associator.py:222-229)
     hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
@@ -358,8 +375,46 @@ extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, con
     Lin sc; sc.w = const_cast<float*>(mD); sc.b = nullptr; sc.K = D; sc.N = ND;
     RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
     const size_t lds = ((size_t)(T + 1) * (n_det + 1) + (T + 1) + (n_det + 1)) * sizeof(float);
-    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out);
+    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out, n_dev);
     ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+// One frame.  The sequence above is launch-bound (44 small GEMMs + 18 attention launches + prepare / pooling / Sinkhorn),
+// so it is captured ONCE per track count into a hipGraph and replayed: the inputs are copied into fixed buffers, the
+// frame's detection count travels through a device word the Sinkhorn kernel reads, the result is copied out.  Same
+// kernels, same bits as the eager sequence (ODAM_ASSOC_GRAPH=0 keeps that).
+extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det,
+                                  float* Z_out, void* stream) {
+    if (!m || !tracks || !detections || !Z_out) return odam_fail(1, "odam_assoc_forward: null pointer");
+    if (!m->finalized) return odam_fail(1, "odam_assoc_forward: call odam_assoc_finalize first");
+    if (T < 1 || T > m->max_tracks || n_det < 1 || n_det > ND) return odam_fail(3, "odam_assoc_forward: T / n_det out of range");
+    hipStream_t st = (hipStream_t)stream;
+    if (!m->use_graph) return enqueue_forward(m, tracks, T, detections, n_det, nullptr, Z_out, st);
+    ODAM_HIP(hipMemcpyAsync(m->in_tracks, tracks, sizeof(float) * (size_t)T * NF * NT, hipMemcpyDeviceToDevice, st));
+    ODAM_HIP(hipMemcpyAsync(m->in_det, detections, sizeof(float) * NF * ND, hipMemcpyDeviceToDevice, st));
+    int* slot = m->h_ndet + (m->ring++ & 63);
+    *slot = n_det;
+    ODAM_HIP(hipMemcpyAsync(m->d_ndet, slot, sizeof(int), hipMemcpyHostToDevice, st));
+    auto it = m->graphs.find(T);
+    if (it == m->graphs.end()) {
+        // captured on a stream of the handle (the caller's may be the legacy default stream, which cannot capture);
+        // nothing executes during capture, the instantiated graph is then launched on the caller's stream
+        hipGraph_t g = nullptr;
+        if (!m->cap_stream) ODAM_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
+        ODAM_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
+        const int rc = enqueue_forward(m, m->in_tracks, T, m->in_det, ND, m->d_ndet, m->out_Z, m->cap_stream);   // LDS sized for 30 detections
+        const hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
+        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
+        ODAM_HIP(e);
+        hipGraphExec_t ex = nullptr;
+        const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        ODAM_HIP(ei);
+        it = m->graphs.emplace(T, ex).first;
+    }
+    ODAM_HIP(hipGraphLaunch(it->second, st));
+    ODAM_HIP(hipMemcpyAsync(Z_out, m->out_Z, sizeof(float) * (size_t)(T + 1) * (n_det + 1), hipMemcpyDeviceToDevice, st));
     return 0;
 }
 
@@ -373,7 +428,8 @@ extern "C" int odam_assoc_sinkhorn(const float* scores, int lds_, int m_, int n_
         attr = true;
     }
     const size_t lds = ((size_t)(m_ + 1) * (n_ + 1) + (m_ + 1) + (n_ + 1)) * sizeof(float);
-    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, (hipStream_t)stream, scores, lds_, m_, n_, alpha, iters, Z_out);
+    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, (hipStream_t)stream, scores, lds_, m_, n_, alpha, iters, Z_out,
+                       (const int*)nullptr);
     ODAM_HIP(hipGetLastError());
     return 0;
 }

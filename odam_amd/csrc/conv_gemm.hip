@@ -510,10 +510,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 //     bank range (r & 3), i.e. 16 distinct 16-byte slots: conflict-free; the DMA writes lane-linearly, so the
 //     permutation is applied to its source address (lane l -> row l >> 2, chunk (l & 3) ^ ((l >> 4) & 3)).
 // Gather, epilogue, XCD-aware tile order and numerics (fp32 accumulate, k-ordered inside a k-step) are the ones above.
-template <int BN, int NST>
-__global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(ConvGemmArgs a) {
-    using T = unsigned short;
-    constexpr int BM = 256, BKE = 32, NTH = 512;
+template <bool BF16, int BN, int NST>
+__global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmArgs a) {
+    // element type: bf16 (32-element k-tiles on v_mfma_f32_32x32x16_bf16) or fp32 (16-element k-tiles on
+    // v_mfma_f32_32x32x2_f32: the same 64-byte rows, ring and schedule; per k-tile a wave issues 64 / 32 MFMAs of 64
+    // cycles, so the matrix pipe is paced by the instruction itself and the ring only has to keep up)
+    using T = typename std::conditional<BF16, unsigned short, float>::type;
+    constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
+    constexpr int BM = 256, BKE = 4 * EPC, NTH = 512;
+    constexpr int KU = 2 * BKE;             // channels per unit of the chunk-major K order (conv_gemm.h k_order)
     constexpr int WM = BN == 256 ? 2 : 4, WN = BN == 256 ? 4 : 2;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPP = NTH / 4;            // 128 tile rows per DMA pass (4 chunks of 16 bytes per row)
@@ -565,7 +570,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(ConvGemmArgs a) {
             iy0 = oy * a.stride - a.pad; ix0 = ox * a.stride - a.pad;
             base = ((b * a.H + iy0) * a.W + ix0) * lda;
         }
-        a_voff[i] = (unsigned)(base - b0 * a.H * a.W * lda + margin + csrc * 8) * 2u;
+        a_voff[i] = (unsigned)(base - b0 * a.H * a.W * lda + margin + csrc * EPC) * (unsigned)sizeof(T);
         unsigned mk = plain ? 1u : 0u;
         for (int t = 0; t < (plain ? 0 : ntaps); t++) {
             const int ky = (t * kw_inv) >> 16, kx = t - ky * a.KW;
@@ -576,24 +581,24 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(ConvGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < B_LD; i++) {
         const int n = n0 + r0 + RPP * i;
-        w_voff[i] = n < a.Cout ? (unsigned)(n * a.Kpad + csrc * 8) * 2u : OOB_VOFF;
+        w_voff[i] = n < a.Cout ? (unsigned)(n * a.Kpad + csrc * EPC) * (unsigned)sizeof(T) : OOB_VOFF;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
     auto load_tile = [&](int kt, int st) {
         int tap, cbase;
-        if (a.k_order) {   // chunk-major K in units of 64 channels (conv_gemm.h): kt / 2 = chunk * ntaps + tap
-            const int k64 = kt >> 1, chunk = (k64 * nt_inv) >> 16;
-            tap = k64 - chunk * ntaps;
-            cbase = chunk * 64 + (kt & 1) * 32;
+        if (a.k_order) {   // chunk-major K in units of KU channels (conv_gemm.h): kt / 2 = chunk * ntaps + tap
+            const int ku = kt >> 1, chunk = (ku * nt_inv) >> 16;
+            tap = ku - chunk * ntaps;
+            cbase = chunk * KU + (kt & 1) * BKE;
         } else {
             const int kb = kt * BKE;
             tap = kb >> a.log2Cin;
             cbase = kb & (a.Cin - 1);
         }
         const int ky = (tap * kw_inv) >> 16, kx = tap - ky * a.KW;
-        const int soff = ((ky * a.W + kx) * lda + cbase) * 2;
+        const int soff = ((ky * a.W + kx) * lda + cbase) * (int)sizeof(T);
         const unsigned sb = lds_base + (unsigned)(st * STAGE + wave_u * 16 * ROWB);
 #pragma unroll
         for (int i = 0; i < A_LD; i++) {
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(ConvGemmArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < B_LD; i++)
-            lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), w_voff[i], kt * BKE * 2);
+            lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), w_voff[i], kt * BKE * (int)sizeof(T));
     };
 
     floatx16 acc[TM][TN];
@@ -641,9 +646,17 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(ConvGemmArgs a) {
 #pragma unroll
             for (int i = 0; i < TM; i++)
 #pragma unroll
-                for (int j = 0; j < TN; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
-                                                                        __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; j++) {
+                    if constexpr (BF16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
+                                                                            __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
+                    } else {   // the chunk's four values are the k slots of four steps (A and B pair up the same way)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].x, bf[q][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].y, bf[q][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].z, bf[q][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].w, bf[q][j].w, acc[i][j], 0, 0, 0);
+                    }
+                }
     };
 
     const int nk = a.Kpad / BKE;
@@ -664,18 +677,18 @@ __global__ __launch_bounds__(512) void conv_gemm_bf16_kernel(ConvGemmArgs a) {
     }
     __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
     static_assert(WM * WN * 32 * (BN / WN) * 4 <= NST * STAGE, "epilogue staging fits the ring");
-    epilogue<BM, BN, WM, WN, TM, TN, true>(a, acc, smem, NST * STAGE / 4, m0, n0, wm, wn, wave, lane);
+    epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, NST * STAGE / 4, m0, n0, wm, wn, wave, lane);
 }
 
-template <int BN, int NST>
+template <bool BF16, int BN, int NST>
 static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
     constexpr int bytes = NST * (256 + BN) * 64;
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)conv_gemm_bf16_kernel<BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<BF16, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     const int tiles = ((a.M + 255) / 256) * ((a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_bf16_kernel<BN, NST>), dim3(tiles), dim3(512), bytes, stream, a);
+    hipLaunchKernelGGL((conv_gemm_big_kernel<BF16, BN, NST>), dim3(tiles), dim3(512), bytes, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -685,15 +698,19 @@ void set_big_mode(int mode) { g_big_mode = mode; }
 
 // the bf16-native kernel takes a layer when its gather is uniform-tap at k-tile 32 and the problem is large enough
 // to give every CU a 256-row tile with a K loop worth pipelining
+static int g_big_f32 = getenv("ODAM_CG_BIG_F32") ? atoi(getenv("ODAM_CG_BIG_F32")) : 0;   // fp32 layers on the 256-row kernel too
 static bool big_eligible(const ConvGemmArgs& a, int bn) {
-    if (a.dtype != ODAM_CG_BF16 || a.Cin % 32 != 0 || a.KH * a.KW > 32 || a.Kpad % 32 != 0) return false;
-    if (a.k_order && a.Cin % 64 != 0) return false;
+    const bool bf = a.dtype == ODAM_CG_BF16;
+    if (!bf && !g_big_f32) return false;
+    const int bke = bf ? 32 : 16, esz = bf ? 2 : 4;
+    if (a.Cin % bke != 0 || a.KH * a.KW > 32 || a.Kpad % bke != 0) return false;
+    if (a.k_order && a.Cin % (2 * bke) != 0) return false;
     const long lda = a.lda > 0 ? a.lda : a.Cin;
     const long span = (256L / ((long)a.Ho * a.Wo) + 2) * a.H * a.W * lda + (long)(a.pad * a.W + a.pad) * lda + a.Cin;
-    if (span * 2 >= 0x7fffffffL || (long)a.Cout * a.Kpad * 2 >= 0x7fffffffL) return false;
+    if (span * esz >= 0x7fffffffL || (long)a.Cout * a.Kpad * esz >= 0x7fffffffL) return false;
     if (g_big_mode >= 2) return true;
     const long tiles = (long)((a.M + 255) / 256) * ((a.Cout + bn - 1) / bn);
-    return a.Kpad >= 512 && tiles >= 192 && a.Cout >= bn;
+    return tiles >= 192 && a.Cout >= bn;     // short-K expand layers too: with 16-byte stores its one block per CU streams faster than two 128x128 blocks
 }
 
 template <int BM, int BN, int WM, int WN, int NST_UT = 2>
@@ -727,8 +744,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         return odam_fail(1, "conv_gemm: k_order 1 needs Cin % k-tile == 0, at most 32 taps, fewer than 2048 k-tiles");
     if (a.M <= 0 || a.Cout <= 0) return 0;
     if (g_big_mode) {
-        if (a.Cout % 256 == 0 || a.Cout >= 384) { if (big_eligible(a, 256)) return launch_big<256, 4>(a, stream); }
-        else if (a.Cout > 64 && g_big_mode >= 2 && big_eligible(a, 128)) return launch_big<128, 4>(a, stream);   // measured slower than the 128x128 tiles: tests only
+        const bool bf = a.dtype == ODAM_CG_BF16;
+        if (a.Cout % 256 == 0 || a.Cout >= 384) {
+            if (big_eligible(a, 256)) return bf ? launch_big<true, 256, 4>(a, stream) : launch_big<false, 256, 4>(a, stream);
+        } else if (a.Cout > 64 && g_big_mode >= 2 && big_eligible(a, 128)) {   // measured slower than the 128x128 tiles: tests only
+            return bf ? launch_big<true, 128, 4>(a, stream) : launch_big<false, 128, 4>(a, stream);
+        }
     }
     static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 7;  // 8-wave tiles (+2-3 %)
     static const int force = getenv("ODAM_CG_FORCE") ? atoi(getenv("ODAM_CG_FORCE")) : 0;   // experiments: pin one tile shape

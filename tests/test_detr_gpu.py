@@ -418,7 +418,7 @@ def test_bf16_r101_full_size_close_to_fp32_oracle():
 
 
 @pytest.mark.parametrize("env", [{"ODAM_CG_NO_UT": "1"}, {"ODAM_CG_VARIANT": "0"}, {"ODAM_CG_FORCE": "2"}, {"ODAM_CG_BIG": "2"},
-                                 {"ODAM_CG_BIG": "0"}])
+                                 {"ODAM_CG_BIG": "0"}, {"ODAM_CG_BIG": "2", "ODAM_CG_BIG_F32": "1"}])
 def test_conv_gemm_alternative_paths(env):
     """the register-staged gather (what layers too large for 31-bit buffer offsets fall back to), the 4-wave tiles,
     the four-stage small-tile pipeline, and the bf16-native 256-row kernel forced onto / kept off every eligible shape:
