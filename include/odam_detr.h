@@ -127,6 +127,12 @@ int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* s
 /* which layers the bf16-native 256-row schedule of the contraction kernel takes: 0 none, 1 those large enough to fill
  * the device (default), 2 every eligible layer (parity tests on small shapes).  Process-wide; also ODAM_CG_BIG. */
 int odam_op_conv_bf16_mode(int mode);
+/* how fp32 layers large enough for the 256-row schedule are multiplied: 0 = v_mfma_f32_32x32x2_f32 on 128x128 tiles
+ * (the k-ordered fp32 FMA chain), 1 = the same instruction in the ring
+ * kernel, 2 (default) = every fp32 operand split exactly into three bf16 values and the six significant cross products taken on
+ * v_mfma_f32_32x32x16_bf16 (fp32-class accuracy -- 0.8-1.4e-7 of sum |a b| against float64, the fp32 instruction
+ * 1.1-1.9e-7 -- at 2.7x the matrix rate; last bits differ from mode 0).  Process-wide; also ODAM_CG_BIG_F32. */
+int odam_op_conv_f32_mode(int mode);
 int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                       int B, int H, int Lq, int Lk, void* stream);
 int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y, int M,

@@ -53,4 +53,9 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 // 2 = whenever the layer is eligible (any size).  Also read once from ODAM_CG_BIG.
 void set_big_mode(int mode);
 
+// fp32 layers: 0 = v_mfma_f32_32x32x2_f32 on 128x128 tiles, 1 = the same instruction in the 256-row ring kernel,
+// 2 (default) = products on the bf16 matrix instruction through an exact three-way bf16 split of both operands (six
+// MFMAs per 16 k; fp32-class accuracy, different last bits).  Also read once from ODAM_CG_BIG_F32.
+void set_f32_mode(int mode);
+
 }  // namespace odam_cg

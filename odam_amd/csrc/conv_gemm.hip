@@ -510,19 +510,32 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 //     bank range (r & 3), i.e. 16 distinct 16-byte slots: conflict-free; the DMA writes lane-linearly, so the
 //     permutation is applied to its source address (lane l -> row l >> 2, chunk (l & 3) ^ ((l >> 4) & 3)).
 // Gather, epilogue, XCD-aware tile order and numerics (fp32 accumulate, k-ordered inside a k-step) are the ones above.
-template <bool BF16, int BN, int NST>
-__global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmArgs a) {
-    // element type: bf16 (32-element k-tiles on v_mfma_f32_32x32x16_bf16) or fp32 (16-element k-tiles on
-    // v_mfma_f32_32x32x2_f32: the same 64-byte rows, ring and schedule; per k-tile a wave issues 64 / 32 MFMAs of 64
-    // cycles, so the matrix pipe is paced by the instruction itself and the ring only has to keep up)
+// MODE 0: bf16 operands (32-element k-tiles on v_mfma_f32_32x32x16_bf16).
+// MODE 1: fp32 operands on v_mfma_f32_32x32x2_f32 (16-element k-tiles: the same 64-byte rows, ring and schedule).
+// MODE 2: fp32 operands, products on the bf16 matrix instruction through an EXACT three-way split: every fp32 value is
+//   a = hi + mid + lo with hi, mid, lo bf16 (8 + 8 + 8 significant bits, by truncation: no rounding anywhere), and
+//   a * b is taken as the six products hi hi + (hi mid + mid hi) + (hi lo + mid mid + lo hi); each bf16 x bf16 product is
+//   exact in fp32 and the matrix instruction accumulates in fp32.  The three dropped products are below 2^-24 |a b|.
+//   Measured against float64 (tests/native/x3_probe.hip, K = 64 ... 4608): max error 0.8-1.4e-7 of sum |a b|, the
+//   fp32 matrix instruction's own k-ordered chain 1.1-1.9e-7 -- the same accuracy class, at 6 x 32 instead of 8 x 64
+//   matrix-pipe cycles per 16 k.  Results differ from MODE 1 in the last bits (different summation tree), so this mode
+//   is a switch (set_f32_mode), validated by the same tests as MODE 1.
+// NTH = 512: one workgroup per CU (two waves per SIMD run the same tile in lock step).  NTH = 256 (BN <= 128): a four-wave
+// workgroup with the same 128x64 / 64x64 wave tile, TWO per CU with independent barriers -- one workgroup's k-tile boundary
+// (barrier, fragment latency, DMA issue) falls under the other's MFMAs.
+template <int MODE, int BN, int NST, int NTH = 512>
+__global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
+    constexpr bool BF16 = MODE == 0;
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
-    constexpr int BM = 256, BKE = 4 * EPC, NTH = 512;
+    constexpr int BM = 256, BKE = 4 * EPC;
     constexpr int KU = 2 * BKE;             // channels per unit of the chunk-major K order (conv_gemm.h k_order)
-    constexpr int WM = BN == 256 ? 2 : 4, WN = BN == 256 ? 4 : 2;
+    constexpr int NW = NTH / 64;
+    constexpr int WM = NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4), WN = NW / WM;
+    // NTH = 256 with BN = 256: one wave per SIMD owns 128 x 128 (256 accumulator registers of the 512 a lone wave may use)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPP = NTH / 4;            // 128 tile rows per DMA pass (4 chunks of 16 bytes per row)
-    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+    constexpr int A_LD = BM / RPP, B_LD = (BN + RPP - 1) / RPP;   // BN < RPP: only the first waves carry filter rows
     constexpr int ROWB = 64;                // bytes per LDS row
     constexpr int STAGE = (BM + BN) * ROWB; // bytes per ring stage
     constexpr int LPT = A_LD + B_LD;        // DMA instructions per thread per tile
@@ -581,10 +594,11 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmArgs a) {
 #pragma unroll
     for (int i = 0; i < B_LD; i++) {
         const int n = n0 + r0 + RPP * i;
-        w_voff[i] = n < a.Cout ? (unsigned)(n * a.Kpad + csrc * EPC) * (unsigned)sizeof(T) : OOB_VOFF;
+        w_voff[i] = (n < a.Cout && r0 + RPP * i < BN) ? (unsigned)(n * a.Kpad + csrc * EPC) * (unsigned)sizeof(T) : OOB_VOFF;
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool b_wave = BN >= RPP || wave_u * 16 < BN;     // BN = 64 with eight waves: waves 0-3 stage the filter rows
 
     auto load_tile = [&](int kt, int st) {
         int tap, cbase;
@@ -605,9 +619,11 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmArgs a) {
             const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB_VOFF;
             lds_dma16(a_rs4, sb + (unsigned)(RPP * i * ROWB), vo, soff);
         }
+        if (b_wave) {
 #pragma unroll
-        for (int i = 0; i < B_LD; i++)
-            lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), w_voff[i], kt * BKE * (int)sizeof(T));
+            for (int i = 0; i < B_LD; i++)
+                lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), w_voff[i], kt * BKE * (int)sizeof(T));
+        }
     };
 
     floatx16 acc[TM][TN];
@@ -626,11 +642,62 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmArgs a) {
     const int b_off = (BM + wn * (BN / WN) + frow) * ROWB;
     int fq[2];
 #pragma unroll
-    for (int q = 0; q < 2; q++) fq[q] = ((2 * q + (lane >> 5)) ^ fsw) * 16;
+    for (int q = 0; q < 2; q++)     // MODE 2: the lane's 8 consecutive k (chunks 2 half, 2 half + 1); else chunk 2 q + half
+        fq[q] = ((MODE == 2 ? 2 * (lane >> 5) + q : 2 * q + (lane >> 5)) ^ fsw) * 16;
+
+    // exact split of 8 fp32 values (two 16-byte chunks) into three bf16x8 operands: hi = top 16 bits of a, mid = top 16
+    // bits of a - hi, lo = a - hi - mid (at most 8 significant bits left, so its top 16 bits hold it exactly)
+    auto split8 = [](const float4& c0, const float4& c1, uint4& hi, uint4& mid, uint4& lo) {
+        const float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        unsigned uh[8], um[8], ul[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            uh[e] = __builtin_bit_cast(unsigned, v[e]);
+            const float r1 = v[e] - __builtin_bit_cast(float, uh[e] & 0xffff0000u);
+            um[e] = __builtin_bit_cast(unsigned, r1);
+            ul[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, um[e] & 0xffff0000u));
+        }
+        auto pk = [](unsigned lo_, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo_, 0x07060302u); };   // two top halves
+        hi = uint4{pk(uh[0], uh[1]), pk(uh[2], uh[3]), pk(uh[4], uh[5]), pk(uh[6], uh[7])};
+        mid = uint4{pk(um[0], um[1]), pk(um[2], um[3]), pk(um[4], um[5]), pk(um[6], um[7])};
+        lo = uint4{pk(ul[0], ul[1]), pk(ul[2], ul[3]), pk(ul[4], ul[5]), pk(ul[6], ul[7])};
+    };
 
     auto mma_tile = [&](int st, auto&& issue_next) {
         const char* Ab = lds_c + st * STAGE + a_off;
         const char* Bb = lds_c + st * STAGE + b_off;
+        if constexpr (MODE == 2) {
+            uint4 bh[TN], bm[TN], bl[TN];
+            float4 b0[TN], b1[TN], a0, a1;
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                b0[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[0]);
+                b1[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[1]);
+            }
+            a0 = *reinterpret_cast<const float4*>(Ab + fq[0]);
+            a1 = *reinterpret_cast<const float4*>(Ab + fq[1]);
+            issue_next();
+#pragma unroll
+            for (int j = 0; j < TN; j++) split8(b0[j], b1[j], bh[j], bm[j], bl[j]);
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                uint4 ah, am, al;
+                split8(a0, a1, ah, am, al);
+                if (i + 1 < TM) {      // next row tile's fragments fly under this tile's products
+                    a0 = *reinterpret_cast<const float4*>(Ab + (i + 1) * 32 * ROWB + fq[0]);
+                    a1 = *reinterpret_cast<const float4*>(Ab + (i + 1) * 32 * ROWB + fq[1]);
+                }
+#define ODAM_MM(x, y) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc[i][j], 0, 0, 0)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {     // smallest products first
+                    ODAM_MM(al, bh[j]); ODAM_MM(am, bm[j]); ODAM_MM(ah, bl[j]);
+                    ODAM_MM(am, bh[j]); ODAM_MM(ah, bm[j]);
+                    ODAM_MM(ah, bh[j]);
+                }
+#undef ODAM_MM
+            }
+            return;
+        }
         float4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[0]);
@@ -667,8 +734,12 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         // my DMAs retire in order: at most (NST - 2) tiles' worth outstanding = my part of tile kt has landed; the
         // barrier extends that to every wave and says ring slot (kt - 1) % NST has been read by all (it is refilled next)
-        if (kt + NST - 1 <= nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (kt + NST - 1 <= nk) {
+            if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * A_LD) : "memory");     // this wave stages no filter rows
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         mma_tile(st, [&] { if (kt + NST - 1 < nk) load_tile(kt + NST - 1, st_next); });
@@ -680,15 +751,15 @@ __global__ __launch_bounds__(512) void conv_gemm_big_kernel(ConvGemmArgs a) {
     epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, NST * STAGE / 4, m0, n0, wm, wn, wave, lane);
 }
 
-template <bool BF16, int BN, int NST>
+template <int MODE, int BN, int NST, int NTH = 512>
 static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
     constexpr int bytes = NST * (256 + BN) * 64;
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<BF16, BN, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     const int tiles = ((a.M + 255) / 256) * ((a.Cout + BN - 1) / BN);
-    hipLaunchKernelGGL((conv_gemm_big_kernel<BF16, BN, NST>), dim3(tiles), dim3(512), bytes, stream, a);
+    hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, BN, NST, NTH>), dim3(tiles), dim3(NTH), bytes, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -698,7 +769,11 @@ void set_big_mode(int mode) { g_big_mode = mode; }
 
 // the bf16-native kernel takes a layer when its gather is uniform-tap at k-tile 32 and the problem is large enough
 // to give every CU a 256-row tile with a K loop worth pipelining
-static int g_big_f32 = getenv("ODAM_CG_BIG_F32") ? atoi(getenv("ODAM_CG_BIG_F32")) : 0;   // fp32 layers on the 256-row kernel too
+// fp32 layers on the 256-row kernel: 0 = no (128x128 tiles on the fp32 matrix instruction), 1 = MODE 1 (measured slower than
+// those tiles), 2 = MODE 2 (products on the bf16 matrix instruction through the exact three-way split; the default: same
+// accuracy class as the fp32 instruction, every parity test unchanged, 1.26x the R50 forward)
+static int g_big_f32 = getenv("ODAM_CG_BIG_F32") ? atoi(getenv("ODAM_CG_BIG_F32")) : 2;
+void set_f32_mode(int mode) { g_big_f32 = mode; }
 static bool big_eligible(const ConvGemmArgs& a, int bn) {
     const bool bf = a.dtype == ODAM_CG_BF16;
     if (!bf && !g_big_f32) return false;
@@ -745,10 +820,19 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.Cout <= 0) return 0;
     if (g_big_mode) {
         const bool bf = a.dtype == ODAM_CG_BF16;
+        const bool x3 = !bf && g_big_f32 == 2;
+        static const int two_wg = getenv("ODAM_CG_TWO_WG") ? atoi(getenv("ODAM_CG_TWO_WG")) : 0;   // experiment: 1 = fp32 split, 2 = bf16 too
+        if (a.Cout >= 128 && ((x3 && two_wg == 1) || (bf && two_wg == 2)) && big_eligible(a, 128))
+            return bf ? launch_big<0, 128, 3, 256>(a, stream) : launch_big<2, 128, 3, 256>(a, stream);
+        if (x3 && two_wg == 3 && (a.Cout % 256 == 0 || a.Cout >= 384) && big_eligible(a, 256))   // one wave per SIMD, 128 x 128 each
+            return launch_big<2, 256, 4, 256>(a, stream);
         if (a.Cout % 256 == 0 || a.Cout >= 384) {
-            if (big_eligible(a, 256)) return bf ? launch_big<true, 256, 4>(a, stream) : launch_big<false, 256, 4>(a, stream);
-        } else if (a.Cout > 64 && g_big_mode >= 2 && big_eligible(a, 128)) {   // measured slower than the 128x128 tiles: tests only
-            return bf ? launch_big<true, 128, 4>(a, stream) : launch_big<false, 128, 4>(a, stream);
+            if (big_eligible(a, 256))
+                return bf ? launch_big<0, 256, 4>(a, stream) : (x3 ? launch_big<2, 256, 4>(a, stream) : launch_big<1, 256, 4>(a, stream));
+        } else if (a.Cout > 64 && (g_big_mode >= 2 || x3) && big_eligible(a, 128)) {   // bf16 / fp32: measured slower than the 128x128 tiles (tests only)
+            return bf ? launch_big<0, 128, 4>(a, stream) : (x3 ? launch_big<2, 128, 4>(a, stream) : launch_big<1, 128, 4>(a, stream));
+        } else if (x3 && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
+            return launch_big<2, 64, 4>(a, stream);
         }
     }
     static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 7;  // 8-wave tiles (+2-3 %)

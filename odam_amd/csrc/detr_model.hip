@@ -587,6 +587,14 @@ extern "C" int odam_op_conv_bf16_mode(int mode) {
     return 0;
 }
 
+// fp32 contraction mode of the 256-row kernel (conv_gemm.h set_f32_mode): 0 fp32 matrix instruction on 128x128 tiles,
+// 1 the same instruction in the ring kernel, 2 bf16 matrix instruction through the exact three-way split
+extern "C" int odam_op_conv_f32_mode(int mode) {
+    if (mode < 0 || mode > 2) return odam_fail(1, "odam_op_conv_f32_mode: mode must be 0, 1 or 2");
+    odam_cg::set_f32_mode(mode);
+    return 0;
+}
+
 extern "C" int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                                  int ldo, int B, int H, int Lq, int Lk, void* stream) {
     if (!Q || !K || !V || !O) return odam_fail(1, "odam_op_attention: null pointer");
