@@ -28,6 +28,9 @@ constexpr int ODAM_CG_BF16 = 1;
 struct ConvGemmArgs {
     const void* A;       // NHWC input [B, H, W, Cin] fp32 or bf16; Cin a power of two >= one 16-byte chunk (4 / 8)
     const void* Wt;      // [Cout][Kpad] same type, k-major, zero padded to a multiple of the k-tile (32 / 64)
+    const void* Wt3 = nullptr;   // fp32 layers, optional: the same filters split exactly into three bf16 values per weight,
+                         //    [Cout][Kpad / 16][3][16] (hi | mid | lo of every 16-k group; split3_filters); lets the split
+                         //    contraction mode (set_f32_mode 2) skip splitting them in registers
     const float* scale;  // [Cout] fp32 or nullptr
     const float* bias;   // [Cout] fp32 or nullptr
     const void* res;     // [M, Cout] activation type, or nullptr
@@ -57,5 +60,8 @@ void set_big_mode(int mode);
 // 2 (default) = products on the bf16 matrix instruction through an exact three-way bf16 split of both operands (six
 // MFMAs per 16 k; fp32-class accuracy, different last bits).  Also read once from ODAM_CG_BIG_F32.
 void set_f32_mode(int mode);
+
+// host: exact three-way bf16 split (truncation) of packed fp32 filters w[Cout][Kpad] (Kpad % 16 == 0) into the Wt3 layout
+void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out);
 
 }  // namespace odam_cg

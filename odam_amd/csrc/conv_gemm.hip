@@ -2,6 +2,7 @@
 #include "conv_gemm.h"
 
 #include <cstdlib>
+#include <cstring>
 
 #include "odam_err.h"
 
@@ -523,22 +524,42 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 // NTH = 512: one workgroup per CU (two waves per SIMD run the same tile in lock step).  NTH = 256 (BN <= 128): a four-wave
 // workgroup with the same 128x64 / 64x64 wave tile, TWO per CU with independent barriers -- one workgroup's k-tile boundary
 // (barrier, fragment latency, DMA issue) falls under the other's MFMAs.
+// dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
+template <int MODE, int BN, int NST, int NTH>
+constexpr int big_lds_bytes() {
+    const int ring = NST * (MODE == 3 ? 256 * 64 + 96 * BN : (256 + BN) * 64);
+    const int wm = MODE == 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
+    const int wn = NTH / 64 / wm;
+    const int slab = (NTH / 64) * 32 * (BN / wn) * 4;
+    return ring > slab ? ring : slab;
+}
+
 template <int MODE, int BN, int NST, int NTH = 512>
 __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     constexpr bool BF16 = MODE == 0;
+    // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
+    // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
+    // split in registers; the wave grid is 4 x 2 (64 x 128 per wave), so a wave splits 2 row tiles instead of 4 + 2
+    // -- a third of the vector work of MODE 2.
+    constexpr bool PRE = MODE == 3;
+    static_assert(!PRE || NTH == 512, "pre-split filters: eight-wave workgroups");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
     constexpr int BM = 256, BKE = 4 * EPC;
     constexpr int KU = 2 * BKE;             // channels per unit of the chunk-major K order (conv_gemm.h k_order)
     constexpr int NW = NTH / 64;
-    constexpr int WM = NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4), WN = NW / WM;
+    constexpr int WM = PRE ? (BN == 256 ? 4 : 8)
+                           : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4)), WN = NW / WM;
     // NTH = 256 with BN = 256: one wave per SIMD owns 128 x 128 (256 accumulator registers of the 512 a lone wave may use)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPP = NTH / 4;            // 128 tile rows per DMA pass (4 chunks of 16 bytes per row)
     constexpr int A_LD = BM / RPP, B_LD = (BN + RPP - 1) / RPP;   // BN < RPP: only the first waves carry filter rows
     constexpr int ROWB = 64;                // bytes per LDS row
-    constexpr int STAGE = (BM + BN) * ROWB; // bytes per ring stage
-    constexpr int LPT = A_LD + B_LD;        // DMA instructions per thread per tile
+    constexpr int A_BYTES = BM * ROWB;
+    constexpr int STAGE = PRE ? A_BYTES + 3 * BN * 32 : (BM + BN) * ROWB;   // bytes per ring stage (PRE: three 32-byte-row planes)
+    constexpr int NB3 = 3 * BN / 32;        // PRE: 1 KiB DMA instructions per filter tile (32 rows x 32 bytes each)
+    constexpr int B3_HI = (NB3 + NW - 1) / NW;   // ... per wave: B3_HI for waves < NB3 % NW (or all), B3_HI - 1 for the rest
+    constexpr int LPT = A_LD + (PRE ? B3_HI : B_LD);   // DMA instructions per thread per tile (waves that carry the most)
     extern __shared__ __align__(16) float smem[];   // NST * STAGE bytes (dynamic: 96 / 128 KiB)
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     const T* __restrict__ Ag = reinterpret_cast<const T*>(a.A);
@@ -598,9 +619,39 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     }
     const unsigned lds_base = (unsigned)(size_t)(lds_ptr_t)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const bool b_wave = BN >= RPP || wave_u * 16 < BN;     // BN = 64 with eight waves: waves 0-3 stage the filter rows
+    const bool b_wave = PRE ? (NB3 % NW == 0 || wave_u < NB3 % NW)     // PRE: this wave issues B3_HI (else B3_HI - 1) filter DMAs
+                            : (BN >= RPP || wave_u * 16 < BN);           // BN = 64 with eight waves: waves 0-3 stage the filter rows
+    // PRE: DMA instruction q = wave + 8 j of a tile covers plane q / (BN / 32), rows 32 (q % (BN / 32)) .. + 31; lane l
+    // writes row l >> 1, 16-byte half l & 1, and fetches half (l & 1) ^ ((row >> 3) & 1): with 32-byte rows the 16-lane
+    // groups of ds_read_b128 then see 16 distinct slots
+    unsigned w3_voff[B3_HI > 0 ? B3_HI : 1];
+    u32x4 w3_rs4 = w_rs4;
+    if constexpr (PRE) {
+        const unsigned long long p3 = (unsigned long long)a.Wt3;
+        w3_rs4 = u32x4{(unsigned)p3, (unsigned)(p3 >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+#pragma unroll
+        for (int j = 0; j < B3_HI; j++) {
+            const int q = wave_u + NW * j;
+            const int pl = q / (BN / 32), rb = q - pl * (BN / 32);
+            const int row = rb * 32 + (lane >> 1);
+            const int n = n0 + row;
+            const int cs = (lane & 1) ^ ((lane >> 4) & 1);
+            w3_voff[j] = (q < NB3 && n < a.Cout) ? (unsigned)(n * (a.Kpad / 16) * 96 + pl * 32 + cs * 16) : OOB_VOFF;
+        }
+    }
 
-    auto load_tile = [&](int kt, int st) {
+    // One tile's DMAs are LPT instructions per thread; tile_prep computes what is wave-uniform about them, dma_part issues
+    // the p-th.  The main loop spreads the parts between MFMA groups (a DMA instruction costs the issuing wave ~100
+    // cycles of issue; issued in one block right after the barrier those cycles leave the matrix pipe idle on both
+    // waves of the SIMD, which run in lock step).
+    // Measured: spreading changes nothing (fp32 split) or costs 3 % (bf16) -- the PMC split of a wave's cycles is one third
+    // issuing, one third waiting for the matrix pipe it shares with its SIMD partner, one third parked at s_waitcnt /
+    // the barrier, and the DMA issue is not what the parked third waits for.  Kept as a switch.
+#ifndef CG_SPREAD_DMA
+#define CG_SPREAD_DMA 0
+#endif
+    struct TilePrep { int tap, soff_a, soff_b; };
+    auto tile_prep = [&](int kt) {
         int tap, cbase;
         if (a.k_order) {   // chunk-major K in units of KU channels (conv_gemm.h): kt / 2 = chunk * ntaps + tap
             const int ku = kt >> 1, chunk = (ku * nt_inv) >> 16;
@@ -612,18 +663,26 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
             cbase = kb & (a.Cin - 1);
         }
         const int ky = (tap * kw_inv) >> 16, kx = tap - ky * a.KW;
-        const int soff = ((ky * a.W + kx) * lda + cbase) * (int)sizeof(T);
+        return TilePrep{tap, ((ky * a.W + kx) * lda + cbase) * (int)sizeof(T), PRE ? kt * 96 : kt * BKE * (int)sizeof(T)};
+    };
+    auto dma_part = [&](const TilePrep& tp, int st, int part) {      // part is a compile-time constant at every call site
         const unsigned sb = lds_base + (unsigned)(st * STAGE + wave_u * 16 * ROWB);
-#pragma unroll
-        for (int i = 0; i < A_LD; i++) {
-            const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB_VOFF;
-            lds_dma16(a_rs4, sb + (unsigned)(RPP * i * ROWB), vo, soff);
+        if (part < A_LD) {
+            const unsigned vo = ((a_mask[part] >> tp.tap) & 1u) ? a_voff[part] : OOB_VOFF;
+            lds_dma16(a_rs4, sb + (unsigned)(RPP * part * ROWB), vo, tp.soff_a);
+        } else if constexpr (PRE) {
+            const int j = part - A_LD;
+            if (j + 1 < B3_HI || b_wave)      // the last one only on the waves that carry B3_HI
+                lds_dma16(w3_rs4, lds_base + (unsigned)(st * STAGE + A_BYTES + (wave_u + NW * j) * 1024), w3_voff[j < B3_HI ? j : 0], tp.soff_b);
+        } else if (b_wave) {
+            const int i = part - A_LD;
+            lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), w_voff[i < B_LD ? i : 0], tp.soff_b);
         }
-        if (b_wave) {
+    };
+    auto load_tile = [&](int kt, int st) {
+        const TilePrep tp = tile_prep(kt);
 #pragma unroll
-            for (int i = 0; i < B_LD; i++)
-                lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), w_voff[i], kt * BKE * (int)sizeof(T));
-        }
+        for (int part = 0; part < LPT; part++) dma_part(tp, st, part);
     };
 
     floatx16 acc[TM][TN];
@@ -643,7 +702,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     int fq[2];
 #pragma unroll
     for (int q = 0; q < 2; q++)     // MODE 2: the lane's 8 consecutive k (chunks 2 half, 2 half + 1); else chunk 2 q + half
-        fq[q] = ((MODE == 2 ? 2 * (lane >> 5) + q : 2 * q + (lane >> 5)) ^ fsw) * 16;
+        fq[q] = ((MODE >= 2 ? 2 * (lane >> 5) + q : 2 * q + (lane >> 5)) ^ fsw) * 16;
 
     // exact split of 8 fp32 values (two 16-byte chunks) into three bf16x8 operands: hi = top 16 bits of a, mid = top 16
     // bits of a - hi, lo = a - hi - mid (at most 8 significant bits left, so its top 16 bits hold it exactly)
@@ -663,9 +722,52 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         lo = uint4{pk(ul[0], ul[1]), pk(ul[2], ul[3]), pk(ul[4], ul[5]), pk(ul[6], ul[7])};
     };
 
+    // PRE: filter fragment of row R = wn (BN / WN) + 32 j + (lane & 31) in plane p: 16 bytes at p BN 32 + R 32 + half'
+    const int b3_off = A_BYTES + (wn * (BN / WN) + frow) * 32 + (((lane >> 5) ^ ((frow >> 3) & 1)) * 16);
+
     auto mma_tile = [&](int st, auto&& issue_next) {
         const char* Ab = lds_c + st * STAGE + a_off;
         const char* Bb = lds_c + st * STAGE + b_off;
+        if constexpr (PRE) {
+            const char* B3 = lds_c + st * STAGE + b3_off;
+            uint4 bh[TN], bm[TN], bl[TN];
+            float4 a0, a1;
+            a0 = *reinterpret_cast<const float4*>(Ab + fq[0]);
+            a1 = *reinterpret_cast<const float4*>(Ab + fq[1]);
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                bh[j] = *reinterpret_cast<const uint4*>(B3 + j * 32 * 32);
+                bm[j] = *reinterpret_cast<const uint4*>(B3 + BN * 32 + j * 32 * 32);
+                bl[j] = *reinterpret_cast<const uint4*>(B3 + 2 * BN * 32 + j * 32 * 32);
+            }
+            int part = 0;
+            issue_next(part++);
+            if (!CG_SPREAD_DMA) {
+#pragma unroll
+                for (; part < LPT; part++) issue_next(part);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                uint4 ah, am, al;
+                split8(a0, a1, ah, am, al);
+                if (i + 1 < TM) {
+                    a0 = *reinterpret_cast<const float4*>(Ab + (i + 1) * 32 * ROWB + fq[0]);
+                    a1 = *reinterpret_cast<const float4*>(Ab + (i + 1) * 32 * ROWB + fq[1]);
+                }
+#define ODAM_MM(x, y) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc[i][j], 0, 0, 0)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    ODAM_MM(al, bh[j]); ODAM_MM(am, bm[j]); ODAM_MM(ah, bl[j]);
+                    ODAM_MM(am, bh[j]); ODAM_MM(ah, bm[j]);
+                    ODAM_MM(ah, bh[j]);
+                    if (part < LPT) issue_next(part++);      // one DMA under every six matrix instructions
+                }
+#undef ODAM_MM
+            }
+#pragma unroll
+            for (; part < LPT; part++) issue_next(part);
+            return;
+        }
         if constexpr (MODE == 2) {
             uint4 bh[TN], bm[TN], bl[TN];
             float4 b0[TN], b1[TN], a0, a1;
@@ -676,7 +778,12 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
             }
             a0 = *reinterpret_cast<const float4*>(Ab + fq[0]);
             a1 = *reinterpret_cast<const float4*>(Ab + fq[1]);
-            issue_next();
+            int part = 0;
+            issue_next(part++);
+            if (!CG_SPREAD_DMA) {
+#pragma unroll
+                for (; part < LPT; part++) issue_next(part);
+            }
 #pragma unroll
             for (int j = 0; j < TN; j++) split8(b0[j], b1[j], bh[j], bm[j], bl[j]);
 #pragma unroll
@@ -693,9 +800,12 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                     ODAM_MM(al, bh[j]); ODAM_MM(am, bm[j]); ODAM_MM(ah, bl[j]);
                     ODAM_MM(am, bh[j]); ODAM_MM(ah, bm[j]);
                     ODAM_MM(ah, bh[j]);
+                    if (part < LPT) issue_next(part++);
                 }
 #undef ODAM_MM
             }
+#pragma unroll
+            for (; part < LPT; part++) issue_next(part);
             return;
         }
         float4 af[2][TM], bf[2][TN];
@@ -703,7 +813,12 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[0]);
 #pragma unroll
         for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[0]);
-        issue_next();
+        int part = 0;
+        issue_next(part++);
+        if (!CG_SPREAD_DMA) {
+#pragma unroll
+            for (; part < LPT; part++) issue_next(part);
+        }
 #pragma unroll
         for (int i = 0; i < TM; i++) af[1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[1]);
 #pragma unroll
@@ -711,7 +826,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; q++)
 #pragma unroll
-            for (int i = 0; i < TM; i++)
+            for (int i = 0; i < TM; i++) {
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
                     if constexpr (BF16) {
@@ -724,6 +839,10 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].w, bf[q][j].w, acc[i][j], 0, 0, 0);
                     }
                 }
+                if (part < LPT) issue_next(part++);          // one DMA under every row of matrix instructions
+            }
+#pragma unroll
+        for (; part < LPT; part++) issue_next(part);
     };
 
     const int nk = a.Kpad / BKE;
@@ -736,24 +855,27 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         // barrier extends that to every wave and says ring slot (kt - 1) % NST has been read by all (it is refilled next)
         if (kt + NST - 1 <= nk) {
             if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * LPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * A_LD) : "memory");     // this wave stages no filter rows
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (PRE ? LPT - 1 : A_LD)) : "memory");   // this wave stages fewer / no filter rows
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        mma_tile(st, [&] { if (kt + NST - 1 < nk) load_tile(kt + NST - 1, st_next); });
+        const bool more = kt + NST - 1 < nk;
+        const TilePrep tp = tile_prep(more ? kt + NST - 1 : 0);
+        mma_tile(st, [&](int part) { if (more) dma_part(tp, st_next, part); });
         st = st + 1 == NST ? 0 : st + 1;
         st_next = st_next + 1 == NST ? 0 : st_next + 1;
     }
     __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
-    static_assert(WM * WN * 32 * (BN / WN) * 4 <= NST * STAGE, "epilogue staging fits the ring");
-    epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, NST * STAGE / 4, m0, n0, wm, wn, wave, lane);
+    static_assert(WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>(),
+                  "ring and epilogue staging fit the dynamic LDS");
+    epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
 }
 
 template <int MODE, int BN, int NST, int NTH = 512>
 static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
-    constexpr int bytes = NST * (256 + BN) * 64;
+    constexpr int bytes = big_lds_bytes<MODE, BN, NST, NTH>();
     static const bool attr_ok = [] {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
@@ -766,6 +888,26 @@ static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
 
 static int g_big_mode = getenv("ODAM_CG_BIG") ? atoi(getenv("ODAM_CG_BIG")) : 1;   // 0 off, 1 auto, 2 whenever eligible
 void set_big_mode(int mode) { g_big_mode = mode; }
+
+void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out) {
+    const int nk = Kpad / 16;
+    for (int n = 0; n < Cout; n++)
+        for (int kt = 0; kt < nk; kt++) {
+            unsigned short* o = out + ((size_t)n * nk + kt) * 48;
+            for (int e = 0; e < 16; e++) {
+                const float v = w[(size_t)n * Kpad + kt * 16 + e];
+                unsigned u;
+                memcpy(&u, &v, 4);
+                float fh; const unsigned uh = u & 0xffff0000u; memcpy(&fh, &uh, 4);
+                const float r1 = v - fh;
+                unsigned u1; memcpy(&u1, &r1, 4);
+                float fm; const unsigned um = u1 & 0xffff0000u; memcpy(&fm, &um, 4);
+                const float r2 = r1 - fm;
+                unsigned u2; memcpy(&u2, &r2, 4);
+                o[e] = (unsigned short)(u >> 16); o[16 + e] = (unsigned short)(u1 >> 16); o[32 + e] = (unsigned short)(u2 >> 16);
+            }
+        }
+}
 
 // the bf16-native kernel takes a layer when its gather is uniform-tap at k-tile 32 and the problem is large enough
 // to give every CU a 256-row tile with a K loop worth pipelining
@@ -826,13 +968,17 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
             return bf ? launch_big<0, 128, 3, 256>(a, stream) : launch_big<2, 128, 3, 256>(a, stream);
         if (x3 && two_wg == 3 && (a.Cout % 256 == 0 || a.Cout >= 384) && big_eligible(a, 256))   // one wave per SIMD, 128 x 128 each
             return launch_big<2, 256, 4, 256>(a, stream);
+        static const bool use_pre = getenv("ODAM_CG_NO_PRESPLIT") == nullptr;
+        const bool pre = x3 && a.Wt3 != nullptr && use_pre && a.Kpad % 16 == 0 && (long)a.Cout * a.Kpad * 6 < 0x7fffffffL;
         if (a.Cout % 256 == 0 || a.Cout >= 384) {
             if (big_eligible(a, 256))
-                return bf ? launch_big<0, 256, 4>(a, stream) : (x3 ? launch_big<2, 256, 4>(a, stream) : launch_big<1, 256, 4>(a, stream));
+                return bf ? launch_big<0, 256, 4>(a, stream)
+                          : (pre ? launch_big<3, 256, 4>(a, stream) : (x3 ? launch_big<2, 256, 4>(a, stream) : launch_big<1, 256, 4>(a, stream)));
         } else if (a.Cout > 64 && (g_big_mode >= 2 || x3) && big_eligible(a, 128)) {   // bf16 / fp32: measured slower than the 128x128 tiles (tests only)
-            return bf ? launch_big<0, 128, 4>(a, stream) : (x3 ? launch_big<2, 128, 4>(a, stream) : launch_big<1, 128, 4>(a, stream));
+            return bf ? launch_big<0, 128, 4>(a, stream)
+                      : (pre ? launch_big<3, 128, 4>(a, stream) : (x3 ? launch_big<2, 128, 4>(a, stream) : launch_big<1, 128, 4>(a, stream)));
         } else if (x3 && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
-            return launch_big<2, 64, 4>(a, stream);
+            return pre ? launch_big<3, 64, 4>(a, stream) : launch_big<2, 64, 4>(a, stream);
         }
     }
     static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 7;  // 8-wave tiles (+2-3 %)

@@ -30,6 +30,7 @@ struct HostTensor {
 
 struct Conv {          // packed convolution / linear layer on device
     void* w = nullptr;       // [Cout][Kpad], fp32 or bf16
+    void* w3 = nullptr;      // fp32 models: the same filters split into three bf16 planes (conv_gemm.h Wt3), or null
     float* scale = nullptr;  // [Cout] or null
     float* bias = nullptr;   // [Cout] or null
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
@@ -110,6 +111,18 @@ struct odam_detr {
         return 0;
     }
     // weights in the model's element type: fp32 as is, bf16 rounded to nearest even on the host
+    // fp32 models: the exact three-way bf16 split of a packed filter [Cout][Kpad] for the split contraction mode
+    int upload_w3(void** p, const std::vector<float>& v, int Cout, int Kpad) {
+        *p = nullptr;
+        if (dt != 0 || Kpad % 16 != 0 || (long)Cout * Kpad * 6 >= 0x7fffffffL) return 0;
+        std::vector<unsigned short> h((size_t)Cout * Kpad * 3);
+        odam_cg::split3_filters(v.data(), Cout, Kpad, h.data());
+        unsigned short* d = nullptr;
+        if (int rc = dev_alloc(&d, h.size())) return rc;
+        ODAM_HIP(hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        *p = d;
+        return 0;
+    }
     int upload_w(void** p, const std::vector<float>& v) {
         if (dt == 0) return upload((float**)p, v);
         std::vector<unsigned short> h(v.size());
@@ -162,6 +175,7 @@ int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad) {
                 }
     c.k_order = k_order;
     c.Cin = CinP; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
+    if (int rc = m->upload_w3(&c.w3, p, Cout, Kpad)) return rc;
     return m->upload_w(&c.w, p);
 }
 
@@ -170,6 +184,7 @@ int pack_linear(odam_detr* m, Conv& c, const HostTensor& w, const HostTensor* b,
     const int K = (int)w.shape[1];
     std::vector<float> p(w.data.begin() + (size_t)r0 * K, w.data.begin() + (size_t)r1 * K);
     c.Cin = K; c.Cout = r1 - r0; c.KH = c.KW = 1; c.stride = 1; c.pad = 0; c.Kpad = K;
+    if (int rc = m->upload_w3(&c.w3, p, r1 - r0, K)) return rc;
     if (int rc = m->upload_w(&c.w, p)) return rc;
     if (b) {
         std::vector<float> bb(b->data.begin() + r0, b->data.begin() + r1);
@@ -203,7 +218,7 @@ int run_conv(const Conv& c, const void* x, int B, int H, int W, const void* res,
              hipStream_t st, int dtype = 0, int out_f32 = 0) {
     ConvGemmArgs a{};
     a.dtype = dtype; a.out_f32 = out_f32;
-    a.A = x; a.Wt = c.w; a.scale = c.scale; a.bias = c.bias; a.res = res; a.C = y;
+    a.A = x; a.Wt = c.w; a.Wt3 = c.w3; a.scale = c.scale; a.bias = c.bias; a.res = res; a.C = y;
     a.B = B; a.H = H; a.W = W; a.Cin = c.Cin; a.log2Cin = ilog2(c.Cin);
     a.Ho = conv_out(H, c.KH, c.stride, c.pad); a.Wo = conv_out(W, c.KW, c.stride, c.pad);
     a.Cout = c.Cout; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad; a.Kpad = c.Kpad;
