@@ -32,6 +32,11 @@ int launch_nchw_to_nhwc4(const float* in, void* out, int B, int H, int W, int dt
 int launch_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, int dtype,
                         hipStream_t stream);
 
+// Fused stem (conv 7x7/2 + FrozenBN + ReLU + max-pool 3x3/2): img fp32 NCHW [B,3,H,W], w148 [64][148] fp32 with
+// k = (c*7 + ky)*7 + kx (147, one zero pad), scale / bias [64] -> out NHWC [B,H2,W2,64] in the activation type
+int launch_stem_pool(const float* img, const float* w148, const float* scale, const float* bias, void* out, int B, int H,
+                     int W, int dtype, hipStream_t stream);
+
 // NHWC [B,H,W,C] -> NCHW [B,C,H,W]  (only for exposing intermediate features to tests)
 int launch_nhwc_to_nchw(const void* in, float* out, int B, int H, int W, int C, int dtype, hipStream_t stream);
 

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -68,6 +69,8 @@ struct odam_detr {
     LN dec_norm;
     Conv class_embed;
     Conv mlp[5][3];  // bbox, offset, angle, size, depth
+    float* stem_w148 = nullptr;  // fused stem: conv1 filters [64][148], k = (c*7 + ky)*7 + kx (odam_dk::launch_stem_pool)
+    bool stem_fused = true;
     float* pos = nullptr;        // [L, 256]
     float* query_pos = nullptr;  // [Q, 256]
 
@@ -335,6 +338,13 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
         NEED(w, bb + "conv1.weight");
         RC(pack_conv(m, m->stem, *w, 2, 3));
         RC(fold_bn(m, m->stem, bb + "bn1"));
+        if (w->shape.size() == 4 && w->shape[0] == 64 && w->shape[1] == 3 && w->shape[2] == 7 && w->shape[3] == 7) {
+            std::vector<float> p148((size_t)64 * 148, 0.0f);
+            for (int o = 0; o < 64; o++)
+                for (int k = 0; k < 147; k++) p148[(size_t)o * 148 + k] = w->data[(size_t)o * 147 + k];   // [o][c][ky][kx] is already (c, ky, kx)-major
+            RC(m->upload(&m->stem_w148, p148));
+        }
+        m->stem_fused = m->stem_w148 != nullptr && (getenv("ODAM_STEM_FUSED") == nullptr || atoi(getenv("ODAM_STEM_FUSED")) != 0);
     }
     for (int l = 0; l < 4; l++) {
         for (int i = 0; i < c.resnet_blocks[l]; i++) {
@@ -462,9 +472,13 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
     auto off = [&](char* p, size_t n) { return p + n * es; };   // element offset in the activation type
 
     // ---- backbone (backbone.py:59-94) ----------------------------------------------------------
-    RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, dt, st));
-    RC(conv_t(m, m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, st));
-    RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, dt, st));
+    if (m->stem_fused) {   // conv1 + bn1 + relu + maxpool in one kernel, straight from the NCHW image
+        RC(odam_dk::launch_stem_pool(img, m->stem_w148, m->stem.scale, m->stem.bias, m->bufA, B, c.img_h, c.img_w, dt, st));
+    } else {
+        RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, dt, st));
+        RC(conv_t(m, m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, st));
+        RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, dt, st));
+    }
     char* cur = m->bufA;
     char* nxt = m->bufB;
     int H = m->H2, W = m->W2;
