@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 #include "odam_err.h"
 
@@ -14,6 +15,19 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // One k-tile is 8 chunks of 16 bytes per row in both precisions: 32 fp32 or 64 bf16 values; LDS rows are
 // padded by one chunk (144-byte rows: 16-byte aligned, conflict-free for ds_read_b128).
 constexpr int LDS_STRIDE = 36;  // floats per LDS row
+// CG_STAMP=1 (diagnostic build only, tests/native/ring_stamps.hip): the ring kernel accumulates s_memtime deltas of its
+// loop phases per wave (0 vmcnt wait + barrier, 1 fragment reads + DMA issue, 2 first half of the matrix instructions, 3
+// the rest) into g_stamps[0..3], k-tiles into [4], waves into [5].  No stamp executes in the product build.
+#ifndef CG_STAMP
+#define CG_STAMP 0
+#endif
+#if CG_STAMP
+__device__ unsigned long long g_stamps[8];
+#define CG_STAMP_AT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                            st_acc[i] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CG_STAMP_AT(i) do { } while (0)
+#endif
 #ifndef CG_ABLATE
 #define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores, 16 no first-tile load
 #endif
@@ -725,6 +739,9 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     // PRE: filter fragment of row R = wn (BN / WN) + 32 j + (lane & 31) in plane p: 16 bytes at p BN 32 + R 32 + half'
     const int b3_off = A_BYTES + (wn * (BN / WN) + frow) * 32 + (((lane >> 5) ^ ((frow >> 3) & 1)) * 16);
 
+#if CG_STAMP
+    unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
+#endif
     auto mma_tile = [&](int st, auto&& issue_next) {
         const char* Ab = lds_c + st * STAGE + a_off;
         const char* Bb = lds_c + st * STAGE + b_off;
@@ -746,6 +763,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
 #pragma unroll
                 for (; part < LPT; part++) issue_next(part);
             }
+            CG_STAMP_AT(1);
 #pragma unroll
             for (int i = 0; i < TM; i++) {
                 uint4 ah, am, al;
@@ -763,6 +781,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                     if (part < LPT) issue_next(part++);      // one DMA under every six matrix instructions
                 }
 #undef ODAM_MM
+                if (i == 0) CG_STAMP_AT(2);
             }
 #pragma unroll
             for (; part < LPT; part++) issue_next(part);
@@ -846,11 +865,158 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     };
 
     const int nk = a.Kpad / BKE;
+#ifndef CG_PRE_PIPE
+#define CG_PRE_PIPE 1
+#endif
+    if constexpr (PRE && CG_PRE_PIPE && NST == 4) {
+        // Pre-split filters, software-pipelined across the barrier.  Tile kt is consumed from REGISTERS: its fragments were
+        // read from the ring during iteration kt - 1 -- the filter fragments of column tile j into the registers that
+        // column's last matrix instruction has just released, the activation fragments into a second set, row tile 0
+        // already split -- so after the barrier a wave goes straight to matrix instructions, and fragment latency,
+        // splitting and DMA issue all sit between them (measured with CG_STAMP before this: of 4,330 cycles per k-tile a
+        // wave spent 890 at the barrier and 850 on reads + DMA issue before its first matrix instruction).
+        // Ring bookkeeping: at the barrier of iteration kt every wave's part of tile kt + 1 has landed (each waits with at
+        // most one tile of its DMAs outstanding) and every read of tile kt - 1 was consumed by iteration kt - 1's matrix
+        // instructions, so slot (kt + 3) % 4 = (kt - 1) % 4 is refilled with tile kt + 3.  Past the last tile the DMAs are
+        // still issued, out of bounds (zeros into a dead slot): the outstanding count stays uniform.
+        // The order of the matrix instructions on every accumulator is the one of the loop below: results are identical.
+        struct Ops { uint4 h, m, l; };       // one row tile's activations as three bf16x8 operands
+        Ops S[2];                            // row tile i of the tile in flight uses S[i & 1]; the next one is split into the other
+        uint4 bh[TN], bm[TN], bl[TN];
+        float4 ar0[TM], ar1[TM];
+        static_assert(TM == 1 || TN >= 3, "the pipelined schedule places a row tile's split and re-read under three column tiles");
+        constexpr int NC = TM * TN;          // chunks of six matrix instructions per k-tile
+        auto read_a = [&](int s_, int i) {
+            const char* Ab = lds_c + s_ * STAGE + a_off + i * 32 * ROWB;
+            ar0[i] = *reinterpret_cast<const float4*>(Ab + fq[0]);
+            ar1[i] = *reinterpret_cast<const float4*>(Ab + fq[1]);
+        };
+        auto read_b = [&](int s_, int j) {
+            const char* B3 = lds_c + s_ * STAGE + b3_off + j * 32 * 32;
+            bh[j] = *reinterpret_cast<const uint4*>(B3);
+            bm[j] = *reinterpret_cast<const uint4*>(B3 + BN * 32);
+            bl[j] = *reinterpret_cast<const uint4*>(B3 + 2 * BN * 32);
+        };
+        // half of split8: the four values of one 16-byte chunk -> elements (2 hf, 2 hf + 1) of the three operands
+        auto half_split = [](const float4& c, Ops& o, int hf) {
+            const float v[4] = {c.x, c.y, c.z, c.w};
+            unsigned uh[4], um[4], ul[4];
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uh[e] = __builtin_bit_cast(unsigned, v[e]);
+                const float r1 = v[e] - __builtin_bit_cast(float, uh[e] & 0xffff0000u);
+                um[e] = __builtin_bit_cast(unsigned, r1);
+                ul[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, um[e] & 0xffff0000u));
+            }
+            auto pk = [](unsigned lo_, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo_, 0x07060302u); };
+            if (hf == 0) {
+                o.h.x = pk(uh[0], uh[1]); o.h.y = pk(uh[2], uh[3]); o.m.x = pk(um[0], um[1]); o.m.y = pk(um[2], um[3]);
+                o.l.x = pk(ul[0], ul[1]); o.l.y = pk(ul[2], ul[3]);
+            } else {
+                o.h.z = pk(uh[0], uh[1]); o.h.w = pk(uh[2], uh[3]); o.m.z = pk(um[0], um[1]); o.m.w = pk(um[2], um[3]);
+                o.l.z = pk(ul[0], ul[1]); o.l.w = pk(ul[2], ul[3]);
+            }
+        };
+        auto dma_ok = [&](const TilePrep& tp, int s_, int part, bool ok) {   // dma_part, out of bounds when !ok
+            if (part < A_LD) {
+                const unsigned vo = (ok && ((a_mask[part] >> tp.tap) & 1u)) ? a_voff[part] : OOB_VOFF;
+                lds_dma16(a_rs4, lds_base + (unsigned)(s_ * STAGE + wave_u * 16 * ROWB + RPP * part * ROWB), vo, tp.soff_a);
+            } else {
+                const int j = part - A_LD;
+                if (j + 1 < B3_HI || b_wave)
+                    lds_dma16(w3_rs4, lds_base + (unsigned)(s_ * STAGE + A_BYTES + (wave_u + NW * j) * 1024),
+                              ok ? w3_voff[j < B3_HI ? j : 0] : OOB_VOFF, tp.soff_b);
+            }
+        };
+        constexpr int LPT_LO = LPT - 1;      // DMAs per tile of the waves that carry one filter piece less
+#pragma unroll
+        for (int s0 = 0; s0 < 3; s0++) {
+            const TilePrep tp = tile_prep(s0 < nk ? s0 : 0);
+#pragma unroll
+            for (int part = 0; part < LPT; part++) dma_ok(tp, s0, part, s0 < nk);
+        }
+        if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT_LO) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < TM; i++) read_a(0, i);
+#pragma unroll
+        for (int j = 0; j < TN; j++) read_b(0, j);
+        half_split(ar0[0], S[0], 0); half_split(ar1[0], S[0], 1);
+#if CG_STAMP
+        st_prev = __builtin_readcyclecounter();
+#endif
+#define ODAM_MM(x, y) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc[i][j], 0, 0, 0)
+        // One k-tile out of the registers, in NC chunks of six matrix instructions (row tile i x column tile j) fenced
+        // against reordering; what rides under each chunk:
+        //   chunks (i, 0), (i, 1)     the two halves of row tile i + 1's split           (i + 1 < TM)
+        //   chunk  (i, 2)             NEXT: row tile i + 1's raw fragment of tile kt + 1   (its registers were just split)
+        //   chunk  (0, 0)             NEXT: row tile 0's raw fragment of tile kt + 1
+        //   chunks (TM - 1, j)        NEXT: column tile j's filter fragments of tile kt + 1 (their last use is this chunk)
+        //   the last two chunks       NEXT: the halves of tile kt + 1's row tile 0 split
+        //   every chunk               NEXT: its share of the LPT DMA instructions of tile kt + 3
+        auto body = [&](auto next_c, int sn, const TilePrep& tp, int sf, bool ok) {
+            constexpr bool NEXT = decltype(next_c)::value;
+            int part = 0;
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int c = i * TN + j;
+                    const Ops& o = S[i & 1];
+                    ODAM_MM(o.l, bh[j]); ODAM_MM(o.m, bm[j]); ODAM_MM(o.h, bl[j]);
+                    ODAM_MM(o.m, bh[j]); ODAM_MM(o.h, bm[j]);
+                    ODAM_MM(o.h, bh[j]);
+                    if (i + 1 < TM) {
+                        if (j == 0) half_split(ar0[i + 1], S[(i + 1) & 1], 0);
+                        if (j == 1) half_split(ar1[i + 1], S[(i + 1) & 1], 1);
+                    }
+                    if constexpr (NEXT) {
+                        if (c == 0) read_a(sn, 0);
+                        if (i + 1 < TM && j == 2) read_a(sn, i + 1);
+                        if (i == TM - 1) read_b(sn, j);
+#pragma unroll
+                        for (; part < ((c + 1) * LPT + NC - 1) / NC; part++) dma_ok(tp, sf, part, ok);
+                        if (NC >= 4) {
+                            if (c == NC - 2) half_split(ar0[0], S[TM & 1], 0);
+                            if (c == NC - 1) half_split(ar1[0], S[TM & 1], 1);
+                        } else if (c == NC - 1) {
+                            half_split(ar0[0], S[TM & 1], 0); half_split(ar1[0], S[TM & 1], 1);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (c == TN - 1) CG_STAMP_AT(2);
+                }
+            }
+            if constexpr (NEXT && (TM & 1)) S[0] = S[1];
+        };
+        int sn = 1, sf = 3;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            CG_STAMP_AT(3);
+            if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");     // all but my newest tile (kt + 2): tile kt + 1 is in
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT_LO) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            CG_STAMP_AT(0);
+            const bool ok = kt + 3 < nk;
+            const TilePrep tp = tile_prep(ok ? kt + 3 : 0);
+            body(std::true_type{}, sn, tp, sf, ok);
+            sn = (sn + 1) & 3; sf = (sf + 1) & 3;
+        }
+        CG_STAMP_AT(3);
+        body(std::false_type{}, 0, TilePrep{0, 0, 0}, 0, false);
+#undef ODAM_MM
+    } else {
 #pragma unroll
     for (int s0 = 0; s0 < NST - 1; s0++)
         if (s0 < nk) load_tile(s0, s0);
     int st = 0, st_next = NST - 1;
+#if CG_STAMP
+    st_prev = __builtin_readcyclecounter();
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        if (kt) CG_STAMP_AT(3);
         // my DMAs retire in order: at most (NST - 2) tiles' worth outstanding = my part of tile kt has landed; the
         // barrier extends that to every wave and says ring slot (kt - 1) % NST has been read by all (it is refilled next)
         if (kt + NST - 1 <= nk) {
@@ -861,12 +1027,22 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        CG_STAMP_AT(0);
         const bool more = kt + NST - 1 < nk;
         const TilePrep tp = tile_prep(more ? kt + NST - 1 : 0);
         mma_tile(st, [&](int part) { if (more) dma_part(tp, st_next, part); });
         st = st + 1 == NST ? 0 : st + 1;
         st_next = st_next + 1 == NST ? 0 : st_next + 1;
     }
+    }
+#if CG_STAMP
+    CG_STAMP_AT(3);
+    if (lane == 0) {
+        for (int i = 0; i < 4; i++) atomicAdd(&g_stamps[i], st_acc[i]);
+        atomicAdd(&g_stamps[4], (unsigned long long)nk);
+        atomicAdd(&g_stamps[5], 1ull);
+    }
+#endif
     __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
     static_assert(WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>(),
                   "ring and epilogue staging fit the dynamic LDS");

@@ -535,9 +535,9 @@ __host__ __device__ constexpr int st_koff(int k) {    // float offset of filter 
     return k >= 147 ? 0 : (k / 49) * (ST_IH * ST_IW) + ((k % 49) / 7) * ST_IW + (k % 7);
 }
 
-template <typename T, int S>
-__device__ __forceinline__ void stem_steps(floatx16& acc0, floatx16& acc1, const float* in_lds, int b0, int b1, int b2, int b3,
-                                           const float (&w0)[ST_NS], const float (&w1)[ST_NS]) {
+// the 74 A-operand values of one M-tile for this lane: value S is pixel m's input at tap k = 2 S + half
+template <int S>
+__device__ __forceinline__ void stem_load_a(float (&av)[ST_NS], const float* in_lds, int b0, int b1, int b2, int b3) {
     if constexpr (S < ST_NS) {
         constexpr int e = st_koff(2 * S), d = st_koff(2 * S + 1) - e;
         // half 0 reads off(2 S), half 1 off(2 S + 1) = off(2 S) + d with d = 1, IW - 6 or IH IW - 6 IW - 6; for the zero
@@ -545,10 +545,8 @@ __device__ __forceinline__ void stem_steps(floatx16& acc0, floatx16& acc1, const
         constexpr int D1 = 1, D2 = ST_IW - 6, D3 = ST_IH * ST_IW - 6 * ST_IW - 6;
         static_assert(2 * S + 1 >= 147 || d == D1 || d == D2 || d == D3, "three kinds of neighbours");
         const int base = (2 * S + 1 >= 147) ? b0 : (d == D1 ? b1 : (d == D2 ? b2 : b3));
-        const float av = in_lds[base + e];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w0[S], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w1[S], acc1, 0, 0, 0);
-        stem_steps<T, S + 1>(acc0, acc1, in_lds, b0, b1, b2, b3, w0, w1);
+        av[S] = in_lds[base + e];
+        stem_load_a<S + 1>(av, in_lds, b0, b1, b2, b3);
     }
 }
 
@@ -568,7 +566,6 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
         w1[s] = w148[(n + 32) * ST_K + 2 * s + half];
     }
     const float sc0 = scale[n], sc1 = scale[n + 32], bi0 = bias[n], bi1 = bias[n + 32];
-    constexpr int D2 = ST_IW - 6, D3 = ST_IH * ST_IW - 6 * ST_IW - 6;
     const int n_tiles = B * tiles_y * tiles_x;
     for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
         const int b = t / (tiles_y * tiles_x), ty = (t / tiles_x) % tiles_y, tx = t % tiles_x;
@@ -583,17 +580,37 @@ __global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict_
             in_lds[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? ib[((size_t)c * H + y) * W + x] : 0.0f;
         }
         __syncthreads();
-#pragma unroll 1
-        for (int mt = 0; mt < ST_MT / 4; mt++) {
+        // A values of an M-tile are fetched one tile ahead (74 registers each): with one wave per SIMD nothing else
+        // hides the LDS latency, and a read in front of every four MFMAs stalled the matrix pipe a third of the time
+        constexpr int D2 = ST_IW - 6, D3 = ST_IH * ST_IW - 6 * ST_IW - 6;
+        auto bases = [&](int mt, int& b0, int& b1, int& b2, int& b3) {
             const int m = (wave * (ST_MT / 4) + mt) * 32 + n;                 // this lane's conv pixel of the M-tile
             const int mm = m < ST_CH * ST_CW ? m : 0;
             const int cy = mm / ST_CW, cx = mm - cy * ST_CW;
-            const int base = (2 * cy) * ST_IW + 2 * cx;
-            const int b1 = base + half, b2 = base + half * D2, b3 = base + half * D3;
+            b0 = (2 * cy) * ST_IW + 2 * cx;
+            b1 = b0 + half; b2 = b0 + half * D2; b3 = b0 + half * D3;
+        };
+        float av[2][ST_NS];
+        {
+            int b0, b1, b2, b3;
+            bases(0, b0, b1, b2, b3);
+            stem_load_a<0>(av[0], in_lds, b0, b1, b2, b3);
+        }
+#pragma unroll
+        for (int mt = 0; mt < ST_MT / 4; mt++) {
+            if (mt + 1 < ST_MT / 4) {
+                int b0, b1, b2, b3;
+                bases(mt + 1, b0, b1, b2, b3);
+                stem_load_a<0>(av[(mt + 1) & 1], in_lds, b0, b1, b2, b3);
+            }
             floatx16 a0, a1;
 #pragma unroll
             for (int r = 0; r < 16; r++) { a0[r] = 0.0f; a1[r] = 0.0f; }
-            stem_steps<T, 0>(a0, a1, in_lds, base, b1, b2, b3, w0, w1);
+#pragma unroll
+            for (int st = 0; st < ST_NS; st++) {
+                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt & 1][st], w0[st], a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt & 1][st], w1[st], a1, 0, 0, 0);
+            }
             // accumulator register r of lane (channel n, half) is conv pixel acc_row(r, half) of this M-tile
 #pragma unroll
             for (int r = 0; r < 16; r++) {

@@ -344,7 +344,10 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
                 for (int k = 0; k < 147; k++) p148[(size_t)o * 148 + k] = w->data[(size_t)o * 147 + k];   // [o][c][ky][kx] is already (c, ky, kx)-major
             RC(m->upload(&m->stem_w148, p148));
         }
-        m->stem_fused = m->stem_w148 != nullptr && (getenv("ODAM_STEM_FUSED") == nullptr || atoi(getenv("ODAM_STEM_FUSED")) != 0);
+        // Experiment, off unless ODAM_STEM_FUSED=1: measured at B = 32, 800x1066 the fused kernel ties the three-kernel stem in
+        // fp32 (36.5 vs 36.4 ms per forward) and loses 1 ms in bf16 -- one 156 KB workgroup per CU runs its window load,
+        // matrix and pooling phases one after another, while the separate kernels overlap across workgroups.
+        m->stem_fused = m->stem_w148 != nullptr && getenv("ODAM_STEM_FUSED") != nullptr && atoi(getenv("ODAM_STEM_FUSED")) != 0;
     }
     for (int l = 0; l < 4; l++) {
         for (int i = 0; i < c.resnet_blocks[l]; i++) {

@@ -1,0 +1,62 @@
+// Phase timing of the ring contraction kernel (conv_gemm.hip, conv_gemm_big_kernel) on single layers of the detector, and a
+// torch-free timing harness for it.  Built with CG_STAMP=1 the kernel accumulates s_memtime deltas per wave:
+//   phase 0  s_waitcnt vmcnt + s_barrier          phase 1  fragment ds_reads + LDS-DMA issue (ends when the reads landed)
+//   phase 2  first row tile: split + its MFMAs     phase 3  the other row tiles (+ loop bookkeeping)
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DCG_STAMP=1 -I odam_amd/csrc -o tests/native/ring_stamps tests/native/ring_stamps.hip
+//   ./tests/native/ring_stamps            (-DCG_STAMP=0: plain timing, no stamps execute)
+#include "../../odam_amd/csrc/conv_gemm.hip"
+#include <cstdio>
+#include <random>
+#include <vector>
+
+struct Shape { const char* name; int B, H, W, Cin, Cout, k, pad; };
+
+int main() {
+    const Shape shapes[] = {{"l3.c2", 32, 50, 67, 256, 256, 3, 1}, {"l4.c2", 32, 25, 34, 512, 512, 3, 1},
+                            {"l3.c1", 32, 50, 67, 1024, 256, 1, 0}, {"l4.c1", 32, 50, 67, 1024, 512, 1, 0},
+                            {"l2.c2", 32, 100, 134, 128, 128, 3, 1}, {"l2.c1", 32, 100, 134, 512, 128, 1, 0},
+                            {"l1.c2", 32, 200, 267, 64, 64, 3, 1}, {"l3.c3", 32, 50, 67, 256, 1024, 1, 0}};
+    std::mt19937 rng(1);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (const Shape& s : shapes) {
+        const int K = s.k * s.k * s.Cin, Kpad = (K + 31) / 32 * 32, M = s.B * s.H * s.W;
+        std::vector<float> x((size_t)M * s.Cin), w((size_t)s.Cout * Kpad, 0.f);
+        for (auto& v : x) v = nd(rng);
+        for (int n = 0; n < s.Cout; n++)
+            for (int k = 0; k < K; k++) w[(size_t)n * Kpad + k] = nd(rng) / sqrtf((float)K);
+        std::vector<unsigned short> w3((size_t)s.Cout * Kpad * 3);
+        odam_cg::split3_filters(w.data(), s.Cout, Kpad, w3.data());
+        float *dx, *dw, *dy; void* dw3;
+        hipMalloc(&dx, x.size() * 4); hipMalloc(&dw, w.size() * 4); hipMalloc(&dy, (size_t)M * s.Cout * 4); hipMalloc(&dw3, w3.size() * 2);
+        hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+        hipMemcpy(dw3, w3.data(), w3.size() * 2, hipMemcpyHostToDevice);
+        odam_cg::ConvGemmArgs a{};
+        a.A = dx; a.Wt = dw; a.Wt3 = dw3; a.C = dy; a.B = s.B; a.H = s.H; a.W = s.W; a.Cin = s.Cin;
+        a.log2Cin = 31 - __builtin_clz(s.Cin); a.Ho = s.H; a.Wo = s.W; a.Cout = s.Cout; a.KH = a.KW = s.k; a.stride = 1; a.pad = s.pad;
+        a.Kpad = Kpad; a.relu = 1; a.M = M; a.ldc = s.Cout; a.dtype = 0; a.k_order = (s.k > 1 && s.Cin % 32 == 0) ? 1 : 0;
+        for (int i = 0; i < 3; i++) odam_cg::launch_conv_gemm(a, 0);
+        hipDeviceSynchronize();
+#if CG_STAMP
+        unsigned long long z[8] = {0};
+        hipMemcpyToSymbol(HIP_SYMBOL(odam_cg::g_stamps), z, sizeof(z));
+#endif
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int n = 20;
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < n; i++) odam_cg::launch_conv_gemm(a, 0);
+        hipEventRecord(e1, 0); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double us = ms * 1e3 / n, tf = 2.0 * M * s.Cout * K / us / 1e6;
+        printf("%s M=%d N=%d K=%d: %8.1f us %7.1f TF", s.name, M, s.Cout, K, us, tf);
+#if CG_STAMP
+        hipMemcpyFromSymbol(z, HIP_SYMBOL(odam_cg::g_stamps), sizeof(z));
+        const double tiles = (double)z[4];   // wave-k-tiles
+        printf("  | per wave and k-tile: wait+barrier %6.0f  reads+dma %6.0f  first row tile %6.0f  rest %6.0f  (sum %6.0f cycles; %llu waves)",
+               z[0] / tiles, z[1] / tiles, z[2] / tiles, z[3] / tiles, (z[0] + z[1] + z[2] + z[3]) / tiles, z[5]);
+#endif
+        printf("\n");
+        hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dw3);
+    }
+    return 0;
+}
