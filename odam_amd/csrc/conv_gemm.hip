@@ -16,8 +16,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // padded by one chunk (144-byte rows: 16-byte aligned, conflict-free for ds_read_b128).
 constexpr int LDS_STRIDE = 36;  // floats per LDS row
 // CG_STAMP=1 (diagnostic build only, tests/native/ring_stamps.hip): the ring kernel accumulates s_memtime deltas of its
-// loop phases per wave (0 vmcnt wait + barrier, 1 fragment reads + DMA issue, 2 first half of the matrix instructions, 3
-// the rest) into g_stamps[0..3], k-tiles into [4], waves into [5].  No stamp executes in the product build.
+// loop phases per wave (1 s_waitcnt vmcnt, 0 s_barrier, 2 first half of the matrix instructions, 3 the rest; the
+// unpipelined loops: 0 wait + barrier, 1 fragment reads + DMA issue) into g_stamps[0..3], k-tiles into [4], waves into [5].  No stamp executes in the product build.
 #ifndef CG_STAMP
 #define CG_STAMP 0
 #endif
@@ -996,6 +996,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
             CG_STAMP_AT(3);
             if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");     // all but my newest tile (kt + 2): tile kt + 1 is in
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT_LO) : "memory");
+            CG_STAMP_AT(1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             CG_STAMP_AT(0);
@@ -1007,6 +1008,90 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         CG_STAMP_AT(3);
         body(std::false_type{}, 0, TilePrep{0, 0, 0}, 0, false);
 #undef ODAM_MM
+#ifndef CG_BF16_PIPE
+#define CG_BF16_PIPE 0   // measured on the same box (R50 / R101 bf16 forwards, B = 32): 13.87 / 20.3 ms with, 13.72 / 20.3 ms without
+#endif
+    } else if constexpr (BF16 && CG_BF16_PIPE && NST == 4) {
+        // bf16 operands, the same pipeline (experiment, off: no gain -- a bf16 k-tile is 16 matrix instructions per wave
+        // against 4 DMA instructions and 12 fragment reads, and the phase stamps show their issue, not the barrier, pacing it): tile kt's fragments sit in registers (af / bf), and every fragment register is
+        // re-read from tile kt + 1's ring slot right after the last matrix instruction that uses it (row fragment (q, i) after
+        // its TN products, column fragment (q, j) in the last row); the DMAs of tile kt + 3 are spread over the 2 TM rows.
+        float4 af[2][TM], bf[2][TN];
+        auto read_af = [&](int s_, int q, int i) { af[q][i] = *reinterpret_cast<const float4*>(lds_c + s_ * STAGE + a_off + i * 32 * ROWB + fq[q]); };
+        auto read_bf = [&](int s_, int q, int j) { bf[q][j] = *reinterpret_cast<const float4*>(lds_c + s_ * STAGE + b_off + j * 32 * ROWB + fq[q]); };
+        auto dma_ok = [&](const TilePrep& tp, int s_, int part, bool ok) {
+            const unsigned sb = lds_base + (unsigned)(s_ * STAGE + wave_u * 16 * ROWB);
+            if (part < A_LD) {
+                const unsigned vo = (ok && ((a_mask[part] >> tp.tap) & 1u)) ? a_voff[part] : OOB_VOFF;
+                lds_dma16(a_rs4, sb + (unsigned)(RPP * part * ROWB), vo, tp.soff_a);
+            } else if (b_wave) {
+                const int i = part - A_LD;
+                lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), ok ? w_voff[i < B_LD ? i : 0] : OOB_VOFF, tp.soff_b);
+            }
+        };
+#pragma unroll
+        for (int s0 = 0; s0 < 3; s0++) {
+            const TilePrep tp = tile_prep(s0 < nk ? s0 : 0);
+#pragma unroll
+            for (int part = 0; part < LPT; part++) dma_ok(tp, s0, part, s0 < nk);
+        }
+        if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * A_LD) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+#pragma unroll
+            for (int i = 0; i < TM; i++) read_af(0, q, i);
+#pragma unroll
+            for (int j = 0; j < TN; j++) read_bf(0, q, j);
+        }
+#if CG_STAMP
+        st_prev = __builtin_readcyclecounter();
+#endif
+        auto body = [&](auto next_c, int sn, const TilePrep& tp, int sf, bool ok) {
+            constexpr bool NEXT = decltype(next_c)::value;
+            constexpr int NR = 2 * TM;      // rows of TN matrix instructions per k-tile
+            int part = 0;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+#pragma unroll
+                for (int i = 0; i < TM; i++) {
+                    const int r = q * TM + i;
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
+                                                                            __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
+                        if constexpr (NEXT) {
+                            if (i == TM - 1) read_bf(sn, q, j);
+                        }
+                    }
+                    if constexpr (NEXT) {
+                        read_af(sn, q, i);
+#pragma unroll
+                        for (; part < ((r + 1) * LPT + NR - 1) / NR; part++) dma_ok(tp, sf, part, ok);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (r == TM - 1) CG_STAMP_AT(2);
+                }
+            }
+        };
+        int sn = 1, sf = 3;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            CG_STAMP_AT(3);
+            if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD) : "memory");
+            CG_STAMP_AT(1);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            CG_STAMP_AT(0);
+            const bool ok = kt + 3 < nk;
+            const TilePrep tp = tile_prep(ok ? kt + 3 : 0);
+            body(std::true_type{}, sn, tp, sf, ok);
+            sn = (sn + 1) & 3; sf = (sf + 1) & 3;
+        }
+        CG_STAMP_AT(3);
+        body(std::false_type{}, 0, TilePrep{0, 0, 0}, 0, false);
     } else {
 #pragma unroll
     for (int s0 = 0; s0 < NST - 1; s0++)

@@ -8,10 +8,12 @@ Reference citations (paths relative to /root/reference):
   frozen_bn ............ src/models/backbone.py:46-56
   resnet_body .......... torchvision.models.resnet50/101 (ResNet v1.5 bottleneck: stride on the 3x3,
                          blocks [3,4,6,3] / [3,4,23,3]) as instantiated at src/models/backbone.py:90-92;
-                         torchvision itself is not vendored in the reference and not installed here:
-                         PARITY UNPINNED for the ResNet body -- the public architecture
-                         is restated; everything else below is pinned against the imported reference
-                         (tests/golden/make_golden_detr.py).
+                         torchvision itself is not vendored in the reference and not installed here, so the
+                         ResNet body cannot be pinned against a reference run: the public
+                         architecture is restated and pinned against an independent third-party implementation
+                         of it instead (transformers.ResNetModel with the same weights, tests/test_resnet_pin.py:
+                         layer4 features agree to 2e-5 of their range for R50 and R101).  Everything else below
+                         is pinned against the imported reference (tests/golden/make_golden_detr.py).
   position_embedding ... src/models/position_encoding.py:26-46 (normalize=True, 128 feats/axis)
   transformer .......... src/models/transformer.py:45-57, 154-167, 217-238, 107-129
   detr_forward ......... src/models/detr.py:49-94

@@ -3,15 +3,19 @@
 //   phase 0  s_waitcnt vmcnt + s_barrier          phase 1  fragment ds_reads + LDS-DMA issue (ends when the reads landed)
 //   phase 2  first row tile: split + its MFMAs     phase 3  the other row tiles (+ loop bookkeeping)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DCG_STAMP=1 -I odam_amd/csrc -o tests/native/ring_stamps tests/native/ring_stamps.hip
-//   ./tests/native/ring_stamps            (-DCG_STAMP=0: plain timing, no stamps execute)
+//   ./tests/native/ring_stamps [bf16]     (-DCG_STAMP=0: plain timing, no stamps execute)
 #include "../../odam_amd/csrc/conv_gemm.hip"
 #include <cstdio>
+#include <cstring>
 #include <random>
 #include <vector>
 
 struct Shape { const char* name; int B, H, W, Cin, Cout, k, pad; };
 
-int main() {
+static unsigned short to_bf16(float v) { unsigned u; memcpy(&u, &v, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+
+int main(int argc, char** argv) {
+    const bool bf = argc > 1 && !strcmp(argv[1], "bf16");     // bf16 operands (MODE 0) instead of fp32 through the split
     const Shape shapes[] = {{"l3.c2", 32, 50, 67, 256, 256, 3, 1}, {"l4.c2", 32, 25, 34, 512, 512, 3, 1},
                             {"l3.c1", 32, 50, 67, 1024, 256, 1, 0}, {"l4.c1", 32, 50, 67, 1024, 512, 1, 0},
                             {"l2.c2", 32, 100, 134, 128, 128, 3, 1}, {"l2.c1", 32, 100, 134, 512, 128, 1, 0},
@@ -19,7 +23,7 @@ int main() {
     std::mt19937 rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
     for (const Shape& s : shapes) {
-        const int K = s.k * s.k * s.Cin, Kpad = (K + 31) / 32 * 32, M = s.B * s.H * s.W;
+        const int K = s.k * s.k * s.Cin, Kpad = (K + 63) / 64 * 64, M = s.B * s.H * s.W;
         std::vector<float> x((size_t)M * s.Cin), w((size_t)s.Cout * Kpad, 0.f);
         for (auto& v : x) v = nd(rng);
         for (int n = 0; n < s.Cout; n++)
@@ -28,13 +32,22 @@ int main() {
         odam_cg::split3_filters(w.data(), s.Cout, Kpad, w3.data());
         float *dx, *dw, *dy; void* dw3;
         hipMalloc(&dx, x.size() * 4); hipMalloc(&dw, w.size() * 4); hipMalloc(&dy, (size_t)M * s.Cout * 4); hipMalloc(&dw3, w3.size() * 2);
-        hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
-        hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+        if (bf) {
+            std::vector<unsigned short> xb(x.size()), wb(w.size());
+            for (size_t i = 0; i < x.size(); i++) xb[i] = to_bf16(x[i]);
+            for (size_t i = 0; i < w.size(); i++) wb[i] = to_bf16(w[i]);
+            hipMemcpy(dx, xb.data(), xb.size() * 2, hipMemcpyHostToDevice);
+            hipMemcpy(dw, wb.data(), wb.size() * 2, hipMemcpyHostToDevice);
+        } else {
+            hipMemcpy(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice);
+            hipMemcpy(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice);
+        }
         hipMemcpy(dw3, w3.data(), w3.size() * 2, hipMemcpyHostToDevice);
         odam_cg::ConvGemmArgs a{};
         a.A = dx; a.Wt = dw; a.Wt3 = dw3; a.C = dy; a.B = s.B; a.H = s.H; a.W = s.W; a.Cin = s.Cin;
         a.log2Cin = 31 - __builtin_clz(s.Cin); a.Ho = s.H; a.Wo = s.W; a.Cout = s.Cout; a.KH = a.KW = s.k; a.stride = 1; a.pad = s.pad;
-        a.Kpad = Kpad; a.relu = 1; a.M = M; a.ldc = s.Cout; a.dtype = 0; a.k_order = (s.k > 1 && s.Cin % 32 == 0) ? 1 : 0;
+        a.Kpad = Kpad; a.relu = 1; a.M = M; a.ldc = s.Cout; a.dtype = bf ? 1 : 0; a.k_order = (s.k > 1 && s.Cin % (bf ? 64 : 32) == 0) ? 1 : 0;
+        if (bf) a.Wt3 = nullptr;
         for (int i = 0; i < 3; i++) odam_cg::launch_conv_gemm(a, 0);
         hipDeviceSynchronize();
 #if CG_STAMP
@@ -52,7 +65,7 @@ int main() {
 #if CG_STAMP
         hipMemcpyFromSymbol(z, HIP_SYMBOL(odam_cg::g_stamps), sizeof(z));
         const double tiles = (double)z[4];   // wave-k-tiles
-        printf("  | per wave and k-tile: wait+barrier %6.0f  reads+dma %6.0f  first row tile %6.0f  rest %6.0f  (sum %6.0f cycles; %llu waves)",
+        printf("  | per wave and k-tile: barrier %6.0f  vmcnt %6.0f  first half %6.0f  rest %6.0f  (sum %6.0f cycles; %llu waves)",
                z[0] / tiles, z[1] / tiles, z[2] / tiles, z[3] / tiles, (z[0] + z[1] + z[2] + z[3]) / tiles, z[5]);
 #endif
         printf("\n");
