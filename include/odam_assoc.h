@@ -33,6 +33,15 @@ int odam_assoc_finalize(odam_assoc* m);
 int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, float* Z_out,
                        void* stream);
 
+/* diagnostics of the persistent matching kernel: enable != 0 makes the following forwards record a 100 MHz timestamp of
+ * workgroup 0 at kernel start and after every stage (5 per GNN layer, final projection, score matrix, Sinkhorn loop);
+ * out [host][n <= 128], if not null, receives the stamps of the last forward (synchronises the device). */
+int odam_assoc_stage_stamps(odam_assoc* m, int enable, unsigned long long* out, int n);
+
+/* diagnostics: copies a workspace buffer of the last forward to out [host][n]: which = 0 the row block X [(T+30), 512],
+ * 1 the descriptors [(T+30), 256], 2 the score matrix [T, 32] (synchronises the device) */
+int odam_assoc_debug_read(odam_assoc* m, int which, float* out, long long n);
+
 /* log_optimal_transport alone: scores [dev][m, n] with row stride lds, alpha = bin_score */
 int odam_assoc_sinkhorn(const float* scores, int lds, int m, int n, float alpha, int iters, float* Z_out, void* stream);
 

@@ -1007,6 +1007,9 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         }
         CG_STAMP_AT(3);
         body(std::false_type{}, 0, TilePrep{0, 0, 0}, 0, false);
+        // the out-of-bounds DMAs issued past the last tile still write (zeros) into the ring: they must have landed
+        // before the epilogue stages its output there (the compiler does not count DMAs issued from inline assembly)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ODAM_MM
 #ifndef CG_BF16_PIPE
 #define CG_BF16_PIPE 0   // measured on the same box (R50 / R101 bf16 forwards, B = 32): 13.87 / 20.3 ms with, 13.72 / 20.3 ms without
@@ -1092,6 +1095,9 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         }
         CG_STAMP_AT(3);
         body(std::false_type{}, 0, TilePrep{0, 0, 0}, 0, false);
+        // the out-of-bounds DMAs issued past the last tile still write (zeros) into the ring: they must have landed
+        // before the epilogue stages its output there (the compiler does not count DMAs issued from inline assembly)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
 #pragma unroll
     for (int s0 = 0; s0 < NST - 1; s0++)
@@ -1235,6 +1241,11 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
             if (big_eligible(a, 256))
                 return bf ? launch_big<0, 256, 4>(a, stream)
                           : (pre ? launch_big<3, 256, 4>(a, stream) : (x3 ? launch_big<2, 256, 4>(a, stream) : launch_big<1, 256, 4>(a, stream)));
+#ifndef CG_NO_BN128_FALLBACK
+            // too few 256-wide tiles to fill the device (the encoder's N = 256 layers at M = 27,200: 107) but enough 128-wide
+            // ones: the ring kernel on 256 x 128 tiles instead of the 128 x 128 tiles of the fp32 matrix instruction
+            if (pre && big_eligible(a, 128)) return launch_big<3, 128, 4>(a, stream);
+#endif
         } else if (a.Cout > 64 && (g_big_mode >= 2 || x3) && big_eligible(a, 128)) {   // bf16 / fp32: measured slower than the 128x128 tiles (tests only)
             return bf ? launch_big<0, 128, 4>(a, stream)
                       : (pre ? launch_big<3, 128, 4>(a, stream) : (x3 ? launch_big<2, 128, 4>(a, stream) : launch_big<1, 128, 4>(a, stream)));

@@ -16,8 +16,10 @@ reference's own outputs (a) when one world-position column of every track is sca
 its ulp-level self-sensitivity, the yardstick for a fit given IDENTICAL inputs) and (b) when every continuous track
 column (box, dimensions, position, azimuth) carries relative noise of 2e-5 (six seeds: the size by which two correct
 fp32 detectors differ, measured 1.2e-5 median / 1.9e-5 max between the GPU and this CPU run -- the yardstick for the
-fit at the end of the whole chain).  Inputs are regenerated from seeds
-(odam_amd.synth.make_sequence).  Run: python tests/golden/make_golden_e2e.py"""
+fit at the end of the whole chain).  Also stored: the assignment matrix of every association call (Z<i>), which the GPU
+test compares frame by frame together with the decisions taken from it.  Inputs are regenerated from seeds
+(odam_amd.synth.make_sequence).
+Run: python tests/golden/make_golden_e2e.py            (about 3 minutes on 8 cores)"""
 import os
 import sys
 
@@ -95,7 +97,13 @@ def main():
     net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0, scene=True), strict=True)
     net.eval()
     fwd = net.forward
-    net.forward = lambda data, thr, eval_only=False: fwd(data, thr, eval_only=eval_only, device="cpu")
+    zs = []
+
+    def forward(data, thr, eval_only=False):
+        out = fwd(data, thr, eval_only=eval_only, device="cpu")
+        zs.append(out["pred"][0][0].detach().numpy().astype(np.float32))
+        return out
+    net.forward = forward
 
     seq = synth.make_sequence(**SEQ)
     proc = ref_processor.OdamProcess(model, net, transforms.Transforms(size=SEQ["h"]), None, score_threshold=SCORE_THRESHOLD)
@@ -130,6 +138,9 @@ def main():
         d[f"merged{i}"] = t
     for fid, r in dets.items():
         d[f"det{fid}"] = r
+    d["n_calls"] = np.int32(len(zs))
+    for i, zz in enumerate(zs):
+        d[f"Z{i}"] = zz
     np.savez_compressed(os.path.join(HERE, "e2e.npz"), **d)
     print("e2e golden:", len(tracks), "tracks (lengths", [len(t) for t in tracks], ") ->", len(merged_in), "merged (lengths",
           [len(t) for t in merged_in], "); classes", [int(np.median(t[:, 1])) for t in tracks])

@@ -13,3 +13,14 @@ for c in range(int(z["n_cases"])):
     torch.cuda.synchronize(); t0 = time.time()
     for _ in range(50): a.assignment(tr, de, T, n)
     torch.cuda.synchronize(); print(f"{(time.time()-t0)/50*1e3:.3f} ms per frame (GNN + Sinkhorn, incl. host launch)")
+# stage stamps of the persistent matching kernel (last case)
+import ctypes
+from odam_amd import _lib
+L = _lib.lib()
+buf = (ctypes.c_ulonglong * 64)()
+L.odam_assoc_stage_stamps(a._handle(), 1, None, 0)
+a.assignment(tr, de, T, n); a.assignment(tr, de, T, n)
+L.odam_assoc_stage_stamps(a._handle(), 0, buf, 64)
+t = np.array(buf[:42], dtype=np.int64)
+d = np.diff(t) / 100.0
+print("stage us (8 x [qkv attn merge m0 m2], final):", " ".join(f"{x:.1f}" for x in d), "| total", (t[41] - t[0]) / 100.0)
