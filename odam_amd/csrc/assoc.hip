@@ -54,8 +54,17 @@ __global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ 
 // F.avg_pool1d over the L time steps of each track: out[s, c] = mean_l cat[(s*L + l), c]   (associator.py:231-232)
 __global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ cat, int L, float* __restrict__ out) {
     const int s = blockIdx.x, c = threadIdx.x;
+    const float* p = cat + (size_t)s * L * 512 + c;
     float acc = 0.0f;
-    for (int l = 0; l < L; l++) acc += cat[((size_t)s * L + l) * 512 + c];
+    int l = 0;
+    for (; l + 10 <= L; l += 10) {          // ten rows in flight, added in order (the sum is the sequential one)
+        float v[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) v[i] = p[(size_t)(l + i) * 512];
+#pragma unroll
+        for (int i = 0; i < 10; i++) acc += v[i];
+    }
+    for (; l < L; l++) acc += p[(size_t)l * 512];
     out[(size_t)s * 512 + c] = acc / (float)L;
 }
 
@@ -328,6 +337,134 @@ __global__ __launch_bounds__(PG_NT) void gnn_persistent_kernel(GnnArgs a) {
     stamp();
 }
 
+// ---- Sinkhorn for at most 31 columns (the associator's case: <= 30 detections + dustbin) ----------------------------------
+// Same iteration as sinkhorn_kernel; what differs is who reduces what.  A row (<= 32 entries) is one 16-lane DPP row of a
+// wavefront, two columns per lane: four rows per wavefront, 64 rows per sweep of the 16 waves, reduced by quad permutes and
+// half-row / row mirrors alone (register-file speed).  A wavefront takes two columns at once, lane = row; its 64-lane
+// reductions finish through v_readlane.  No ds_bpermute is left on the dependent path of an iteration, and Z is stored with
+// an odd row stride so that a column walks all LDS banks.  Measured per 100 iterations: DESIGN.md section 4.
+__device__ __forceinline__ float dpp_f(float v, int ctrl_sel) {
+    const int x = __builtin_bit_cast(int, v);
+    int r;
+    switch (ctrl_sel) {
+        case 0: r = __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false); break;     // quad_perm [1,0,3,2]
+        case 1: r = __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false); break;     // quad_perm [2,3,0,1]
+        case 2: r = __builtin_amdgcn_update_dpp(x, x, 0x141, 0xf, 0xf, false); break;    // row_half_mirror
+        default: r = __builtin_amdgcn_update_dpp(x, x, 0x140, 0xf, 0xf, false); break;   // row_mirror
+    }
+    return __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float max16(float v) {
+    v = fmaxf(v, dpp_f(v, 0)); v = fmaxf(v, dpp_f(v, 1)); v = fmaxf(v, dpp_f(v, 2)); v = fmaxf(v, dpp_f(v, 3));
+    return v;
+}
+__device__ __forceinline__ float sum16(float v) {
+    v += dpp_f(v, 0); v += dpp_f(v, 1); v += dpp_f(v, 2); v += dpp_f(v, 3);
+    return v;
+}
+
+// exp / log of the iteration: the hardware's v_exp_f32 / v_log_f32 (through exp2 / log2).  The library functions are a
+// range reduction and a polynomial each -- four of them sit on the dependent path of every iteration and were most of its
+// 1.9 us; arguments here are (x - max) <= 0 and sums in [1, 64], where the hardware forms are good to ~1e-6 relative.
+#define SK_EXP(x) __expf(x)
+#define SK_LOG(x) __logf(x)
+__global__ __launch_bounds__(SK_NT) void sinkhorn32_kernel(const float* __restrict__ scores, int lds, int m, int n,
+                                                           float alpha, int iters, float* __restrict__ out,
+                                                           const int* __restrict__ n_dev) {
+    extern __shared__ float sm[];
+    if (n_dev) n = *n_dev;
+    const int M1 = m + 1, N1 = n + 1;       // N1 <= 32
+    constexpr int ZS = 33;
+    float* Z = sm;                          // [M1][33]
+    float* u = Z + (size_t)M1 * ZS;         // [M1]
+    float* v = u + M1;                      // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = SK_NT / 64;
+    for (int i = tid; i < M1 * N1; i += SK_NT) {
+        const int r = i / N1, c = i - r * N1;
+        Z[r * ZS + c] = (r < m && c < n) ? scores[(size_t)r * lds + c] : alpha;
+    }
+    for (int i = tid; i < M1; i += SK_NT) u[i] = 0.0f;
+    if (tid < 32) v[tid] = 0.0f;
+    const float norm = -logf((float)m + (float)n);
+    const float log_mu_last = logf((float)n) + norm, log_nu_last = logf((float)m) + norm;
+    __syncthreads();
+    const int q4 = lane >> 4, l16 = lane & 15;
+    // 64-lane reductions: DPP inside the four 16-lane rows, then the four row results through SGPRs (v_readlane) --
+    // no ds_bpermute on the dependent path
+    auto max64 = [](float x) {
+        x = max16(x);
+        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 16));
+        const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 32));
+        const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 48));
+        return fmaxf(fmaxf(a0, a1), fmaxf(a2, a3));
+    };
+    auto sum64 = [](float x) {
+        x = sum16(x);
+        const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 0));
+        const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 16));
+        const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 32));
+        const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), 48));
+        return (a0 + a1) + (a2 + a3);
+    };
+    for (int it = 0; it < iters; ++it) {
+        // u: four rows per wavefront, one per 16-lane DPP row; a lane holds columns l16 and l16 + 16 of its row
+        for (int r0 = 4 * wave; r0 < M1; r0 += 4 * NWV) {
+            const int r = r0 + q4;
+            const bool ok0 = r < M1 && l16 < N1, ok1 = r < M1 && l16 + 16 < N1;
+            const float x0 = ok0 ? Z[r * ZS + l16] + v[l16] : -INFINITY;
+            const float x1 = ok1 ? Z[r * ZS + l16 + 16] + v[l16 + 16] : -INFINITY;
+            const float mx = max16(fmaxf(x0, x1));
+            const float e = sum16((ok0 ? SK_EXP(x0 - mx) : 0.0f) + (ok1 ? SK_EXP(x1 - mx) : 0.0f));
+            if (r < M1 && l16 == 0) u[r] = ((r < m) ? norm : log_mu_last) - (SK_LOG(e) + mx);
+        }
+        __syncthreads();
+        // v: columns wave and wave + 16 on this wavefront (two independent chains), lane = row
+        {
+            const int c0 = wave, c1 = wave + NWV;
+            const bool h0 = c0 < N1, h1 = c1 < N1;
+            float m0 = -INFINITY, m1 = -INFINITY;
+            for (int r = lane; r < M1; r += 64) {
+                const float ur = u[r];
+                if (h0) m0 = fmaxf(m0, Z[r * ZS + c0] + ur);
+                if (h1) m1 = fmaxf(m1, Z[r * ZS + c1] + ur);
+            }
+            m0 = max64(m0); m1 = max64(m1);
+            float e0 = 0.0f, e1 = 0.0f;
+            for (int r = lane; r < M1; r += 64) {
+                const float ur = u[r];
+                if (h0) e0 += SK_EXP(Z[r * ZS + c0] + ur - m0);
+                if (h1) e1 += SK_EXP(Z[r * ZS + c1] + ur - m1);
+            }
+            e0 = sum64(e0); e1 = sum64(e1);
+            if (lane == 0) {
+                if (h0) v[c0] = ((c0 < n) ? norm : log_nu_last) - (SK_LOG(e0) + m0);
+                if (h1) v[c1] = ((c1 < n) ? norm : log_nu_last) - (SK_LOG(e1) + m1);
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < M1 * N1; i += SK_NT) {
+        const int r = i / N1, c = i - r * N1;
+        out[i] = Z[r * ZS + c] + u[r] + v[c] - norm;
+    }
+}
+
+// log_optimal_transport on the device: the 31-column kernel where it applies, the general one otherwise
+static int launch_sinkhorn(const float* scores, int lds_, int m_, int n_, int n_cap, float alpha, int iters, float* Z_out,
+                           const int* n_dev, hipStream_t st) {
+    if (n_cap + 1 <= 32 && m_ + 1 <= 1100) {        // 1100 rows of 33 floats + u + v fit the 150 KB of dynamic LDS
+        const size_t lds = ((size_t)(m_ + 1) * 33 + (m_ + 1) + 32) * sizeof(float);
+        hipLaunchKernelGGL(sinkhorn32_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev);
+    } else {
+        const size_t lds = ((size_t)(m_ + 1) * (n_cap + 1) + (m_ + 1) + (n_cap + 1)) * sizeof(float);
+        hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev);
+    }
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
 int lin(const Lin& L, const float* x, int lda, int M, const float* res, bool relu, float* y, int ldc, const float* scale,
         hipStream_t st) {
     ConvGemmArgs a{};
@@ -529,6 +666,7 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     RC(m->alloc(&m->hX, (T + ND) * 512));
     RC(m->alloc(&m->mT, (T + ND + 2) * D)); RC(m->alloc(&m->scores, T * 32));   // the score block reads 32 detection rows
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     RC(m->alloc(&m->in_tracks, T * NF * NT)); RC(m->alloc(&m->in_det, (size_t)NF * ND)); RC(m->alloc(&m->out_Z, (T + 1) * (ND + 1)));
     float* nd = nullptr;
     RC(m->alloc(&nd, 1));
@@ -598,10 +736,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         const float* mD = m->mT + (size_t)T * D;
         Lin sc; sc.w = const_cast<float*>(mD); sc.b = nullptr; sc.K = D; sc.N = ND;
         RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
-        const size_t lds = ((size_t)(T + 1) * (n_det + 1) + (T + 1) + (n_det + 1)) * sizeof(float);
-        hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out, n_dev);
-        ODAM_HIP(hipGetLastError());
-        return 0;
+        return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, nullptr, st);
     }
     for (size_t i = 0; i < m->gnn.size(); i++) {
         const Prop& P = m->gnn[i];
@@ -622,10 +757,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
     const float* mD = m->mT + (size_t)T * D;
     Lin sc; sc.w = const_cast<float*>(mD); sc.b = nullptr; sc.K = D; sc.N = ND;
     RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
-    const size_t lds = ((size_t)(T + 1) * (n_det + 1) + (T + 1) + (n_det + 1)) * sizeof(float);
-    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, m->scores, 32, T, n_det, m->bin_score, m->iters, Z_out, n_dev);
-    ODAM_HIP(hipGetLastError());
-    return 0;
+    return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, n_dev, st);   // n_dev (graph replay): n_det is the capacity, 30
 }
 
 // One frame.  The sequence above is launch-bound (44 small GEMMs + 18 attention launches + prepare / pooling / Sinkhorn),
@@ -694,12 +826,9 @@ extern "C" int odam_assoc_sinkhorn(const float* scores, int lds_, int m_, int n_
         return odam_fail(1, "odam_assoc_sinkhorn: bad argument");
     static bool attr = false;
     if (!attr) {
+        ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr = true;
     }
-    const size_t lds = ((size_t)(m_ + 1) * (n_ + 1) + (m_ + 1) + (n_ + 1)) * sizeof(float);
-    hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, (hipStream_t)stream, scores, lds_, m_, n_, alpha, iters, Z_out,
-                       (const int*)nullptr);
-    ODAM_HIP(hipGetLastError());
-    return 0;
+    return launch_sinkhorn(scores, lds_, m_, n_, n_, alpha, iters, Z_out, nullptr, (hipStream_t)stream);
 }
