@@ -27,9 +27,12 @@ int odam_assoc_finalize(odam_assoc* m);
 
 /* tracks [dev][T,79,100] and detections [dev][79,30] in the associator's input layout (channel 0 = frame index,
  * -1 padding; processor.py:49-68, 155-179); Z_out [dev][(T+1),(n_det+1)] = log assignment incl. dustbins.
- * The ~65 launches of one forward are captured into a hipGraph the first time a track count T is seen and replayed
- * afterwards (inputs / result pass through buffers of the handle; stream-ordered, no host synchronisation);
- * ODAM_ASSOC_GRAPH=0 issues the launches one by one instead.  One handle serves one stream at a time. */
+ * Stream-ordered, no host synchronisation.  The encoder and the per-track fuser layers are launches on 100 T rows; the
+ * matching GNN layers and the final projection run as ONE persistent launch (256 workgroups, device-wide barriers between
+ * the stages, exchanged buffers coherent through sc1 accesses), then the score matrix and the Sinkhorn kernel.
+ * ODAM_ASSOC_PERSIST=0 issues the matching layers as separate launches instead (and ODAM_ASSOC_GRAPH=1 replays that
+ * sequence from a hipGraph per track count).  One handle serves one stream at a time; the persistent launch assumes its
+ * 256 small workgroups become co-resident, i.e. that no other kernel holds every CU indefinitely. */
 int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, float* Z_out,
                        void* stream);
 
