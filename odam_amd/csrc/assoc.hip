@@ -85,7 +85,7 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict__ scores, int lds, int m, int n,
                                                          float alpha, int iters, float* __restrict__ out,
-                                                         const int* __restrict__ n_dev) {
+                                                         const int* __restrict__ n_dev, const unsigned* __restrict__ err) {
     extern __shared__ float sm[];
     if (n_dev) n = *n_dev;      // replayed from a captured graph: the number of detections of THIS frame lives in memory
     const int M1 = m + 1, N1 = n + 1;
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict
     }
     for (int i = tid; i < M1 * N1; i += SK_NT) {
         const int r = i / N1, c = i - r * N1;
-        out[i] = Z[i] + u[r] + v[c] - norm;
+        out[i] = (err && *err) ? NAN : Z[i] + u[r] + v[c] - norm;     // a barrier of the matching kernel timed out: fail loudly downstream
     }
 }
 
@@ -370,7 +370,7 @@ __device__ __forceinline__ float sum16(float v) {
 #define SK_LOG(x) __logf(x)
 __global__ __launch_bounds__(SK_NT) void sinkhorn32_kernel(const float* __restrict__ scores, int lds, int m, int n,
                                                            float alpha, int iters, float* __restrict__ out,
-                                                           const int* __restrict__ n_dev) {
+                                                           const int* __restrict__ n_dev, const unsigned* __restrict__ err) {
     extern __shared__ float sm[];
     if (n_dev) n = *n_dev;
     const int M1 = m + 1, N1 = n + 1;       // N1 <= 32
@@ -447,19 +447,19 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn32_kernel(const float* __restri
     }
     for (int i = tid; i < M1 * N1; i += SK_NT) {
         const int r = i / N1, c = i - r * N1;
-        out[i] = Z[r * ZS + c] + u[r] + v[c] - norm;
+        out[i] = (err && *err) ? NAN : Z[r * ZS + c] + u[r] + v[c] - norm;
     }
 }
 
 // log_optimal_transport on the device: the 31-column kernel where it applies, the general one otherwise
 static int launch_sinkhorn(const float* scores, int lds_, int m_, int n_, int n_cap, float alpha, int iters, float* Z_out,
-                           const int* n_dev, hipStream_t st) {
+                           const int* n_dev, hipStream_t st, const unsigned* err = nullptr) {
     if (n_cap + 1 <= 32 && m_ + 1 <= 1100) {        // 1100 rows of 33 floats + u + v fit the 150 KB of dynamic LDS
         const size_t lds = ((size_t)(m_ + 1) * 33 + (m_ + 1) + 32) * sizeof(float);
-        hipLaunchKernelGGL(sinkhorn32_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev);
+        hipLaunchKernelGGL(sinkhorn32_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err);
     } else {
         const size_t lds = ((size_t)(m_ + 1) * (n_cap + 1) + (m_ + 1) + (n_cap + 1)) * sizeof(float);
-        hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev);
+        hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err);
     }
     ODAM_HIP(hipGetLastError());
     return 0;
@@ -736,7 +736,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         const float* mD = m->mT + (size_t)T * D;
         Lin sc; sc.w = const_cast<float*>(mD); sc.b = nullptr; sc.K = D; sc.N = ND;
         RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
-        return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, nullptr, st);
+        return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, nullptr, st, m->bar + 1);
     }
     for (size_t i = 0; i < m->gnn.size(); i++) {
         const Prop& P = m->gnn[i];
