@@ -272,8 +272,12 @@ def main():
                                                 "measured": "one forward alone on one stream, HIP event pair around every launch"}}
 
     if att_ms > 0:
-        result["attention_kernel"] = {"achieved": att_flops / (att_ms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA / 1e12,
-                                      "unit": "TFLOP/s", "frac": att_flops / (att_ms * 1e-3) / PEAK_FP32_MFMA,
+        att_x3 = os.environ.get("ODAM_ATT_X3", "1") != "0"      # fp32 attention through the exact bf16 split (the default)
+        att_peak = PEAK_F32_SPLIT if att_x3 else PEAK_FP32_MFMA
+        result["attention_kernel"] = {"achieved": att_flops / (att_ms * 1e-3) / 1e12, "peak": att_peak / 1e12,
+                                      "unit": "TFLOP/s", "frac": att_flops / (att_ms * 1e-3) / att_peak,
+                                      "kernel": ("attention_x3_kernel: fp32 operands, six bf16 matrix instructions per product block"
+                                                 if att_x3 else "attention_kernel on v_mfma_f32_32x32x2_f32"),
                                       "launches_per_forward": att_n, "ms_per_forward": att_ms, "batch": args.batch,
                                       "measured": "QK^T + PV flops of the fused attention kernel / its launch durations "
                                                   "(HIP events, one forward alone on one stream)"}

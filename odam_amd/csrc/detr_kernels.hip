@@ -338,6 +338,183 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
     }
 }
 
+// =================================================================================================
+// Fused attention for fp32 operands on the bf16 matrix instruction, d_head = 32: the dataflow of attention_bf16_kernel
+// with every product taken through the exact three-way bf16 split of conv_gemm.hip (a = hi + mid + lo by truncation, six
+// bf16 x bf16 products per fp32 product, fp32 accumulate; max error vs float64 0.8-1.4e-7 of sum |a b|, the fp32 matrix
+// instruction's own chain 1.1-1.9e-7).  K and V tiles are split once when they are staged (three bf16 planes each in
+// LDS, K key-major with the swizzle of the bf16 kernel, V transposed), the pre-scaled query fragment is split once per
+// workgroup, the probabilities -- fp32 in the S^T accumulators -- are split in registers and are the B operand of the PV
+// product as they stand.  Per 64-key tile and wave 48 matrix instructions of 32 cycles against 64 of 64 on
+// v_mfma_f32_32x32x2_f32.  Softmax as in the fp32 kernel (q pre-scaled, __expf).
+// =================================================================================================
+__device__ __forceinline__ void att_split8(const float4& c0, const float4& c1, uint4& hi, uint4& mid, uint4& lo) {
+    const float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    unsigned uh[8], um[8], ul[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        uh[e] = __builtin_bit_cast(unsigned, v[e]);
+        const float r1 = v[e] - __builtin_bit_cast(float, uh[e] & 0xffff0000u);
+        um[e] = __builtin_bit_cast(unsigned, r1);
+        ul[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, um[e] & 0xffff0000u));
+    }
+    auto pk = [](unsigned lo_, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo_, 0x07060302u); };   // two top halves
+    hi = uint4{pk(uh[0], uh[1]), pk(uh[2], uh[3]), pk(uh[4], uh[5]), pk(uh[6], uh[7])};
+    mid = uint4{pk(um[0], um[1]), pk(um[2], um[3]), pk(um[4], um[5]), pk(um[6], um[7])};
+    lo = uint4{pk(ul[0], ul[1]), pk(ul[2], ul[3]), pk(ul[4], ul[5]), pk(ul[6], ul[7])};
+}
+
+__global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restrict__ Q, int ldq,
+                                                           const float* __restrict__ K, int ldk,
+                                                           const float* __restrict__ V, int ldv,
+                                                           float* __restrict__ O, int ldo, int Lq, int Lk, float scale,
+                                                           const unsigned char* __restrict__ key_mask) {
+    constexpr int KT = 64, D = 32, VLD = KT + 4;
+    __shared__ __align__(16) uint4 Ks[2][3][KT * 4];
+    __shared__ __align__(16) unsigned short Vt[2][3][D][VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, col = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float* Qb = Q + (size_t)b * Lq * ldq + h * D;
+    const float* Kb = K + (size_t)b * Lk * ldk + h * D;
+    const float* Vb = V + (size_t)b * Lk * ldv + h * D;
+
+    uint4 qh[2], qm[2], ql[2];     // B operand of S^T = K . Q^T: lane (query col, half) holds Q[q][16 s + 8 half .. + 7], pre-scaled
+    {
+        const int q = q0 + col;
+#pragma unroll
+        for (int st = 0; st < 2; st++) {
+            float4 a = float4{0.f, 0.f, 0.f, 0.f}, c = a;
+            if (q < Lq) {
+                a = ld4(Qb + (size_t)q * ldq + 16 * st + 8 * half);
+                c = ld4(Qb + (size_t)q * ldq + 16 * st + 8 * half + 4);
+            }
+            a.x *= scale; a.y *= scale; a.z *= scale; a.w *= scale;
+            c.x *= scale; c.y *= scale; c.z *= scale; c.w *= scale;
+            att_split8(a, c, qh[st], qm[st], ql[st]);
+        }
+    }
+    const int lk = tid >> 2, lc = tid & 3;          // loader: key row of the tile, 8-channel chunk
+    auto load_kv = [&](int kt, float4 (&kr)[2], float4 (&vr)[2]) {
+        const int key = kt * KT + lk;
+        if (key < Lk) {
+            kr[0] = ld4(Kb + (size_t)key * ldk + lc * 8); kr[1] = ld4(Kb + (size_t)key * ldk + lc * 8 + 4);
+            vr[0] = ld4(Vb + (size_t)key * ldv + lc * 8); vr[1] = ld4(Vb + (size_t)key * ldv + lc * 8 + 4);
+        } else {
+            kr[0] = kr[1] = vr[0] = vr[1] = float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto store_kv = [&](int buf, const float4 (&kr)[2], const float4 (&vr)[2]) {
+        uint4 p[3];
+        att_split8(kr[0], kr[1], p[0], p[1], p[2]);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) Ks[buf][pl][lk * 4 + (lc ^ ((lk >> 2) & 3))] = p[pl];
+        att_split8(vr[0], vr[1], p[0], p[1], p[2]);
+#pragma unroll
+        for (int pl = 0; pl < 3; pl++) {
+            const unsigned w[4] = {p[pl].x, p[pl].y, p[pl].z, p[pl].w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                Vt[buf][pl][lc * 8 + 2 * e][lk] = (unsigned short)(w[e] & 0xffffu);
+                Vt[buf][pl][lc * 8 + 2 * e + 1][lk] = (unsigned short)(w[e] >> 16);
+            }
+        }
+    };
+#define ODAM_MMA(acc, a, bq) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0)
+
+    floatx16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) oacc[r] = 0.0f;
+    float m_run = -1e30f, l_run = 0.0f;
+    const int ntiles = (Lk + KT - 1) / KT;
+    float4 kr[2], vr[2];
+    load_kv(0, kr, vr);
+    store_kv(0, kr, vr);
+    __syncthreads();
+    for (int kt = 0; kt < ntiles; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < ntiles) load_kv(kt + 1, kr, vr);
+        floatx16 s[2];
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[jh][r] = 0.0f;
+            const int key = jh * 32 + col;
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                const int idx = key * 4 + ((2 * st + half) ^ ((key >> 2) & 3));
+                const uint4 kh = Ks[cur][0][idx], km = Ks[cur][1][idx], kl = Ks[cur][2][idx];
+                ODAM_MMA(s[jh], kl, qh[st]); ODAM_MMA(s[jh], km, qm[st]); ODAM_MMA(s[jh], kh, ql[st]);     // smallest products first
+                ODAM_MMA(s[jh], km, qh[st]); ODAM_MMA(s[jh], kh, qm[st]);
+                ODAM_MMA(s[jh], kh, qh[st]);
+            }
+        }
+        const int kbase = kt * KT;
+        if (kbase + KT > Lk || key_mask) {
+            const unsigned char* mk = key_mask ? key_mask + (size_t)b * Lk + kbase : nullptr;
+#pragma unroll
+            for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int k = jh * 32 + acc_row(r, half);
+                    if (kbase + k >= Lk || (mk && mk[k])) s[jh][r] = -1e30f;
+                }
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) mx = fmaxf(mx, s[jh][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float psum = 0.0f;
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                s[jh][r] = __expf(s[jh][r] - m_new);
+                psum += s[jh][r];
+            }
+        psum += __shfl_xor(psum, 32);
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; r++) oacc[r] *= alpha;
+        // O^T += V^T . P^T: the accumulator registers 8 st .. 8 st + 7 of s[jh], split, are the B operand of k-step (jh, st)
+#pragma unroll
+        for (int jh = 0; jh < 2; jh++)
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                uint4 ph, pm, pl_;
+                att_split8(float4{s[jh][8 * st + 0], s[jh][8 * st + 1], s[jh][8 * st + 2], s[jh][8 * st + 3]},
+                           float4{s[jh][8 * st + 4], s[jh][8 * st + 5], s[jh][8 * st + 6], s[jh][8 * st + 7]}, ph, pm, pl_);
+                uint4 vf[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; pl++) {
+                    const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[cur][pl][col][jh * 32 + 16 * st + 4 * half]);
+                    const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[cur][pl][col][jh * 32 + 16 * st + 8 + 4 * half]);
+                    vf[pl] = uint4{lo.x, lo.y, hi.x, hi.y};
+                }
+                ODAM_MMA(oacc, vf[2], ph); ODAM_MMA(oacc, vf[1], pm); ODAM_MMA(oacc, vf[0], pl_);
+                ODAM_MMA(oacc, vf[1], ph); ODAM_MMA(oacc, vf[0], pm);
+                ODAM_MMA(oacc, vf[0], ph);
+            }
+        if (kt + 1 < ntiles) store_kv(cur ^ 1, kr, vr);
+        __syncthreads();
+    }
+#undef ODAM_MMA
+    const int q = q0 + col;
+    if (q < Lq) {
+        const float inv = 1.0f / l_run;
+        float* Ob = O + ((size_t)b * Lq + q) * ldo + h * D;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            st4(Ob + 8 * g + 4 * half, float4{oacc[4 * g + 0] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv});
+    }
+}
+
 int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                      int B, int H, int Lq, int Lk, int dtype, hipStream_t stream, const unsigned char* key_mask) {
     if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
@@ -347,6 +524,14 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
     if (dtype == 1 && bf16_mfma && (ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0) {
         hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                            (const bf16_t*)V, ldv, (bf16_t*)O, ldo, Lq, Lk, scale * 1.44269504088896341f, key_mask);
+        ODAM_HIP(hipGetLastError());
+        return 0;
+    }
+    // fp32: products through the exact three-way bf16 split (ODAM_ATT_X3=0 keeps the fp32 matrix instruction)
+    static const bool x3 = !(getenv("ODAM_ATT_X3") != nullptr && atoi(getenv("ODAM_ATT_X3")) == 0);
+    if (dtype == 0 && x3 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0) {
+        hipLaunchKernelGGL(attention_x3_kernel, grid, dim3(256), 0, stream, (const float*)Q, ldq, (const float*)K, ldk,
+                           (const float*)V, ldv, (float*)O, ldo, Lq, Lk, scale, key_mask);
         ODAM_HIP(hipGetLastError());
         return 0;
     }
