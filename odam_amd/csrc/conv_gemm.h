@@ -60,6 +60,7 @@ void set_big_mode(int mode);
 // 2 (default) = products on the bf16 matrix instruction through an exact three-way bf16 split of both operands (six
 // MFMAs per 16 k; fp32-class accuracy, different last bits).  Also read once from ODAM_CG_BIG_F32.
 void set_f32_mode(int mode);
+int f32_mode();    // the mode fp32 layers run in right now (0 when the ring kernel is switched off altogether)
 
 // host: exact three-way bf16 split (truncation) of packed fp32 filters w[Cout][Kpad] (Kpad % 16 == 0) into the Wt3 layout
 void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out);

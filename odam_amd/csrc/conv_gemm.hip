@@ -1183,6 +1183,7 @@ void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out) {
 // accuracy class as the fp32 instruction, every parity test unchanged, 1.26x the R50 forward)
 static int g_big_f32 = getenv("ODAM_CG_BIG_F32") ? atoi(getenv("ODAM_CG_BIG_F32")) : 2;
 void set_f32_mode(int mode) { g_big_f32 = mode; }
+int f32_mode() { return g_big_mode ? g_big_f32 : 0; }
 static bool big_eligible(const ConvGemmArgs& a, int bn) {
     const bool bf = a.dtype == ODAM_CG_BF16;
     if (!bf && !g_big_f32) return false;

@@ -27,6 +27,8 @@ int launch_add_pos(const void* x, const float* pos, int L, void* out, int M, int
 
 // fp32 [B,3,H,W] -> [B,H,W,4] fp32 (4th channel zero) or [B,H,W,8] bf16 (one 16-byte chunk per pixel)
 int launch_nchw_to_nhwc4(const float* in, void* out, int B, int H, int W, int dtype, hipStream_t stream);
+// fp32 only: NHWC4 with a zero frame of 3 rows / 3 + 5 columns, [B][H + 6][W + 8][4] (the stem as a 7x1 convolution over 8-pixel rows)
+int launch_nchw_to_nhwc4_framed(const float* in, float* out, int B, int H, int W, hipStream_t stream);
 
 // NHWC max-pool 3x3 stride 2 pad 1 (torchvision ResNet stem)
 int launch_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, int dtype,

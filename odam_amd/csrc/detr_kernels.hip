@@ -645,6 +645,35 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
     }
 }
 
+// fp32 NCHW -> NHWC4 with a zero frame: out [B][H + 6][W + 8][4], the image at rows 3 .. H + 2, columns 3 .. W + 2.
+// What the stem-as-rows convolution reads (detr_model.hip, stem_rows): 8 consecutive pixels = 32 floats per filter row.
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_framed_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                   int H, int W, size_t total) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // pixel index over B*(H+6)*(W+8)
+    if (i >= total) return;
+    const int Wp = W + 8, Hp = H + 6;
+    const int xp = (int)(i % Wp);
+    const size_t r = i / Wp;
+    const int yp = (int)(r % Hp);
+    const size_t b = r / Hp;
+    const int x = xp - 3, y = yp - 3;
+    float4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) {
+        const size_t HW = (size_t)H * W;
+        const float* sp = in + b * 3 * HW + (size_t)y * W + x;
+        v = float4{sp[0], sp[HW], sp[2 * HW], 0.0f};
+    }
+    st4(out + i * 4, v);
+}
+
+int launch_nchw_to_nhwc4_framed(const float* in, float* out, int B, int H, int W, hipStream_t stream) {
+    const size_t total = (size_t)B * (H + 6) * (W + 8);
+    if (!total) return 0;
+    hipLaunchKernelGGL(nchw_to_nhwc4_framed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, H, W, total);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
 int launch_nchw_to_nhwc4(const float* in, void* out, int B, int H, int W, int dtype, hipStream_t stream) {
     const size_t total = (size_t)B * H * W;
     if (!total) return 0;

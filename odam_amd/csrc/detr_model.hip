@@ -69,6 +69,7 @@ struct odam_detr {
     LN dec_norm;
     Conv class_embed;
     Conv mlp[5][3];  // bbox, offset, angle, size, depth
+    Conv stem_rows;              // fp32: conv1 as a 7x1 convolution over 32-float rows of the framed NHWC4 image (see forward_impl)
     float* stem_w148 = nullptr;  // fused stem: conv1 filters [64][148], k = (c*7 + ky)*7 + kx (odam_dk::launch_stem_pool)
     bool stem_fused = true;
     float* pos = nullptr;        // [L, 256]
@@ -251,6 +252,34 @@ int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, cons
     m->ev_used += 2;
     return rc;
 }
+// conv1 over the framed image (forward_impl): the arguments run_conv cannot derive -- output width from the true image,
+// pixel stride smaller than the row length
+int stem_rows_t(odam_detr* m, int B, hipStream_t st) {
+    const Conv& c = m->stem_rows;
+    const odam_detr_cfg& g = m->cfg;
+    ConvGemmArgs a{};
+    a.dtype = 0; a.out_f32 = 0;
+    a.A = m->x4; a.Wt = c.w; a.Wt3 = c.w3; a.scale = c.scale; a.bias = c.bias; a.res = nullptr; a.C = m->stem_out;
+    a.B = B; a.H = g.img_h + 6; a.W = g.img_w + 8; a.Cin = 32; a.log2Cin = 5; a.lda = 4;
+    a.Ho = m->H1; a.Wo = m->W1;
+    a.Cout = c.Cout; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0; a.Kpad = c.Kpad;
+    a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = c.Cout; a.k_order = 1;
+    if (!m->profile) return odam_cg::launch_conv_gemm(a, st);
+    if (m->ev_used + 2 > m->ev.size()) {
+        for (int k = 0; k < 2; k++) {
+            hipEvent_t e;
+            ODAM_HIP(hipEventCreate(&e));
+            m->ev.push_back(e);
+        }
+        m->ev_flops.resize(m->ev.size() / 2);
+    }
+    m->ev_flops[m->ev_used / 2] = 2.0 * a.M * (double)c.Cout * 147;      // the algorithmic products, not the 224 issued
+    ODAM_HIP(hipEventRecord(m->ev[m->ev_used], st));
+    int rc = odam_cg::launch_conv_gemm(a, st);
+    ODAM_HIP(hipEventRecord(m->ev[m->ev_used + 1], st));
+    m->ev_used += 2;
+    return rc;
+}
 int lin_t(odam_detr* m, const Conv& c, const void* x, int M, const void* res, bool relu, void* y, hipStream_t st,
           int out_f32 = 0) {
     return conv_t(m, c, x, 1, 1, M, res, relu, y, st, out_f32);
@@ -347,6 +376,22 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
         // Experiment, off unless ODAM_STEM_FUSED=1: measured at B = 32, 800x1066 the fused kernel ties the three-kernel stem in
         // fp32 (36.5 vs 36.4 ms per forward) and loses 1 ms in bf16 -- one 156 KB workgroup per CU runs its window load,
         // matrix and pooling phases one after another, while the separate kernels overlap across workgroups.
+        if (!m->dt) {
+            // conv1 as KH = 7, KW = 1, Cin = 32: filter row ky of output channel o is the 28 floats w[o][c][ky][kx] at
+            // position 4 kx + c (what 7 consecutive NHWC4 pixels hold), then 4 zeros; K = 7 * 32 = 224
+            const int Cout = (int)w->shape[0];
+            std::vector<float> pr((size_t)Cout * 224, 0.0f);
+            for (int o = 0; o < Cout; o++)
+                for (int ci = 0; ci < 3; ci++)
+                    for (int ky = 0; ky < 7; ky++)
+                        for (int kx = 0; kx < 7; kx++)
+                            pr[(size_t)o * 224 + ky * 32 + kx * 4 + ci] = w->data[(((size_t)o * 3 + ci) * 7 + ky) * 7 + kx];
+            Conv& r = m->stem_rows;
+            r.Cin = 32; r.Cout = Cout; r.KH = 7; r.KW = 1; r.stride = 2; r.pad = 0; r.Kpad = 224; r.k_order = 1;
+            RC(m->upload_w3(&r.w3, pr, Cout, 224));
+            RC(m->upload_w(&r.w, pr));
+            r.scale = m->stem.scale; r.bias = m->stem.bias;
+        }
         m->stem_fused = m->stem_w148 != nullptr && getenv("ODAM_STEM_FUSED") != nullptr && atoi(getenv("ODAM_STEM_FUSED")) != 0;
     }
     for (int l = 0; l < 4; l++) {
@@ -438,7 +483,7 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
     // workspace (bytes = elements * es)
     const size_t B = c.max_batch, es = m->es;
     const size_t big = B * m->H2 * m->W2 * 256 * es;
-    RC(m->dev_alloc(&m->x4, B * c.img_h * c.img_w * (m->dt ? 8 : 4) * es));
+    RC(m->dev_alloc(&m->x4, B * (c.img_h + 6) * (c.img_w + 8) * (m->dt ? 8 : 4) * es));     // room for the framed fp32 image
     RC(m->dev_alloc(&m->stem_out, B * m->H1 * m->W1 * 64 * es));
     RC(m->dev_alloc(&m->bufA, big)); RC(m->dev_alloc(&m->bufB, big)); RC(m->dev_alloc(&m->dsb, big));
     RC(m->dev_alloc(&m->t1, big / 2)); RC(m->dev_alloc(&m->t2, big / 2));
@@ -478,8 +523,20 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
     if (m->stem_fused) {   // conv1 + bn1 + relu + maxpool in one kernel, straight from the NCHW image
         RC(odam_dk::launch_stem_pool(img, m->stem_w148, m->stem.scale, m->stem.bias, m->bufA, B, c.img_h, c.img_w, dt, st));
     } else {
-        RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, dt, st));
-        RC(conv_t(m, m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, st));
+        // fp32, split contraction mode, enough rows to fill the device: conv1 on the ring kernel.  With Cin = 4 the 7x7
+        // filter cannot use its gather (a k-tile must sit inside one tap), but seven consecutive NHWC4 pixels ARE 28
+        // contiguous floats: over an image framed with zeros (3 rows above / below, 3 + 5 columns) conv1 is a 7x1
+        // convolution with "Cin" = 32 floats per row, pixel stride lda = 4, no padding, K = 224 instead of 147 + pad --
+        // a third of the products are zeros, on a path that is 2-3x faster than the 128x64 tiles of the fp32 instruction.
+        static const bool rows_ok = !(getenv("ODAM_STEM_ROWS") != nullptr && atoi(getenv("ODAM_STEM_ROWS")) == 0);
+        const long Mst = (long)B * m->H1 * m->W1;
+        if (!dt && rows_ok && m->stem_rows.w3 && odam_cg::f32_mode() == 2 && Mst >= 192L * 256) {
+            RC(odam_dk::launch_nchw_to_nhwc4_framed(img, (float*)m->x4, B, c.img_h, c.img_w, st));
+            RC(stem_rows_t(m, B, st));
+        } else {
+            RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, dt, st));
+            RC(conv_t(m, m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, st));
+        }
         RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, dt, st));
     }
     char* cur = m->bufA;
