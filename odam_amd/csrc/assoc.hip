@@ -684,6 +684,12 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     }
     // ODAM_ASSOC_PERSIST=0: the matching GNN as one launch per layer op (the round-1 sequence; tests compare the two)
     m->persist = m->n_gnn <= PG_MAXL && !(getenv("ODAM_ASSOC_PERSIST") != nullptr && atoi(getenv("ODAM_ASSOC_PERSIST")) == 0);
+    {   // the persistent launch needs its 256 four-wave workgroups resident at once: eight per CU at most
+        int dev = 0, n_cu = 0;
+        ODAM_HIP(hipGetDevice(&dev));
+        ODAM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n_cu * 4 < PG_WG) m->persist = false;       // a small partition: keep at least half of every CU free for others
+    }
     m->use_graph = getenv("ODAM_ASSOC_GRAPH") != nullptr && atoi(getenv("ODAM_ASSOC_GRAPH")) != 0;   // measured: no gain (the sequence is bound by ~65 dependent kernels of ~10 us on the device, not by host launches)
     m->host.clear();
     m->finalized = true;
