@@ -50,16 +50,16 @@ def test_persistent_matching_kernel_vs_launch_sequence(golden, monkeypatch):
     z = golden("assoc.npz")
     sd = weights.make_associator_state_dict(2, 8, seed=0)
     cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
-    one = associator.Associator(cfg, max_tracks=96, device=DEV)
+    one = associator.Associator(cfg, max_tracks=320, device=DEV)
     one.load_state_dict(sd)
     monkeypatch.setenv("ODAM_ASSOC_PERSIST", "0")
-    many = associator.Associator(cfg, max_tracks=96, device=DEV)
+    many = associator.Associator(cfg, max_tracks=320, device=DEV)
     many.load_state_dict(sd)
     many._handle()                                     # the switch is read when the handle is finalised
     monkeypatch.delenv("ODAM_ASSOC_PERSIST")
     g = torch.Generator().manual_seed(5)
     base_t = torch.from_numpy(z["c0_tracks"]); base_d = torch.from_numpy(z["c0_det"])
-    for T, n in ((1, 1), (3, 30), (17, 9), (40, 21), (70, 30), (96, 5)):
+    for T, n in ((1, 1), (3, 30), (17, 9), (40, 21), (70, 30), (96, 5), (300, 30), (129, 17)):    # > 64 tracks: several key chunks
         tr = base_t[torch.randint(0, base_t.shape[0], (T,), generator=g)].clone()
         tr[:, 1:] += 0.05 * torch.randn(tr[:, 1:].shape, generator=g) * (tr[:, 1:] != -1)
         de = base_d.clone()
