@@ -48,6 +48,17 @@ struct ConvGemmArgs {
     int k_order;         // 0: k = (tap, ci).  1: k = (ci / kt, tap, ci % kt) with kt = the k-tile (32 fp32 / 64 bf16),
                          //    Cin % kt == 0: the taps of one channel chunk are consecutive k-tiles, so a workgroup re-reads
                          //    its input window from L2 while it is still there (tap-major revisits it 8+ k-tiles later)
+    // Fused second layer (optional; conv_gemm_big_kernel with pre-split filters, Cout == 64 only): this layer's output
+    // tile -- after scale / bias / ReLU -- is not stored but multiplied on chip by a 1x1 layer with F_N = 256 outputs,
+    //   F_C[m, n] = act( (relu(C) F_W^T)[m, n] * F_scale[n] + F_bias[n] + F_res[m, n] ),
+    // i.e. a ResNet bottleneck's 3x3 + expand + residual in one launch (detr_model.hip, layer1).  F_Wt3 = the expand
+    // filters split by split3_filters(w, 256, 64, .); fp32 only; C is ignored.
+    const void* F_Wt3 = nullptr;
+    const float* F_scale = nullptr;
+    const float* F_bias = nullptr;
+    const float* F_res = nullptr;   // [M, F_ldc] or null
+    float* F_C = nullptr;           // [M, F_ldc]
+    int F_ldc = 0, F_relu = 0;
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
@@ -60,7 +71,9 @@ void set_big_mode(int mode);
 // 2 (default) = products on the bf16 matrix instruction through an exact three-way bf16 split of both operands (six
 // MFMAs per 16 k; fp32-class accuracy, different last bits).  Also read once from ODAM_CG_BIG_F32.
 void set_f32_mode(int mode);
-int f32_mode();    // the mode fp32 layers run in right now (0 when the ring kernel is switched off altogether)
+int f32_mode();
+// whether launch_conv_gemm would run `a` (with its F_* fields set) on the fused kernel right now
+bool fused_second_ok(const ConvGemmArgs& a);    // the mode fp32 layers run in right now (0 when the ring kernel is switched off altogether)
 
 // host: exact three-way bf16 split (truncation) of packed fp32 filters w[Cout][Kpad] (Kpad % 16 == 0) into the Wt3 layout
 void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out);

@@ -538,6 +538,144 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 // NTH = 512: one workgroup per CU (two waves per SIMD run the same tile in lock step).  NTH = 256 (BN <= 128): a four-wave
 // workgroup with the same 128x64 / 64x64 wave tile, TWO per CU with independent barriers -- one workgroup's k-tile boundary
 // (barrier, fragment latency, DMA issue) falls under the other's MFMAs.
+// ---- fused second layer of the 64-column ring kernel (ConvGemmArgs F_*) ---------------------------------------------------
+// After the K loop a wave holds 32 rows x 64 channels of this layer's output in two accumulators.  It applies scale / bias
+// / ReLU, turns the tile through a private 8 KB LDS slab (row-major, 16-byte chunk c of row r at c ^ (r & 15): conflict-
+// free for the accumulator-layout writes, the A-fragment reads and the row-major reads of the store path) into A fragments
+// -- 8 consecutive k per lane, split exactly into three bf16 operands as in the main loop -- and multiplies them by the
+// expand layer's pre-split filters, which the workgroup has meanwhile pulled into the dead ring by LDS-DMA (96 KB:
+// [k-step 4][plane 3][256 rows][32 bytes], the plane layout of the main loop).  192 matrix instructions per wave; the
+// 256 output channels leave in four groups of 64 through the same slab: scale, bias, residual, ReLU, 16-byte stores.
+// Why: a bottleneck's 3x3 is matrix-bound and its expand + residual HBM-bound; as two launches each leaves the other
+// resource idle (one workgroup per CU), fused the CUs run out of phase and the two overlap across the chip.
+__device__ __forceinline__ void cg_split8(const float4& c0, const float4& c1, uint4& hi, uint4& mid, uint4& lo) {
+    const float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    unsigned uh[8], um[8], ul[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        uh[e] = __builtin_bit_cast(unsigned, v[e]);
+        const float r1 = v[e] - __builtin_bit_cast(float, uh[e] & 0xffff0000u);
+        um[e] = __builtin_bit_cast(unsigned, r1);
+        ul[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, um[e] & 0xffff0000u));
+    }
+    auto pk = [](unsigned lo_, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo_, 0x07060302u); };
+    hi = uint4{pk(uh[0], uh[1]), pk(uh[2], uh[3]), pk(uh[4], uh[5]), pk(uh[6], uh[7])};
+    mid = uint4{pk(um[0], um[1]), pk(um[2], um[3]), pk(um[4], um[5]), pk(um[6], um[7])};
+    lo = uint4{pk(ul[0], ul[1]), pk(ul[2], ul[3]), pk(ul[4], ul[5]), pk(ul[6], ul[7])};
+}
+
+constexpr int FUSE_W3_BYTES = 4 * 3 * 256 * 32, FUSE_LDS_BYTES = FUSE_W3_BYTES + 8 * 32 * 64 * 4;    // 96 KB + 64 KB = all of it
+
+__device__ __forceinline__ void fused_second(const ConvGemmArgs& a, floatx16 (&acc)[1][2], float* smem, unsigned lds_base,
+                                             int m0, int wave, int lane) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // (1) expand filters -> LDS: piece q = wave + 8 j covers (k-step, plane) = q / 8, rows 32 (q % 8) .. + 31
+    {
+        const unsigned long long pf = (unsigned long long)a.F_Wt3;
+        const u32x4 rs = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+#pragma unroll
+        for (int j = 0; j < 12; j++) {
+            const int q = wave_u + 8 * j;
+            const int sp = q >> 3, rb = q & 7, s_ = sp / 3, pl = sp - 3 * s_;
+            const int row = rb * 32 + (lane >> 1);
+            const unsigned vo = (unsigned)(row * 384 + s_ * 96 + pl * 32 + (((lane & 1) ^ ((lane >> 4) & 1)) * 16));
+            lds_dma16(rs, lds_base + (unsigned)(q * 1024), vo, 0);
+        }
+    }
+    // the residual rows are requested two output groups ahead of their use (the first two now): their HBM latency runs
+    // under the filter fetch and the matrix instructions (requested right before use they cost four exposed round trips
+    // per tile; all four groups at once do not fit the registers)
+    const int c4 = lane & 15;                              // 16-byte chunk of a 64-channel group this lane stores
+    const int m_base = m0 + wave * 32;
+    float4 rv[2][8];
+    auto load_res = [&](int g) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int m = m_base + it * 4 + (lane >> 4);
+            rv[g & 1][it] = float4{0.f, 0.f, 0.f, 0.f};
+            if (a.F_res && m < a.M) rv[g & 1][it] = *reinterpret_cast<const float4*>(a.F_res + (size_t)m * a.F_ldc + g * 64 + c4 * 4);
+        }
+    };
+    load_res(0); load_res(1);
+    // (2) this layer's epilogue in registers, tile -> slab
+    float* slab = smem + FUSE_W3_BYTES / 4 + wave * (32 * 64);
+    auto slab_at = [](int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); };
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = j * 32 + l32;
+        const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = acc[0][j][r] * sc + bi;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, n)] = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // (3) A fragments: lane (row l32, half) takes k = 16 s + 8 half .. + 7
+    uint4 ah[4], am[4], al[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+        const float4 c0 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half)]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half + 4)]);
+        cg_split8(c0, c1, ah[s_], am[s_], al[s_]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // my pieces of the filters have landed
+    __syncthreads();                                       // ... and everybody's; also: all slabs have been read
+    // (4) four groups of 64 output channels
+    const char* w3 = reinterpret_cast<const char*>(smem);
+    const int b_off = l32 * 32 + ((half ^ ((l32 >> 3) & 1)) * 16);
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        floatx16 acc2[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[jb][r] = 0.0f;
+            const int nb = 2 * g + jb;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; s_++) {
+                const char* bp = w3 + (s_ * 3) * 8192 + nb * 1024 + b_off;
+                const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 8192),
+                            bl = *reinterpret_cast<const uint4*>(bp + 16384);
+#define ODAM_MM2(x, y) acc2[jb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc2[jb], 0, 0, 0)
+                ODAM_MM2(al[s_], bh); ODAM_MM2(am[s_], bm); ODAM_MM2(ah[s_], bl);
+                ODAM_MM2(am[s_], bh); ODAM_MM2(ah[s_], bm);
+                ODAM_MM2(ah[s_], bh);
+#undef ODAM_MM2
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int n = g * 64 + c4 * 4;
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
+        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m_base + row;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+            float4 o = {v.x * sc.x + bi.x + rv[g & 1][it].x, v.y * sc.y + bi.y + rv[g & 1][it].y, v.z * sc.z + bi.z + rv[g & 1][it].z,
+                        v.w * sc.w + bi.w + rv[g & 1][it].w};
+            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+            if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
+        }
+        if (g + 2 < 4) load_res(g + 2);
+    }
+}
+
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
@@ -548,8 +686,9 @@ constexpr int big_lds_bytes() {
     return ring > slab ? ring : slab;
 }
 
-template <int MODE, int BN, int NST, int NTH = 512>
+template <int MODE, int BN, int NST, int NTH = 512, bool FUSE = false>
 __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
+    static_assert(!FUSE || (MODE == 3 && BN == 64 && NTH == 512), "fused second layer: pre-split filters, 64-column tiles");
     constexpr bool BF16 = MODE == 0;
     // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
     // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
@@ -1135,6 +1274,10 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     }
 #endif
     __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
+    if constexpr (FUSE) {
+        fused_second(a, acc, smem, lds_base, m0, wave, lane);
+        return;
+    }
     static_assert(WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>(),
                   "ring and epilogue staging fit the dynamic LDS");
     epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
@@ -1149,6 +1292,17 @@ static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     const int tiles = ((a.M + 255) / 256) * ((a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, BN, NST, NTH>), dim3(tiles), dim3(NTH), bytes, stream, a);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+static int launch_big_fused(const ConvGemmArgs& a, hipStream_t stream) {
+    static const bool attr_ok = [] {
+        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
+    }();
+    if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
+    const int tiles = (a.M + 255) / 256;
+    hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, true>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -1221,6 +1375,15 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
     return 0;
 }
 
+// the fused kernel applies: fp32 split mode with pre-split filters on both layers, 64 -> 256 channels, a full device
+bool fused_second_ok(const ConvGemmArgs& a) {
+    static const bool on = !(getenv("ODAM_CG_FUSE") != nullptr && atoi(getenv("ODAM_CG_FUSE")) == 0);
+    if (!on || !g_big_mode || g_big_f32 != 2 || a.dtype != ODAM_CG_F32) return false;
+    if (!a.F_Wt3 || !a.F_C || !a.Wt3 || a.Cout != 64 || a.F_ldc != 256 || a.Kpad % 16 != 0) return false;
+    if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL) return false;
+    return big_eligible(a, 64);
+}
+
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const int epc = (a.dtype == ODAM_CG_BF16) ? 8 : 4;
     if (a.Kpad % (8 * epc) != 0 || a.Cin < epc || (a.Cin & (a.Cin - 1)) != 0 || a.KW > 7 || a.KH * a.KW > 64)
@@ -1228,6 +1391,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (a.k_order && (a.Cin % (8 * epc) != 0 || a.KH * a.KW > 32 || a.Kpad / (8 * epc) >= 2048))
         return odam_fail(1, "conv_gemm: k_order 1 needs Cin % k-tile == 0, at most 32 taps, fewer than 2048 k-tiles");
     if (a.M <= 0 || a.Cout <= 0) return 0;
+    if (a.F_Wt3) {
+        if (!fused_second_ok(a)) return odam_fail(1, "conv_gemm: fused second layer asked for where it does not apply (check fused_second_ok)");
+        return launch_big_fused(a, stream);
+    }
     if (g_big_mode) {
         const bool bf = a.dtype == ODAM_CG_BF16;
         const bool x3 = !bf && g_big_f32 == 2;

@@ -252,6 +252,38 @@ int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, cons
     m->ev_used += 2;
     return rc;
 }
+// A bottleneck's 3x3 (c2: 64 channels) and expand + residual + ReLU (c3: 256 channels) as ONE launch where the fused kernel
+// of conv_gemm.hip applies (layer1 in fp32 split mode); returns -1 where it does not, and the caller runs the two layers
+int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, int B, int H, int W, const void* res, void* y,
+                 hipStream_t st) {
+    if (m->dt || !c2.w3 || !c3.w3 || c3.KH != 1 || c3.stride != 1 || c3.Kpad != c2.Cout) return -1;
+    ConvGemmArgs a{};
+    a.dtype = 0; a.out_f32 = 0;
+    a.A = x; a.Wt = c2.w; a.Wt3 = c2.w3; a.scale = c2.scale; a.bias = c2.bias; a.res = nullptr; a.C = nullptr;
+    a.B = B; a.H = H; a.W = W; a.Cin = c2.Cin; a.log2Cin = ilog2(c2.Cin);
+    a.Ho = conv_out(H, c2.KH, c2.stride, c2.pad); a.Wo = conv_out(W, c2.KW, c2.stride, c2.pad);
+    a.Cout = c2.Cout; a.KH = c2.KH; a.KW = c2.KW; a.stride = c2.stride; a.pad = c2.pad; a.Kpad = c2.Kpad;
+    a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = c2.Cout; a.k_order = c2.k_order;
+    a.F_Wt3 = c3.w3; a.F_scale = c3.scale; a.F_bias = c3.bias; a.F_res = (const float*)res; a.F_C = (float*)y;
+    a.F_ldc = c3.Cout; a.F_relu = 1;
+    if (!odam_cg::fused_second_ok(a)) return -1;
+    if (!m->profile) return odam_cg::launch_conv_gemm(a, st);
+    if (m->ev_used + 2 > m->ev.size()) {
+        for (int k = 0; k < 2; k++) {
+            hipEvent_t e;
+            ODAM_HIP(hipEventCreate(&e));
+            m->ev.push_back(e);
+        }
+        m->ev_flops.resize(m->ev.size() / 2);
+    }
+    m->ev_flops[m->ev_used / 2] = 2.0 * a.M * ((double)c2.Cout * c2.KH * c2.KW * c2.Cin + (double)c3.Cout * c2.Cout);
+    ODAM_HIP(hipEventRecord(m->ev[m->ev_used], st));
+    int rc = odam_cg::launch_conv_gemm(a, st);
+    ODAM_HIP(hipEventRecord(m->ev[m->ev_used + 1], st));
+    m->ev_used += 2;
+    return rc;
+}
+
 // conv1 over the framed image (forward_impl): the arguments run_conv cannot derive -- output width from the true image,
 // pixel stride smaller than the row length
 int stem_rows_t(odam_detr* m, int B, hipStream_t st) {
@@ -547,13 +579,17 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
         const int s = m->block_stride[i];
         const int Ho = conv_out(H, 3, s, 1), Wo = conv_out(W, 3, s, 1);
         RC(conv_t(m, b.c1, cur, B, H, W, nullptr, true, m->t1, st));
-        RC(conv_t(m, b.c2, m->t1, B, H, W, nullptr, true, m->t2, st));
         const char* res = cur;
         if (b.has_ds) {
             RC(conv_t(m, b.ds, cur, B, H, W, nullptr, false, m->dsb, st));
             res = m->dsb;
         }
-        RC(conv_t(m, b.c3, m->t2, B, Ho, Wo, res, true, nxt, st));
+        const int frc = (s == 1) ? fused_c2c3_t(m, b.c2, b.c3, m->t1, B, H, W, res, nxt, st) : -1;
+        if (frc > 0) return frc;
+        if (frc < 0) {
+            RC(conv_t(m, b.c2, m->t1, B, H, W, nullptr, true, m->t2, st));
+            RC(conv_t(m, b.c3, m->t2, B, Ho, Wo, res, true, nxt, st));
+        }
         char* t = cur; cur = nxt; nxt = t;
         H = Ho; W = Wo;
     }
