@@ -59,6 +59,12 @@ struct ConvGemmArgs {
     const float* F_res = nullptr;   // [M, F_ldc] or null
     float* F_C = nullptr;           // [M, F_ldc]
     int F_ldc = 0, F_relu = 0;
+    // ... and a third: the NEXT bottleneck's 1x1 reduce (256 -> 64 channels, scale / bias / ReLU) applied to F_C's tile
+    // while it is on chip, G_C[m, 0..63]; G_Wt3 = split3_filters(w, 64, 256, .).  Optional; needs the F_* layer.
+    const void* G_Wt3 = nullptr;
+    const float* G_scale = nullptr;
+    const float* G_bias = nullptr;
+    float* G_C = nullptr;           // [M, 64]
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);

@@ -676,6 +676,172 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, floatx16 (&a
     }
 }
 
+// ---- the chain continued: expand (F_*) AND the next bottleneck's reduce (G_*) on the tile -------------------------------
+// Same data flow as fused_second, but the expand filters are streamed: output group g (64 of the 256 channels) needs only
+// rows 64 g .. 64 g + 63 of them (24 KB as three planes), and the next block's 256 -> 64 reduce needs only k = 64 g .. + 63
+// of ITS filters for that group (another 24 KB).  Both are double-buffered in LDS (2 x 2 x 24 KB) beside the eight 8 KB
+// slabs -- 160 KB exactly -- and fetched one group ahead by LDS-DMA.  After a group's residual / ReLU its 32 x 64 final
+// values go back into the slab, come out as A fragments and are multiplied into a 32 x 64 accumulator of the reduce;
+// after the fourth group that accumulator is the next block's 3x3 input tile.  Saves the launch that re-reads the
+// 256-channel tensor (the largest read of layer1).
+__device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&acc)[1][2], float* smem, unsigned lds_base,
+                                            int m0, int wave, int lane) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    constexpr int SLABS = 8 * 32 * 64 * 4, GB = 4 * 3 * 64 * 32;      // 64 KB of slabs; 24 KB per filter group
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned long long pf = (unsigned long long)a.F_Wt3, pg = (unsigned long long)a.G_Wt3;
+    const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    const u32x4 rsg = u32x4{(unsigned)pg, (unsigned)(pg >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    const int swz = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
+    // filters of output group g -> buffer g & 1: 24 + 24 pieces of 1 KB, piece q = wave + 8 j: (k-step, plane) = q / 2, rows 32 (q % 2) .. + 31
+    auto dma_group = [&](int g) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int q = wave_u + 8 * j;
+            const int sp = q >> 1, rb = q & 1, s_ = sp / 3, pl = sp - 3 * s_;
+            const int row = rb * 32 + (lane >> 1);
+            lds_dma16(rsf, lds_base + (unsigned)(SLABS + (g & 1) * GB + q * 1024),
+                      (unsigned)((64 * g + row) * 384 + s_ * 96 + pl * 32 + swz), 0);
+            lds_dma16(rsg, lds_base + (unsigned)(SLABS + 2 * GB + (g & 1) * GB + q * 1024),
+                      (unsigned)(row * (16 * 96) + (4 * g + s_) * 96 + pl * 32 + swz), 0);
+        }
+    };
+    const int c4 = lane & 15;
+    const int m_base = m0 + wave * 32;
+    float4 rv[8];              // residual rows of one output group, requested one group ahead
+    auto load_res = [&](int g) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int m = m_base + it * 4 + (lane >> 4);
+            rv[it] = float4{0.f, 0.f, 0.f, 0.f};
+            if (a.F_res && m < a.M) rv[it] = *reinterpret_cast<const float4*>(a.F_res + (size_t)m * a.F_ldc + g * 64 + c4 * 4);
+        }
+    };
+    load_res(0);
+    dma_group(0);
+    float* slab = smem + wave * (32 * 64);
+    auto slab_at = [](int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); };
+    auto frags = [&](uint4 (&xh)[4], uint4 (&xm)[4], uint4 (&xl)[4]) {     // the slab's 32 x 64 values as A operands
+#pragma unroll
+        for (int s_ = 0; s_ < 4; s_++) {
+            const float4 c0 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half)]);
+            const float4 c1 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half + 4)]);
+            cg_split8(c0, c1, xh[s_], xm[s_], xl[s_]);
+        }
+    };
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = j * 32 + l32;
+        const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = acc[0][j][r] * sc + bi;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, n)] = v;
+        }
+    }
+    wave_sync();
+    uint4 ah[4], am[4], al[4];
+    frags(ah, am, al);
+    floatx16 acc3[2];
+#pragma unroll
+    for (int jc = 0; jc < 2; jc++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc3[jc][r] = 0.0f;
+    const char* lds_c = reinterpret_cast<const char*>(smem);
+    const int b_off = l32 * 32 + ((half ^ ((l32 >> 3) & 1)) * 16);
+#define ODAM_MM2(accv, x, y) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of group g's filters have landed
+        __syncthreads();                                        // ... and everybody's; everybody is done with group g - 1's buffers
+        if (g + 1 < 4) dma_group(g + 1);
+        const char* wf = lds_c + SLABS + (g & 1) * GB;
+        const char* wg = lds_c + SLABS + 2 * GB + (g & 1) * GB;
+        floatx16 acc2[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[jb][r] = 0.0f;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; s_++) {
+                const char* bp = wf + (s_ * 3) * 2048 + jb * 1024 + b_off;
+                const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 2048),
+                            bl = *reinterpret_cast<const uint4*>(bp + 4096);
+                ODAM_MM2(acc2[jb], al[s_], bh); ODAM_MM2(acc2[jb], am[s_], bm); ODAM_MM2(acc2[jb], ah[s_], bl);
+                ODAM_MM2(acc2[jb], am[s_], bh); ODAM_MM2(acc2[jb], ah[s_], bm);
+                ODAM_MM2(acc2[jb], ah[s_], bh);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
+        wave_sync();
+        const int n = g * 64 + c4 * 4;
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
+        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m_base + row;
+            float4* sp_ = reinterpret_cast<float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+            const float4 v = *sp_;
+            float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
+                        v.w * sc.w + bi.w + rv[it].w};
+            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+            if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
+            *sp_ = o;                                           // the final values: this group's slice of the reduce's input
+        }
+        if (g + 1 < 4) load_res(g + 1);
+        wave_sync();
+        uint4 xh[4], xm[4], xl[4];
+        frags(xh, xm, xl);
+#pragma unroll
+        for (int jc = 0; jc < 2; jc++)
+#pragma unroll
+            for (int s_ = 0; s_ < 4; s_++) {
+                const char* bp = wg + (s_ * 3) * 2048 + jc * 1024 + b_off;
+                const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 2048),
+                            bl = *reinterpret_cast<const uint4*>(bp + 4096);
+                ODAM_MM2(acc3[jc], xl[s_], bh); ODAM_MM2(acc3[jc], xm[s_], bm); ODAM_MM2(acc3[jc], xh[s_], bl);
+                ODAM_MM2(acc3[jc], xm[s_], bh); ODAM_MM2(acc3[jc], xh[s_], bm);
+                ODAM_MM2(acc3[jc], xh[s_], bh);
+            }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef ODAM_MM2
+    // the reduce's own epilogue: scale / bias / ReLU, [32 rows][64 channels] out through the slab
+#pragma unroll
+    for (int jc = 0; jc < 2; jc++) {
+        const int n = jc * 32 + l32;
+        const float sc = a.G_scale ? a.G_scale[n] : 1.0f, bi = a.G_bias ? a.G_bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = acc3[jc][r] * sc + bi;
+            v = v > 0.f ? v : 0.f;
+            slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, n)] = v;
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int row = it * 4 + (lane >> 4);
+        const int m = m_base + row;
+        const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+        if (m < a.M) *reinterpret_cast<float4*>(a.G_C + (size_t)m * 64 + c4 * 4) = v;
+    }
+}
+
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
@@ -686,9 +852,9 @@ constexpr int big_lds_bytes() {
     return ring > slab ? ring : slab;
 }
 
-template <int MODE, int BN, int NST, int NTH = 512, bool FUSE = false>
+template <int MODE, int BN, int NST, int NTH = 512, int FUSE = 0>     // FUSE: 1 = second layer on the tile (F_*), 2 = and a third (G_*)
 __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
-    static_assert(!FUSE || (MODE == 3 && BN == 64 && NTH == 512), "fused second layer: pre-split filters, 64-column tiles");
+    static_assert(!FUSE || (MODE == 3 && BN == 64 && NTH == 512), "fused layers: pre-split filters, 64-column tiles");
     constexpr bool BF16 = MODE == 0;
     // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
     // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
@@ -1274,8 +1440,12 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     }
 #endif
     __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
-    if constexpr (FUSE) {
+    if constexpr (FUSE == 1) {
         fused_second(a, acc, smem, lds_base, m0, wave, lane);
+        return;
+    }
+    if constexpr (FUSE == 2) {
+        fused_chain(a, acc, smem, lds_base, m0, wave, lane);
         return;
     }
     static_assert(WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>(),
@@ -1298,11 +1468,13 @@ static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
 
 static int launch_big_fused(const ConvGemmArgs& a, hipStream_t stream) {
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, true>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
+        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     const int tiles = (a.M + 255) / 256;
-    hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, true>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    if (a.G_Wt3) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 2>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 1>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -1381,6 +1553,8 @@ bool fused_second_ok(const ConvGemmArgs& a) {
     if (!on || !g_big_mode || g_big_f32 != 2 || a.dtype != ODAM_CG_F32) return false;
     if (!a.F_Wt3 || !a.F_C || !a.Wt3 || a.Cout != 64 || a.F_ldc != 256 || a.Kpad % 16 != 0) return false;
     if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL) return false;
+    static const bool chain_on = !(getenv("ODAM_CG_FUSE") != nullptr && atoi(getenv("ODAM_CG_FUSE")) == 1);   // 1: second layer only
+    if (a.G_Wt3 && (!chain_on || !a.G_C)) return false;
     return big_eligible(a, 64);
 }
 

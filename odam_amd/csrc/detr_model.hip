@@ -254,8 +254,11 @@ int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, cons
 }
 // A bottleneck's 3x3 (c2: 64 channels) and expand + residual + ReLU (c3: 256 channels) as ONE launch where the fused kernel
 // of conv_gemm.hip applies (layer1 in fp32 split mode); returns -1 where it does not, and the caller runs the two layers
+// next_c1 (nullable) + t_next: also the following bottleneck's 1x1 reduce on the tile, its output (the next 3x3's input) to
+// t_next; *chained tells the caller whether that happened
 int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, int B, int H, int W, const void* res, void* y,
-                 hipStream_t st) {
+                 hipStream_t st, const Conv* next_c1 = nullptr, void* t_next = nullptr, bool* chained = nullptr) {
+    if (chained) *chained = false;
     if (m->dt || !c2.w3 || !c3.w3 || c3.KH != 1 || c3.stride != 1 || c3.Kpad != c2.Cout) return -1;
     ConvGemmArgs a{};
     a.dtype = 0; a.out_f32 = 0;
@@ -266,6 +269,17 @@ int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, in
     a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = c2.Cout; a.k_order = c2.k_order;
     a.F_Wt3 = c3.w3; a.F_scale = c3.scale; a.F_bias = c3.bias; a.F_res = (const float*)res; a.F_C = (float*)y;
     a.F_ldc = c3.Cout; a.F_relu = 1;
+    double flops3 = 0.0;
+    if (next_c1 && t_next && next_c1->w3 && next_c1->KH == 1 && next_c1->stride == 1 && next_c1->Cout == 64 &&
+        next_c1->Kpad == c3.Cout && c3.Cout == 256) {
+        a.G_Wt3 = next_c1->w3; a.G_scale = next_c1->scale; a.G_bias = next_c1->bias; a.G_C = (float*)t_next;
+        if (odam_cg::fused_second_ok(a)) {
+            if (chained) *chained = true;
+            flops3 = 2.0 * a.M * (double)next_c1->Cout * c3.Cout;
+        } else {
+            a.G_Wt3 = nullptr; a.G_scale = a.G_bias = nullptr; a.G_C = nullptr;
+        }
+    }
     if (!odam_cg::fused_second_ok(a)) return -1;
     if (!m->profile) return odam_cg::launch_conv_gemm(a, st);
     if (m->ev_used + 2 > m->ev.size()) {
@@ -276,7 +290,7 @@ int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, in
         }
         m->ev_flops.resize(m->ev.size() / 2);
     }
-    m->ev_flops[m->ev_used / 2] = 2.0 * a.M * ((double)c2.Cout * c2.KH * c2.KW * c2.Cin + (double)c3.Cout * c2.Cout);
+    m->ev_flops[m->ev_used / 2] = 2.0 * a.M * ((double)c2.Cout * c2.KH * c2.KW * c2.Cin + (double)c3.Cout * c2.Cout) + flops3;
     ODAM_HIP(hipEventRecord(m->ev[m->ev_used], st));
     int rc = odam_cg::launch_conv_gemm(a, st);
     ODAM_HIP(hipEventRecord(m->ev[m->ev_used + 1], st));
@@ -574,21 +588,32 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
     char* cur = m->bufA;
     char* nxt = m->bufB;
     int H = m->H2, W = m->W2;
+    char* tin = m->t1;          // where this block's 1x1 reduce output lives (the 3x3's input)
+    char* tout = m->t2;         // the other small buffer: the 3x3's output, or -- chained -- the NEXT block's reduce output
+    bool have_c1 = false;       // the previous block's launch already computed this block's reduce
     for (size_t i = 0; i < m->blocks.size(); i++) {
         const Bottleneck& b = m->blocks[i];
         const int s = m->block_stride[i];
         const int Ho = conv_out(H, 3, s, 1), Wo = conv_out(W, 3, s, 1);
-        RC(conv_t(m, b.c1, cur, B, H, W, nullptr, true, m->t1, st));
+        if (!have_c1) RC(conv_t(m, b.c1, cur, B, H, W, nullptr, true, tin, st));
+        have_c1 = false;
         const char* res = cur;
         if (b.has_ds) {
             RC(conv_t(m, b.ds, cur, B, H, W, nullptr, false, m->dsb, st));
             res = m->dsb;
         }
-        const int frc = (s == 1) ? fused_c2c3_t(m, b.c2, b.c3, m->t1, B, H, W, res, nxt, st) : -1;
+        // the next block's reduce rides along where that block keeps the resolution and the channel counts (layer1's 2nd, 3rd)
+        const Conv* next_c1 = (i + 1 < m->blocks.size() && m->block_stride[i + 1] == 1 && !m->blocks[i + 1].has_ds)
+                                  ? &m->blocks[i + 1].c1 : nullptr;
+        bool chained = false;
+        const int frc = (s == 1) ? fused_c2c3_t(m, b.c2, b.c3, tin, B, H, W, res, nxt, st, next_c1, tout, &chained) : -1;
         if (frc > 0) return frc;
         if (frc < 0) {
-            RC(conv_t(m, b.c2, m->t1, B, H, W, nullptr, true, m->t2, st));
-            RC(conv_t(m, b.c3, m->t2, B, Ho, Wo, res, true, nxt, st));
+            RC(conv_t(m, b.c2, tin, B, H, W, nullptr, true, tout, st));
+            RC(conv_t(m, b.c3, tout, B, Ho, Wo, res, true, nxt, st));
+        } else if (chained) {
+            char* t = tin; tin = tout; tout = t;      // the next block reads its 3x3 input from where this launch put it
+            have_c1 = true;
         }
         char* t = cur; cur = nxt; nxt = t;
         H = Ho; W = Wo;

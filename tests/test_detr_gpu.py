@@ -425,7 +425,7 @@ def test_bf16_r101_full_size_close_to_fp32_oracle():
 
 @pytest.mark.parametrize("env", [{"ODAM_CG_NO_UT": "1"}, {"ODAM_CG_VARIANT": "0"}, {"ODAM_CG_FORCE": "2"}, {"ODAM_CG_BIG": "2"},
                                  {"ODAM_CG_BIG": "0"}, {"ODAM_CG_BIG": "2", "ODAM_CG_BIG_F32": "1"},
-                                 {"ODAM_CG_BIG": "2", "ODAM_CG_BIG_F32": "2"}, {"ODAM_CG_BIG_F32": "0"}, {"ODAM_STEM_FUSED": "1"}, {"ODAM_ATT_X3": "0"}, {"ODAM_STEM_ROWS": "0", "ODAM_CG_FUSE": "0"}])
+                                 {"ODAM_CG_BIG": "2", "ODAM_CG_BIG_F32": "2"}, {"ODAM_CG_BIG_F32": "0"}, {"ODAM_STEM_FUSED": "1"}, {"ODAM_ATT_X3": "0", "ODAM_CG_FUSE": "1"}, {"ODAM_STEM_ROWS": "0", "ODAM_CG_FUSE": "0"}])
 def test_conv_gemm_alternative_paths(env):
     """the register-staged gather (what layers too large for 31-bit buffer offsets fall back to), the 4-wave tiles,
     the four-stage small-tile pipeline, and the bf16-native 256-row kernel forced onto / kept off every eligible shape:
@@ -444,7 +444,8 @@ def test_conv_gemm_alternative_paths(env):
         sel = "reference_golden or vs_oracle or mixed_size or bf16_forward"
     if "ODAM_STEM_ROWS" in env or "ODAM_CG_FUSE" in env:   # conv1 on the 128x64 tiles of the fp32 instruction at every size;
         sel = "reference_golden or vs_oracle"                #   layer1's 3x3 and expand as two launches
-    if "ODAM_ATT_X3" in env:          # fp32 attention on the fp32 matrix instruction instead of the split products
+    if "ODAM_ATT_X3" in env:          # fp32 attention on the fp32 matrix instruction instead of the split products;
+                                      #   layer1 with the expand fused into the 3x3 but not the next block's reduce
         sel = "attention_vs_torch or reference_golden or vs_oracle or mixed_size"
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", sel],
                        env={**os.environ, **env, "ODAM_NESTED": "1"}, capture_output=True, text=True, timeout=1500)
