@@ -842,6 +842,125 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&ac
     }
 }
 
+// ---- the same for 128 -> 512 channels (layer2's 3x3 + expand + residual; 128-column tiles: a wave owns 32 rows x 128) ----
+// The 3x3's tile goes through the 8 KB slab in two 64-channel halves (eight k-steps of A fragments stay in registers); the
+// expand filters of an output group are 48 KB as three planes, double-buffered beside the slabs (64 + 2 x 48 = 160 KB);
+// eight output groups of 64 channels.  No chained reduce here: its filter slices would need another 96 KB.
+__device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, floatx16 (&acc)[1][4], float* smem, unsigned lds_base,
+                                                int m0, int wave, int lane) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    constexpr int SLABS = 8 * 32 * 64 * 4, KS = 8, GB = KS * 3 * 64 * 32;      // 64 KB of slabs; 48 KB per filter group
+    static_assert(SLABS + 2 * GB == 160 * 1024, "slabs and two filter groups fill the LDS");
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned long long pf = (unsigned long long)a.F_Wt3;
+    const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    const int swz = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
+    const int NG = a.F_ldc >> 6;                            // output groups of 64 channels
+    auto dma_group = [&](int g) {                           // 48 pieces of 1 KB: piece q = wave + 8 j: (k-step, plane) = q / 2, rows 32 (q % 2) .. + 31
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int q = wave_u + 8 * j;
+            const int sp = q >> 1, rb = q & 1, s_ = sp / 3, pl = sp - 3 * s_;
+            const int row = rb * 32 + (lane >> 1);
+            lds_dma16(rsf, lds_base + (unsigned)(SLABS + (g & 1) * GB + q * 1024),
+                      (unsigned)((64 * g + row) * (KS * 96) + s_ * 96 + pl * 32 + swz), 0);
+        }
+    };
+    const int c4 = lane & 15;
+    const int m_base = m0 + wave * 32;
+    float4 rv[8];
+    auto load_res = [&](int g) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int m = m_base + it * 4 + (lane >> 4);
+            rv[it] = float4{0.f, 0.f, 0.f, 0.f};
+            if (a.F_res && m < a.M) rv[it] = *reinterpret_cast<const float4*>(a.F_res + (size_t)m * a.F_ldc + g * 64 + c4 * 4);
+        }
+    };
+    load_res(0);
+    dma_group(0);
+    float* slab = smem + wave * (32 * 64);
+    auto slab_at = [](int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); };
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    uint4 ah[KS], am[KS], al[KS];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {                        // channels 64 h2 .. + 63 of the 3x3's tile
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = h2 * 64 + j * 32 + l32;
+            const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = acc[0][2 * h2 + j][r] * sc + bi;
+                if (a.relu) v = v > 0.f ? v : 0.f;
+                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, j * 32 + l32)] = v;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int s_ = 0; s_ < 4; s_++) {
+            const float4 c0 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half)]);
+            const float4 c1 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half + 4)]);
+            cg_split8(c0, c1, ah[4 * h2 + s_], am[4 * h2 + s_], al[4 * h2 + s_]);
+        }
+        wave_sync();
+    }
+    const char* lds_c = reinterpret_cast<const char*>(smem);
+    const int b_off = l32 * 32 + ((half ^ ((l32 >> 3) & 1)) * 16);
+#define ODAM_MM2(accv, x, y) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
+#pragma unroll 1
+    for (int g = 0; g < NG; g++) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (g + 1 < NG) dma_group(g + 1);
+        const char* wf = lds_c + SLABS + (g & 1) * GB;
+        floatx16 acc2[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[jb][r] = 0.0f;
+#pragma unroll
+            for (int s_ = 0; s_ < KS; s_++) {
+                const char* bp = wf + (s_ * 3) * 2048 + jb * 1024 + b_off;
+                const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 2048),
+                            bl = *reinterpret_cast<const uint4*>(bp + 4096);
+                ODAM_MM2(acc2[jb], al[s_], bh); ODAM_MM2(acc2[jb], am[s_], bm); ODAM_MM2(acc2[jb], ah[s_], bl);
+                ODAM_MM2(acc2[jb], am[s_], bh); ODAM_MM2(acc2[jb], ah[s_], bm);
+                ODAM_MM2(acc2[jb], ah[s_], bh);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
+        wave_sync();
+        const int n = g * 64 + c4 * 4;
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
+        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m_base + row;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+            float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
+                        v.w * sc.w + bi.w + rv[it].w};
+            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+            if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
+        }
+        if (g + 1 < NG) load_res(g + 1);
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef ODAM_MM2
+}
+
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
@@ -854,7 +973,8 @@ constexpr int big_lds_bytes() {
 
 template <int MODE, int BN, int NST, int NTH = 512, int FUSE = 0>     // FUSE: 1 = second layer on the tile (F_*), 2 = and a third (G_*)
 __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
-    static_assert(!FUSE || (MODE == 3 && BN == 64 && NTH == 512), "fused layers: pre-split filters, 64-column tiles");
+    static_assert(!FUSE || (MODE == 3 && NTH == 512 && ((FUSE < 3 && BN == 64) || (FUSE == 3 && BN == 128))),
+                  "fused layers: pre-split filters; 64-column tiles (FUSE 1, 2) or 128-column tiles (FUSE 3)");
     constexpr bool BF16 = MODE == 0;
     // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
     // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
@@ -1448,6 +1568,10 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         fused_chain(a, acc, smem, lds_base, m0, wave, lane);
         return;
     }
+    if constexpr (FUSE == 3) {
+        fused_second128(a, acc, smem, lds_base, m0, wave, lane);
+        return;
+    }
     static_assert(WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>(),
                   "ring and epilogue staging fit the dynamic LDS");
     epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
@@ -1469,11 +1593,13 @@ static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
 static int launch_big_fused(const ConvGemmArgs& a, hipStream_t stream) {
     static const bool attr_ok = [] {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 128, 4, 512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     const int tiles = (a.M + 255) / 256;
-    if (a.G_Wt3) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 2>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    if (a.Cout == 128) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 128, 4, 512, 3>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    else if (a.G_Wt3) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 2>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     else hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 1>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
@@ -1551,11 +1677,13 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
 bool fused_second_ok(const ConvGemmArgs& a) {
     static const bool on = !(getenv("ODAM_CG_FUSE") != nullptr && atoi(getenv("ODAM_CG_FUSE")) == 0);
     if (!on || !g_big_mode || g_big_f32 != 2 || a.dtype != ODAM_CG_F32) return false;
-    if (!a.F_Wt3 || !a.F_C || !a.Wt3 || a.Cout != 64 || a.F_ldc != 256 || a.Kpad % 16 != 0) return false;
+    if (!a.F_Wt3 || !a.F_C || !a.Wt3 || a.Kpad % 16 != 0) return false;
+    const bool l1 = a.Cout == 64 && a.F_ldc == 256, l2 = a.Cout == 128 && a.F_ldc == 512 && !a.G_Wt3;     // the two shapes built
+    if (!l1 && !l2) return false;
     if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL) return false;
     static const bool chain_on = !(getenv("ODAM_CG_FUSE") != nullptr && atoi(getenv("ODAM_CG_FUSE")) == 1);   // 1: second layer only
     if (a.G_Wt3 && (!chain_on || !a.G_C)) return false;
-    return big_eligible(a, 64);
+    return big_eligible(a, a.Cout);
 }
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {

@@ -606,7 +606,7 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
         const Conv* next_c1 = (i + 1 < m->blocks.size() && m->block_stride[i + 1] == 1 && !m->blocks[i + 1].has_ds)
                                   ? &m->blocks[i + 1].c1 : nullptr;
         bool chained = false;
-        const int frc = (s == 1) ? fused_c2c3_t(m, b.c2, b.c3, tin, B, H, W, res, nxt, st, next_c1, tout, &chained) : -1;
+        const int frc = fused_c2c3_t(m, b.c2, b.c3, tin, B, H, W, res, nxt, st, next_c1, tout, &chained);
         if (frc > 0) return frc;
         if (frc < 0) {
             RC(conv_t(m, b.c2, tin, B, H, W, nullptr, true, tout, st));
