@@ -260,7 +260,8 @@ def main():
                               "traffic_bytes_per_frame": pmc.get("conv_gemm_fp32", {}).get("bytes_per_frame"),
                               "algorithmic_gflop_per_launch_avg": conv_flops / max(n_launch, 1) / 1e9,
                               "kernel": "conv_gemm (fp32 implicit-GEMM conv / linear: 256-row LDS-DMA ring kernel with the exact bf16 split "
-                                        "for layers that fill the device, 128x128 tiles on v_mfma_f32_32x32x2_f32 otherwise)"
+                                        "for layers that fill the device -- layer1 / layer2 bottlenecks as one launch each: 3x3 + expand + "
+                                        "residual, in layer1 also the next reduce --, 128x128 tiles on v_mfma_f32_32x32x2_f32 otherwise)"
                               if split_mode else "conv_gemm_kernel (fp32 implicit-GEMM conv / linear, v_mfma_f32_32x32x2_f32)",
                               "launches_per_forward": n_launch,
                               "algorithmic_gflop_per_frame": flops_per_frame / 1e9,
