@@ -59,12 +59,13 @@ struct ConvGemmArgs {
     const float* F_res = nullptr;   // [M, F_ldc] or null
     float* F_C = nullptr;           // [M, F_ldc]
     int F_ldc = 0, F_relu = 0;
-    // ... and a third: the NEXT bottleneck's 1x1 reduce (256 -> 64 channels, scale / bias / ReLU) applied to F_C's tile
-    // while it is on chip, G_C[m, 0..63]; G_Wt3 = split3_filters(w, 64, 256, .).  Optional; needs the F_* layer.
+    // ... and a third: the NEXT bottleneck's 1x1 reduce (256 -> G_N channels, scale / bias / ReLU) applied to F_C's tile
+    // while it is on chip, G_C[m, 0..G_N-1]; G_Wt3 = split3_filters(w, G_N, 256, .).  Optional; needs the F_* layer.
     const void* G_Wt3 = nullptr;
     const float* G_scale = nullptr;
     const float* G_bias = nullptr;
-    float* G_C = nullptr;           // [M, 64]
+    float* G_C = nullptr;           // [M, G_N]
+    int G_N = 64;                   // 64 (the next block of the same stage) or 128 (layer2's first reduce after layer1's last block)
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);

@@ -842,6 +842,190 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&ac
     }
 }
 
+// ---- the chain into the NEXT STAGE: layer1's last block + layer2's first reduce (256 -> 128 channels) ---------------------
+// As fused_chain with 128 reduce outputs: four 32x32 accumulators, the reduce's k-slice of a group is 48 KB and has ONE
+// buffer (slabs 64 + expand filters 2 x 24 + reduce slice 48 = 160 KB): it is fetched at the top of its own group and
+// awaited (with one more workgroup barrier) before the group's second half; its A fragments are split one k-step at a time
+// to stay inside 256 registers.
+__device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, floatx16 (&acc)[1][2], float* smem, unsigned lds_base,
+                                               int m0, int wave, int lane) {
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    constexpr int SLABS = 8 * 32 * 64 * 4, GB = 4 * 3 * 64 * 32, GB2 = 4 * 3 * 128 * 32;      // 64 KB; 24 KB; 48 KB
+    static_assert(SLABS + 2 * GB + GB2 == 160 * 1024, "slabs, two expand groups and one reduce slice fill the LDS");
+    int half = lane >> 5, l32 = lane & 31;      // laundered inside the group loop: the ~60 slab addresses derived from them are
+                                                // loop invariants the compiler would otherwise keep in registers (and spill others)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned long long pf = (unsigned long long)a.F_Wt3, pg = (unsigned long long)a.G_Wt3;
+    const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    const u32x4 rsg = u32x4{(unsigned)pg, (unsigned)(pg >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    const int swz = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
+    auto dma_expand = [&](int g) {      // 24 pieces: q = wave + 8 j: (k-step, plane) = q / 2, rows 32 (q % 2) .. + 31 of the group
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int q = wave_u + 8 * j;
+            const int sp = q >> 1, rb = q & 1, s_ = sp / 3, pl = sp - 3 * s_;
+            const int row = rb * 32 + (lane >> 1);
+            lds_dma16(rsf, lds_base + (unsigned)(SLABS + (g & 1) * GB + q * 1024),
+                      (unsigned)((64 * g + row) * 384 + s_ * 96 + pl * 32 + swz), 0);
+        }
+    };
+    auto dma_reduce = [&](int g) {      // 48 pieces: q = wave + 8 j: (k-step, plane) = q / 4, rows 32 (q % 4) .. + 31 of the 128 outputs
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const int q = wave_u + 8 * j;
+            const int sp = q >> 2, rb = q & 3, s_ = sp / 3, pl = sp - 3 * s_;
+            const int row = rb * 32 + (lane >> 1);
+            lds_dma16(rsg, lds_base + (unsigned)(SLABS + 2 * GB + q * 1024),
+                      (unsigned)(row * (16 * 96) + (4 * g + s_) * 96 + pl * 32 + swz), 0);
+        }
+    };
+    const int c4 = lane & 15;
+    const int m_base = m0 + wave * 32;
+    float4 rv[8];
+    auto load_res = [&](int g) {
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int m = m_base + it * 4 + (lane >> 4);
+            rv[it] = float4{0.f, 0.f, 0.f, 0.f};
+            if (a.F_res && m < a.M) rv[it] = *reinterpret_cast<const float4*>(a.F_res + (size_t)m * a.F_ldc + g * 64 + c4 * 4);
+        }
+    };
+    dma_expand(0);
+    float* slab = smem + wave * (32 * 64);
+    auto slab_at = [](int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); };
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int n = j * 32 + l32;
+        const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            float v = acc[0][j][r] * sc + bi;
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, n)] = v;
+        }
+    }
+    wave_sync();
+    uint4 ah[4], am[4], al[4];
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+        const float4 c0 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half)]);
+        const float4 c1 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half + 4)]);
+        cg_split8(c0, c1, ah[s_], am[s_], al[s_]);
+    }
+    floatx16 acc3[4];
+#pragma unroll
+    for (int jc = 0; jc < 4; jc++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc3[jc][r] = 0.0f;
+    const char* lds_c = reinterpret_cast<const char*>(smem);
+#define ODAM_MM2(accv, x, y) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
+#pragma unroll 1
+    for (int g = 0; g < 4; g++) {
+        asm volatile("" : "+v"(half), "+v"(l32));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                        // group g's expand filters are in; everybody is done with group g - 1
+        if (g + 1 < 4) dma_expand(g + 1);
+        dma_reduce(g);
+        load_res(g);                                            // this group's residual rows: under the expand's matrix instructions
+        const int b_off = l32 * 32 + ((half ^ ((l32 >> 3) & 1)) * 16);
+        const char* wf = lds_c + SLABS + (g & 1) * GB;
+        const char* wg = lds_c + SLABS + 2 * GB;
+        floatx16 acc2[2];
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc2[jb][r] = 0.0f;
+#pragma unroll
+            for (int s_ = 0; s_ < 4; s_++) {
+                const char* bp = wf + (s_ * 3) * 2048 + jb * 1024 + b_off;
+                const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 2048),
+                            bl = *reinterpret_cast<const uint4*>(bp + 4096);
+                ODAM_MM2(acc2[jb], al[s_], bh); ODAM_MM2(acc2[jb], am[s_], bm); ODAM_MM2(acc2[jb], ah[s_], bl);
+                ODAM_MM2(acc2[jb], am[s_], bh); ODAM_MM2(acc2[jb], ah[s_], bm);
+                ODAM_MM2(acc2[jb], ah[s_], bh);
+                __builtin_amdgcn_sched_barrier(0);              // keeps the filter fragments of later k-steps out of the registers
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" : "+v"(half), "+v"(l32));
+#pragma unroll
+        for (int jb = 0; jb < 2; jb++)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
+        wave_sync();
+        const int n = g * 64 + c4 * 4;
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
+        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m_base + row;
+            float4* sp_ = reinterpret_cast<float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+            const float4 v = *sp_;
+            float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
+                        v.w * sc.w + bi.w + rv[it].w};
+            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+            if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
+            *sp_ = o;
+        }
+        wave_sync();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the reduce slice of this group (requested at the top) is in
+        __syncthreads();
+        asm volatile("" : "+v"(half), "+v"(l32));
+#pragma unroll 1
+        for (int s_ = 0; s_ < 4; s_++) {                        // not unrolled: four k-steps of filter fragments at once spill
+            uint4 xh, xm, xl;
+            {
+                const float4 c0 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half)]);
+                const float4 c1 = *reinterpret_cast<const float4*>(&slab[slab_at(l32, 16 * s_ + 8 * half + 4)]);
+                cg_split8(c0, c1, xh, xm, xl);
+            }
+#pragma unroll
+            for (int jc = 0; jc < 4; jc++) {
+                const char* bp = wg + (s_ * 3) * 4096 + jc * 1024 + b_off;
+                const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 4096),
+                            bl = *reinterpret_cast<const uint4*>(bp + 8192);
+                ODAM_MM2(acc3[jc], xl, bh); ODAM_MM2(acc3[jc], xm, bm); ODAM_MM2(acc3[jc], xh, bl);
+                ODAM_MM2(acc3[jc], xm, bh); ODAM_MM2(acc3[jc], xh, bm);
+                ODAM_MM2(acc3[jc], xh, bh);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#undef ODAM_MM2
+    // the reduce's own epilogue, 128 channels in two passes of 64 through the slab
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int n = h2 * 64 + j * 32 + l32;
+            const float sc = a.G_scale ? a.G_scale[n] : 1.0f, bi = a.G_bias ? a.G_bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                float v = acc3[2 * h2 + j][r] * sc + bi;
+                v = v > 0.f ? v : 0.f;
+                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, j * 32 + l32)] = v;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+            const int row = it * 4 + (lane >> 4);
+            const int m = m_base + row;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
+            if (m < a.M) *reinterpret_cast<float4*>(a.G_C + (size_t)m * 128 + h2 * 64 + c4 * 4) = v;
+        }
+        wave_sync();
+    }
+}
+
 // ---- the same for 128 -> 512 channels (layer2's 3x3 + expand + residual; 128-column tiles: a wave owns 32 rows x 128) ----
 // The 3x3's tile goes through the 8 KB slab in two 64-channel halves (eight k-steps of A fragments stay in registers); the
 // expand filters of an output group are 48 KB as three planes, double-buffered beside the slabs (64 + 2 x 48 = 160 KB);
@@ -973,8 +1157,8 @@ constexpr int big_lds_bytes() {
 
 template <int MODE, int BN, int NST, int NTH = 512, int FUSE = 0>     // FUSE: 1 = second layer on the tile (F_*), 2 = and a third (G_*)
 __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
-    static_assert(!FUSE || (MODE == 3 && NTH == 512 && ((FUSE < 3 && BN == 64) || (FUSE == 3 && BN == 128))),
-                  "fused layers: pre-split filters; 64-column tiles (FUSE 1, 2) or 128-column tiles (FUSE 3)");
+    static_assert(!FUSE || (MODE == 3 && NTH == 512 && ((FUSE != 3 && BN == 64) || (FUSE == 3 && BN == 128))),
+                  "fused layers: pre-split filters; 64-column tiles (FUSE 1, 2, 4) or 128-column tiles (FUSE 3)");
     constexpr bool BF16 = MODE == 0;
     // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
     // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
@@ -1572,6 +1756,10 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         fused_second128(a, acc, smem, lds_base, m0, wave, lane);
         return;
     }
+    if constexpr (FUSE == 4) {
+        fused_chain128(a, acc, smem, lds_base, m0, wave, lane);
+        return;
+    }
     static_assert(WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>(),
                   "ring and epilogue staging fit the dynamic LDS");
     epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
@@ -1594,11 +1782,13 @@ static int launch_big_fused(const ConvGemmArgs& a, hipStream_t stream) {
     static const bool attr_ok = [] {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
                hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 128, 4, 512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 128, 4, 512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     const int tiles = (a.M + 255) / 256;
     if (a.Cout == 128) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 128, 4, 512, 3>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    else if (a.G_Wt3 && a.G_N == 128) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 4>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     else if (a.G_Wt3) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 2>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     else hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 1>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     ODAM_HIP(hipGetLastError());
@@ -1682,7 +1872,7 @@ bool fused_second_ok(const ConvGemmArgs& a) {
     if (!l1 && !l2) return false;
     if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL) return false;
     static const bool chain_on = !(getenv("ODAM_CG_FUSE") != nullptr && atoi(getenv("ODAM_CG_FUSE")) == 1);   // 1: second layer only
-    if (a.G_Wt3 && (!chain_on || !a.G_C)) return false;
+    if (a.G_Wt3 && (!chain_on || !a.G_C || (a.G_N != 64 && a.G_N != 128))) return false;
     return big_eligible(a, a.Cout);
 }
 

@@ -270,14 +270,14 @@ int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, in
     a.F_Wt3 = c3.w3; a.F_scale = c3.scale; a.F_bias = c3.bias; a.F_res = (const float*)res; a.F_C = (float*)y;
     a.F_ldc = c3.Cout; a.F_relu = 1;
     double flops3 = 0.0;
-    if (next_c1 && t_next && next_c1->w3 && next_c1->KH == 1 && next_c1->stride == 1 && next_c1->Cout == 64 &&
+    if (next_c1 && t_next && next_c1->w3 && next_c1->KH == 1 && next_c1->stride == 1 && (next_c1->Cout == 64 || next_c1->Cout == 128) &&
         next_c1->Kpad == c3.Cout && c3.Cout == 256) {
-        a.G_Wt3 = next_c1->w3; a.G_scale = next_c1->scale; a.G_bias = next_c1->bias; a.G_C = (float*)t_next;
+        a.G_Wt3 = next_c1->w3; a.G_scale = next_c1->scale; a.G_bias = next_c1->bias; a.G_C = (float*)t_next; a.G_N = next_c1->Cout;
         if (odam_cg::fused_second_ok(a)) {
             if (chained) *chained = true;
             flops3 = 2.0 * a.M * (double)next_c1->Cout * c3.Cout;
         } else {
-            a.G_Wt3 = nullptr; a.G_scale = a.G_bias = nullptr; a.G_C = nullptr;
+            a.G_Wt3 = nullptr; a.G_scale = a.G_bias = nullptr; a.G_C = nullptr; a.G_N = 64;
         }
     }
     if (!odam_cg::fused_second_ok(a)) return -1;
@@ -603,8 +603,8 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
             res = m->dsb;
         }
         // the next block's reduce rides along where that block keeps the resolution and the channel counts (layer1's 2nd, 3rd)
-        const Conv* next_c1 = (i + 1 < m->blocks.size() && m->block_stride[i + 1] == 1 && !m->blocks[i + 1].has_ds)
-                                  ? &m->blocks[i + 1].c1 : nullptr;
+        // (layer2's first reduce after layer1's last block included: a bottleneck's stride sits on its 3x3)
+        const Conv* next_c1 = (i + 1 < m->blocks.size()) ? &m->blocks[i + 1].c1 : nullptr;
         bool chained = false;
         const int frc = fused_c2c3_t(m, b.c2, b.c3, tin, B, H, W, res, nxt, st, next_c1, tout, &chained);
         if (frc > 0) return frc;
