@@ -10,7 +10,7 @@ convs = rows[(nrep - 1) * n:]
 def co(n, k, s, p): return (n + 2 * p - k) // s + 1
 H, W = 800, 1066
 import re
-def fuse_kind(row):          # 5th template argument of the ring kernel: 1 / 3 = 3x3 + expand fused, 2 = ... + the next block's reduce
+def fuse_kind(row):          # 5th template argument of the ring kernel: 1 / 3 = 3x3 + expand fused, 2 / 4 = ... + the next block's reduce
     m_ = re.search(r"conv_gemm_big_kernel<\d+, \d+, \d+, \d+, (\d+)>", row["Kernel_Name"])
     return int(m_.group(1)) if m_ else 0
 seq = []                    # (name, flops) in launch order; built while walking the trace: fused launches cover several layers
@@ -31,8 +31,8 @@ for l, nb in enumerate(BLOCKS):
         have_c1 = False
         if i == 0: take(f"l{l+1}.{i}.ds", 2.0 * B * ho * wo * pl * 4 * inpl)
         fk = fuse_kind(convs[pos]) if pos < len(convs) else 0
-        if fk == 2:
-            take(f"l{l+1}.{i}.c2+c3+c1'", f_c2 + f_c3 + 2.0 * B * ho * wo * pl * pl * 4); have_c1 = True
+        if fk in (2, 4):      # 4: the chained reduce is the next STAGE's (twice the planes)
+            take(f"l{l+1}.{i}.c2+c3+c1'", f_c2 + f_c3 + 2.0 * B * ho * wo * (pl if fk == 2 else 2 * pl) * pl * 4); have_c1 = True
         elif fk:
             take(f"l{l+1}.{i}.c2+c3", f_c2 + f_c3)
         else:
