@@ -233,6 +233,26 @@ def test_resnet101_configuration_vs_oracle():
     det.close()
 
 
+@pytest.mark.parametrize("B,H,W,bb", [(3, 601, 795, "resnet50"), (2, 487, 1013, "resnet101")])
+def test_large_odd_sizes_vs_oracle(B, H, W, bb):
+    """Odd extents at sizes where the ring kernel, conv1-as-rows, the split attention and the fused layer1 / layer2
+    bottlenecks (incl. the chain into the next reduce) all apply: ragged last tiles in every one of them."""
+    import detr_oracle as O
+    from odam_amd import detector, weights
+    sd = weights.make_state_dict(backbone=bb, seed=0, scene=True)
+    det = detector.Detector(backbone=bb, max_batch=B, device=DEV, n_streams=1)
+    det.load_state_dict(sd)
+    torch.manual_seed(H + W)
+    img = torch.randn(B, 3, H, W)
+    torch.set_num_threads(8)
+    ref = O.detr_forward(sd, img, blocks=(3, 4, 23, 3) if bb == "resnet101" else (3, 4, 6, 3))
+    got = det(img.to(DEV))
+    for k in KEYS:
+        assert (got[k].cpu() - ref[k]).abs().max().item() <= 2e-4 * max(1.0, ref[k].abs().max().item()), k
+    assert torch.equal(got["pred_logits"].cpu().argmax(-1), ref["pred_logits"].argmax(-1))
+    det.close()
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 65, 97), (3, 32, 33), (1, 131, 77)])
 def test_odd_input_sizes_vs_oracle(B, H, W):
     """sizes that leave ragged tiles everywhere (odd extents through every stride-2 stage, the 32-pixel minimum)"""
