@@ -30,11 +30,31 @@ int odam_assoc_finalize(odam_assoc* m);
  * Stream-ordered, no host synchronisation.  The encoder and the per-track fuser layers are launches on 100 T rows; the
  * matching GNN layers and the final projection run as ONE persistent launch (256 workgroups, device-wide barriers between
  * the stages, exchanged buffers coherent through sc1 accesses), then the score matrix and the Sinkhorn kernel.
- * ODAM_ASSOC_PERSIST=0 issues the matching layers as separate launches instead (and ODAM_ASSOC_GRAPH=1 replays that
- * sequence from a hipGraph per track count).  One handle serves one stream at a time; the persistent launch assumes its
- * 256 small workgroups become co-resident, i.e. that no other kernel holds every CU indefinitely. */
+ * The persistent launch is used only when the runtime says all its workgroups can be resident at once on this device
+ * (odam_assoc_info; never under a CU mask); ODAM_ASSOC_PERSIST=0 / odam_assoc_set_persistent(m, 0) issue the matching
+ * layers as separate launches instead (and ODAM_ASSOC_GRAPH=1 replays that sequence from a hipGraph per track count).
+ * One handle serves one stream at a time.
+ * Residency can still be lost to a foreign kernel that holds CUs: every barrier wait is bounded (20 ms by default); a launch
+ * that hits the bound is abandoned, Z_out is filled with NaN and the handle's lost-launch counter moves.  The caller checks
+ * odam_assoc_lost_launches after synchronising the stream and re-runs that frame with odam_assoc_forward_sequence (same
+ * arguments, no residency assumption) -- odam_amd/associator.py does. */
 int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, float* Z_out,
                        void* stream);
+
+int odam_assoc_forward_sequence(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, float* Z_out,
+                                void* stream);
+/* count [host] = persistent launches abandoned at a barrier since odam_assoc_finalize (a pinned host word the device bumps:
+ * meaningful after the stream of the forward in question has been synchronised; no device call is made) */
+int odam_assoc_lost_launches(odam_assoc* m, unsigned* count);
+/* on != 0: use the persistent launch where the residency gate allows it; 0: the launch sequence */
+int odam_assoc_set_persistent(odam_assoc* m, int on);
+/* persistent: the path the next forward takes; resident_capacity: workgroups of the persistent kernel this device holds at
+ * once (occupancy query for the compiled kernel, less one per CU of margin, times the CUs; 0 under a CU mask);
+ * workgroups: what the launch needs.  Any pointer may be null. */
+int odam_assoc_info(odam_assoc* m, int* persistent, int* resident_capacity, int* workgroups);
+/* bound of one barrier wait in microseconds (default 20000); 0 abandons every persistent launch at its first barrier
+ * (tests of the fallback path) */
+int odam_assoc_set_barrier_timeout_us(odam_assoc* m, long long us);
 
 /* diagnostics of the persistent matching kernel: enable != 0 makes the following forwards record a 100 MHz timestamp of
  * workgroup 0 at kernel start and after every stage (5 per GNN layer, final projection, score matrix, Sinkhorn loop);

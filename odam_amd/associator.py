@@ -35,6 +35,8 @@ class Associator:
         self.device = torch.device(device)
         self._h = None
         self._sd = None
+        self.lost_launches = 0      # frames whose persistent matching launch was abandoned and re-run (see assignment_checked)
+        self._lost_seen = 0
 
     def to(self, device):
         self.device = torch.device("cuda:0" if str(device) == "cuda" else device)
@@ -55,6 +57,7 @@ class Associator:
         if self._h:
             _lib.lib().odam_assoc_destroy(self._h)
             self._h = None
+            self._lost_seen = 0
 
     def __del__(self):
         try:
@@ -90,24 +93,55 @@ class Associator:
         self._h = h
         return h
 
-    def assignment(self, tracks, detections, n_tracks, n_det):
-        """tracks [T,79,100], detections [1,79,30] or [79,30] (any device) -> Z [(T+1),(n_det+1)] device tensor"""
+    MAX_TRACKS = 1024      # odam_assoc_create's limit (the Sinkhorn kernel keeps the whole matrix in LDS)
+
+    def _grow(self, n_tracks):
+        """the reference has no track limit (associator.py:202-268): the native workspace is sized per handle, so a scene
+        with more live tracks gets a new handle with at least twice the room (weights are kept in self._sd)"""
+        if n_tracks > self.MAX_TRACKS:
+            raise _lib.OdamError(f"Associator: {n_tracks} live tracks exceed the native limit of {self.MAX_TRACKS}")
+        old, old_h = self.max_tracks, self._h
+        self.max_tracks = min(self.MAX_TRACKS, max(n_tracks, 2 * self.max_tracks))
+        torch.cuda.synchronize(self.device)
+        self._h = None
+        try:
+            self._handle()
+        except Exception:
+            self.max_tracks, self._h = old, old_h      # the old handle stays usable for smaller frames
+            raise
+        if old_h:
+            _lib.lib().odam_assoc_destroy(old_h)
+        self._lost_seen = 0
+
+    def assignment(self, tracks, detections, n_tracks, n_det, sequence=False):
+        """tracks [T,79,100], detections [1,79,30] or [79,30] (any device) -> Z [(T+1),(n_det+1)] device tensor.
+        Stream-ordered; sequence=True takes the launch-sequence path (no device-wide barrier)."""
         dev = self.device
         if n_tracks > self.max_tracks:
-            # the reference has no track limit (associator.py:202-268): the native workspace is sized per handle, so a
-            # scene with more live tracks gets a new handle with twice the room (weights are kept in self._sd)
-            while self.max_tracks < n_tracks:
-                self.max_tracks *= 2
-            torch.cuda.synchronize(dev)
-            self.close()
+            self._grow(n_tracks)
         tr = tracks.to(dev, torch.float32).contiguous()
         de = detections.to(dev, torch.float32).reshape(79, 30).contiguous()
         Z = torch.empty(n_tracks + 1, n_det + 1, device=dev, dtype=torch.float32)
+        L = _lib.lib()
+        fn, what = (L.odam_assoc_forward_sequence, "odam_assoc_forward_sequence") if sequence else (L.odam_assoc_forward, "odam_assoc_forward")
         with torch.cuda.device(dev):
-            _lib.check(_lib.lib().odam_assoc_forward(self._handle(), _lib.ptr(tr), ctypes.c_int(n_tracks), _lib.ptr(de),
-                                                     ctypes.c_int(n_det), _lib.ptr(Z),
-                                                     ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
-                       "odam_assoc_forward")
+            _lib.check(fn(self._handle(), _lib.ptr(tr), ctypes.c_int(n_tracks), _lib.ptr(de), ctypes.c_int(n_det), _lib.ptr(Z),
+                          ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), what)
+        return Z
+
+    def assignment_checked(self, tracks, detections, n_tracks, n_det):
+        """assignment() + synchronisation + the lost-launch check: if the persistent matching kernel could not get all its
+        workgroups resident within the barrier bound (a foreign kernel held the CUs), this frame is run again through the
+        launch sequence in the same process and counted in self.lost_launches.  The reference cannot fail this way
+        (associator.py:202-268), so neither may the drop-in."""
+        Z = self.assignment(tracks, detections, n_tracks, n_det)
+        torch.cuda.current_stream(self.device).synchronize()
+        n = ctypes.c_uint(0)
+        _lib.check(_lib.lib().odam_assoc_lost_launches(self._handle(), ctypes.byref(n)), "odam_assoc_lost_launches")
+        if n.value != self._lost_seen:
+            self._lost_seen = n.value
+            self.lost_launches += 1
+            Z = self.assignment(tracks, detections, n_tracks, n_det, sequence=True)
         return Z
 
     def __call__(self, in_data, threshold, eval_only=False, device="cuda"):
@@ -116,7 +150,7 @@ class Associator:
         if len(valid) != 1:
             raise _lib.OdamError("batch size 1 only (what OdamProcess.process_frame passes)")
         n_tracks, n_det = valid[0]
-        Z = self.assignment(in_data["tracks"], in_data["detections"][0], n_tracks, n_det)
+        Z = self.assignment_checked(in_data["tracks"], in_data["detections"][0], n_tracks, n_det)
         pred = [Z[None]]
         match = [hungarian_matching(Z[:-1, :-1].exp(), threshold)]
         return {"pred": pred, "loss": 0, "matches": match}

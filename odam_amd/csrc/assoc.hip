@@ -85,7 +85,7 @@ __device__ __forceinline__ float group_sum(float v) {
 
 __global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict__ scores, int lds, int m, int n,
                                                          float alpha, int iters, float* __restrict__ out,
-                                                         const int* __restrict__ n_dev, const unsigned* __restrict__ err) {
+                                                         const int* __restrict__ n_dev, const unsigned* __restrict__ err, unsigned* lost_count) {
     extern __shared__ float sm[];
     if (n_dev) n = *n_dev;      // replayed from a captured graph: the number of detections of THIS frame lives in memory
     const int M1 = m + 1, N1 = n + 1;
@@ -130,8 +130,9 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict
     }
     for (int i = tid; i < M1 * N1; i += SK_NT) {
         const int r = i / N1, c = i - r * N1;
-        out[i] = (err && *err) ? NAN : Z[i] + u[r] + v[c] - norm;     // a barrier of the matching kernel timed out: fail loudly downstream
+        out[i] = (err && *err) ? NAN : Z[i] + u[r] + v[c] - norm;     // the matching kernel's launch was lost (grid_barrier): fail loudly downstream
     }
+    if (tid == 0 && err && *err && lost_count) __hip_atomic_fetch_add(lost_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- the matching GNN + final projection as ONE persistent launch ----------------------------------------
@@ -159,8 +160,8 @@ struct GnnArgs {
     const float *fin_w, *fin_b;
     float *X, *kv, *att, *h, *mT;     // [MX][512], [MX][768], [MX][256], [MX][512], [MX + 2][256]
     int T;
-    unsigned* bar;                    // [0] generation, [1] error flag (a barrier timed out), [32 (1 + g)] group counters
-    unsigned bar_base;
+    unsigned* bar;                    // [0] generation, [1] error flag (a barrier timed out), [32 (1 + g)] group counters; zeroed before every launch
+    unsigned long long timeout_ticks; // bound of one barrier wait in 100 MHz ticks (0: give up at the first barrier -- tests)
     unsigned long long* stamps;       // diagnostics (odam_assoc_stage_stamps): 100 MHz timer of workgroup 0 after every stage, or null
 };
 
@@ -178,7 +179,13 @@ __device__ __forceinline__ void coh_st(__amdgpu_buffer_rsrc_t r, int float_idx, 
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, float_idx * 4, 0, SC1);
 }
 
-__device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned& target) {
+// Returns false when the launch is lost: this workgroup waited longer than the bound (not every workgroup became resident:
+// a foreign kernel holds CUs, or the device is smaller than the host's gate assumed), or another one said so.  A lost launch
+// is abandoned at once -- every workgroup returns at its next barrier instead of spinning through the remaining stages --
+// and reported: the flag turns Z into NaN in the Sinkhorn kernel and bumps a host-visible counter, and the host re-runs the
+// frame through the launch sequence (odam_assoc_forward_sequence).  The counters are zeroed before every launch, so one
+// lost launch does not poison the next.
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned& target, unsigned long long timeout_ticks, int* lost) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's sc1 stores are at their coherence point
     __syncthreads();
     target += PG_GROUPS;
@@ -186,13 +193,21 @@ __device__ __forceinline__ void grid_barrier(unsigned* bar, unsigned& target) {
         unsigned* grp = bar + 32 * (1 + (blockIdx.x & (PG_GROUPS - 1)));
         const unsigned old = __hip_atomic_fetch_add(grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (((old + 1u) & (PG_WG / PG_GROUPS - 1)) == 0u) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0;
-        while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        unsigned long long* word = reinterpret_cast<unsigned long long*>(bar);      // generation | error flag << 32: one poll sees both
+        bool ok = timeout_ticks != 0;
+        const unsigned long long t0 = wall_clock64();
+        for (int spins = 0; ok; ++spins) {
+            const unsigned long long w = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 32)) { ok = false; break; }
+            if ((int)((unsigned)w - target) >= 0) break;
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 21)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            if ((spins & 63) == 63 && wall_clock64() - t0 > timeout_ticks) ok = false;
         }
+        if (!ok) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lost = ok ? 0 : 1;
     }
     __syncthreads();
+    return *lost == 0;
 }
 
 // Y[M, N] = act((X[M, K] W[N, K]^T) * scale + b (+ res)); one 16x16 output block per workgroup, wave w takes k in
@@ -312,27 +327,30 @@ __device__ void stage_attn(const float* kv, int T, int cross, float* att, float*
 __global__ __launch_bounds__(PG_NT) void gnn_persistent_kernel(GnnArgs a) {
     __shared__ float red[(PG_NW - 1) * 64 * 4];
     __shared__ float scs[PG_NW * 64];
+    __shared__ int lost;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wave_g = wave * PG_WG + blockIdx.x;          // consecutive attention items go to different workgroups
-    unsigned target = a.bar_base;
+    unsigned target = 0;
     const int T = a.T, MX = T + ND;
     int n_stamp = 0;
     auto stamp = [&] { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[n_stamp++] = wall_clock64(); };
+#define PG_BARRIER() do { if (!grid_barrier(a.bar, target, a.timeout_ticks, &lost)) return; stamp(); } while (0)
     stamp();
     float* sc = scs + wave * 64;
     for (int l = 0; l < a.n_layers; l++) {
         const GnnLayerW& P = a.L[l];
         stage_gemm<D, false>(a.X, 512, P.qkv_w, P.qkv_b, MX, 3 * D, nullptr, a.kv, 3 * D, red, wave, lane);
-        grid_barrier(a.bar, target); stamp();
+        PG_BARRIER();
         stage_attn(a.kv, T, P.cross, a.att, sc, wave_g, lane);
-        grid_barrier(a.bar, target); stamp();
+        PG_BARRIER();
         stage_gemm<D, false>(a.att, D, P.mg_w, P.mg_b, MX, D, nullptr, a.X + D, 512, red, wave, lane);
-        grid_barrier(a.bar, target); stamp();
+        PG_BARRIER();
         stage_gemm<2 * D, true>(a.X, 512, P.m0_w, P.m0_b, MX, 2 * D, nullptr, a.h, 2 * D, red, wave, lane);
-        grid_barrier(a.bar, target); stamp();
+        PG_BARRIER();
         stage_gemm<2 * D, false>(a.h, 2 * D, P.m2_w, P.m2_b, MX, D, a.X, a.X, 512, red, wave, lane);
-        grid_barrier(a.bar, target); stamp();
+        PG_BARRIER();
     }
+#undef PG_BARRIER
     stage_gemm<D, false>(a.X, 512, a.fin_w, a.fin_b, MX, D, nullptr, a.mT, D, red, wave, lane);
     stamp();
 }
@@ -370,7 +388,7 @@ __device__ __forceinline__ float sum16(float v) {
 #define SK_LOG(x) __logf(x)
 __global__ __launch_bounds__(SK_NT) void sinkhorn32_kernel(const float* __restrict__ scores, int lds, int m, int n,
                                                            float alpha, int iters, float* __restrict__ out,
-                                                           const int* __restrict__ n_dev, const unsigned* __restrict__ err) {
+                                                           const int* __restrict__ n_dev, const unsigned* __restrict__ err, unsigned* lost_count) {
     extern __shared__ float sm[];
     if (n_dev) n = *n_dev;
     const int M1 = m + 1, N1 = n + 1;       // N1 <= 32
@@ -449,17 +467,19 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn32_kernel(const float* __restri
         const int r = i / N1, c = i - r * N1;
         out[i] = (err && *err) ? NAN : Z[r * ZS + c] + u[r] + v[c] - norm;
     }
+    // ... and tell the host (pinned counter, read after the stream has been synchronised: odam_assoc_lost_launches)
+    if (tid == 0 && err && *err && lost_count) __hip_atomic_fetch_add(lost_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // log_optimal_transport on the device: the 31-column kernel where it applies, the general one otherwise
 static int launch_sinkhorn(const float* scores, int lds_, int m_, int n_, int n_cap, float alpha, int iters, float* Z_out,
-                           const int* n_dev, hipStream_t st, const unsigned* err = nullptr) {
+                           const int* n_dev, hipStream_t st, const unsigned* err = nullptr, unsigned* lost_count = nullptr) {
     if (n_cap + 1 <= 32 && m_ + 1 <= 1100) {        // 1100 rows of 33 floats + u + v fit the 150 KB of dynamic LDS
         const size_t lds = ((size_t)(m_ + 1) * 33 + (m_ + 1) + 32) * sizeof(float);
-        hipLaunchKernelGGL(sinkhorn32_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err);
+        hipLaunchKernelGGL(sinkhorn32_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err, lost_count);
     } else {
         const size_t lds = ((size_t)(m_ + 1) * (n_cap + 1) + (m_ + 1) + (n_cap + 1)) * sizeof(float);
-        hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err);
+        hipLaunchKernelGGL(sinkhorn_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err, lost_count);
     }
     ODAM_HIP(hipGetLastError());
     return 0;
@@ -503,10 +523,12 @@ struct odam_assoc {
     std::map<int, hipGraphExec_t> graphs;
     hipStream_t cap_stream = nullptr;
     bool use_graph = true;
-    // persistent matching kernel: barrier counter (+ error flag) and the count it has reached after the launches so far
+    // persistent matching kernel: barrier counters (+ error flag), zeroed on the stream before every launch
     unsigned* bar = nullptr;
-    unsigned bar_base = 0;
     bool persist = true;
+    int resident_capacity = 0;               // workgroups of the persistent kernel the device can hold at once (with the guide's margin)
+    unsigned long long timeout_ticks = 2000000ull;   // 20 ms per barrier wait (100 MHz ticks); a healthy wait is ~2 us, ~1 ms under a saturated device
+    unsigned* lost_count = nullptr;          // pinned host word: launches abandoned at a barrier so far (the Sinkhorn kernel bumps it)
     unsigned long long* stamps = nullptr;    // device, 128 entries; written only while want_stamps
     bool want_stamps = false;
 
@@ -613,6 +635,7 @@ extern "C" int odam_assoc_destroy(odam_assoc* m) {
     if (!m) return 0;
     for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
     if (m->h_ndet) (void)hipHostFree(m->h_ndet);
+    if (m->lost_count) (void)hipHostFree(m->lost_count);
     if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
@@ -682,13 +705,22 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
         RC(m->alloc(&b, 256));
         m->stamps = reinterpret_cast<unsigned long long*>(b);
     }
-    // ODAM_ASSOC_PERSIST=0: the matching GNN as one launch per layer op (the round-1 sequence; tests compare the two)
+    ODAM_HIP(hipHostMalloc((void**)&m->lost_count, 64, hipHostMallocDefault));
+    *m->lost_count = 0u;
+    // ODAM_ASSOC_PERSIST=0 / odam_assoc_set_persistent(m, 0): the matching GNN as one launch per layer op (the round-1
+    // sequence; tests compare the two)
     m->persist = m->n_gnn <= PG_MAXL && !(getenv("ODAM_ASSOC_PERSIST") != nullptr && atoi(getenv("ODAM_ASSOC_PERSIST")) == 0);
-    {   // the persistent launch needs its 256 four-wave workgroups resident at once: eight per CU at most
-        int dev = 0, n_cu = 0;
+    {   // The persistent launch is a plain launch whose PG_WG workgroups wait for each other: all of them must be resident at
+        // once.  How many fit is asked of the runtime for THIS kernel (246 VGPRs: two workgroups per CU), less one per CU
+        // where it says more than one (MI355X_MICROARCH.md: the API reads one high for some SGPR counts), times the CUs;
+        // a CU mask hides CUs from the launch without changing multiProcessorCount, so it turns the path off.
+        int dev = 0, n_cu = 0, per_cu = 0;
         ODAM_HIP(hipGetDevice(&dev));
         ODAM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu * 4 < PG_WG) m->persist = false;       // a small partition: keep at least half of every CU free for others
+        ODAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gnn_persistent_kernel, PG_NT, 0));
+        m->resident_capacity = (per_cu > 1 ? per_cu - 1 : per_cu) * n_cu;
+        if (getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr) m->resident_capacity = 0;
+        if (m->resident_capacity < PG_WG) m->persist = false;
     }
     m->use_graph = getenv("ODAM_ASSOC_GRAPH") != nullptr && atoi(getenv("ODAM_ASSOC_GRAPH")) != 0;   // measured: no gain (the sequence is bound by ~65 dependent kernels of ~10 us on the device, not by host launches)
     m->host.clear();
@@ -698,7 +730,7 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
 
 // the launch sequence of one forward: ~65 kernels, every one a memory round trip long at these sizes (<= 70 rows)
 static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det, const int* n_dev,
-                           float* Z_out, hipStream_t st) {
+                           float* Z_out, hipStream_t st, bool allow_persist = true) {
     const int N = T * NT;
     // encoder + frame-index encoding (associator.py:222-229)
     hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
@@ -720,7 +752,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
     // go through the same weights, so every projection / MLP runs once on the [T + 30] row block; only the attention
     // differs per side (self: own set, cross: the other set).  All deltas come from the layer's inputs: the query,
     // key and value projections are taken before the residual update of either set.
-    if (m->persist && !n_dev) {
+    if (m->persist && allow_persist && !n_dev) {
         GnnArgs g{};
         for (size_t i = 0; i < m->gnn.size(); i++) {
             const Prop& P = m->gnn[i];
@@ -730,9 +762,9 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         g.fin_w = m->final_proj.w; g.fin_b = m->final_proj.b;
         g.X = X; g.kv = m->kvX; g.att = m->attX; g.h = m->hX; g.mT = m->mT;
         g.T = T;
-        g.bar = m->bar; g.bar_base = m->bar_base;
+        g.bar = m->bar; g.timeout_ticks = m->timeout_ticks;
         g.stamps = m->want_stamps ? m->stamps : nullptr;
-        m->bar_base += (unsigned)PG_GROUPS * 5u * (unsigned)g.n_layers;
+        ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * 32 * (1 + PG_GROUPS), st));     // counters and the error flag start from zero every launch
         hipLaunchKernelGGL(gnn_persistent_kernel, dim3(PG_WG), dim3(PG_NT), 0, st, g);
         ODAM_HIP(hipGetLastError());
         // The score matrix keeps its own launch on the tiles of conv_gemm.hip: with saturated scores (the hand-built scene
@@ -742,7 +774,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         const float* mD = m->mT + (size_t)T * D;
         Lin sc; sc.w = const_cast<float*>(mD); sc.b = nullptr; sc.K = D; sc.N = ND;
         RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
-        return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, nullptr, st, m->bar + 1);
+        return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, nullptr, st, m->bar + 1, m->lost_count);
     }
     for (size_t i = 0; i < m->gnn.size(); i++) {
         const Prop& P = m->gnn[i];
@@ -801,6 +833,42 @@ extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, con
     }
     ODAM_HIP(hipGraphLaunch(it->second, st));
     ODAM_HIP(hipMemcpyAsync(Z_out, m->out_Z, sizeof(float) * (size_t)(T + 1) * (n_det + 1), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// The same forward with the matching layers as separate launches (no device-wide barrier, no residency assumption): what
+// the host re-runs a frame through when odam_assoc_lost_launches has moved.
+extern "C" int odam_assoc_forward_sequence(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det,
+                                           float* Z_out, void* stream) {
+    if (!m || !tracks || !detections || !Z_out) return odam_fail(1, "odam_assoc_forward_sequence: null pointer");
+    if (!m->finalized) return odam_fail(1, "odam_assoc_forward_sequence: call odam_assoc_finalize first");
+    if (T < 1 || T > m->max_tracks || n_det < 1 || n_det > ND) return odam_fail(3, "odam_assoc_forward_sequence: T / n_det out of range");
+    return enqueue_forward(m, tracks, T, detections, n_det, nullptr, Z_out, (hipStream_t)stream, false);
+}
+
+extern "C" int odam_assoc_lost_launches(odam_assoc* m, unsigned* count) {
+    if (!m || !m->finalized || !count) return odam_fail(1, "odam_assoc_lost_launches: bad argument");
+    *count = __atomic_load_n(m->lost_count, __ATOMIC_ACQUIRE);
+    return 0;
+}
+
+extern "C" int odam_assoc_set_persistent(odam_assoc* m, int on) {
+    if (!m || !m->finalized) return odam_fail(1, "odam_assoc_set_persistent: bad argument");
+    m->persist = on != 0 && m->n_gnn <= PG_MAXL && m->resident_capacity >= PG_WG;
+    return 0;
+}
+
+extern "C" int odam_assoc_info(odam_assoc* m, int* persistent, int* resident_capacity, int* workgroups) {
+    if (!m || !m->finalized) return odam_fail(1, "odam_assoc_info: bad argument");
+    if (persistent) *persistent = m->persist ? 1 : 0;
+    if (resident_capacity) *resident_capacity = m->resident_capacity;
+    if (workgroups) *workgroups = PG_WG;
+    return 0;
+}
+
+extern "C" int odam_assoc_set_barrier_timeout_us(odam_assoc* m, long long us) {
+    if (!m || us < 0) return odam_fail(1, "odam_assoc_set_barrier_timeout_us: bad argument");
+    m->timeout_ticks = (unsigned long long)us * 100ull;
     return 0;
 }
 

@@ -907,7 +907,12 @@ extern "C" void sample_on_batch(float* shapes, float* epsilons, float* etas, flo
             eta[i] = buf[lo < buffer_size ? lo : buffer_size - 1];
         }
         host_buffer(a[0], a[1], e[1], PI_F, -PI_F, buf.data(), buffer_size, work);
-        for (int i = 0; i < N; i++) omega[i] = buf[(int)(dis(gen) * (float)buffer_size)];   // sampling.cpp:210-212
+        for (int i = 0; i < N; i++) {                                                        // sampling.cpp:210-212
+            // libstdc++'s uniform_real_distribution<float> can return 1.0f: the reference then reads one element past its
+            // buffer.  Clamped here -- every draw below 1 indexes exactly as the reference does.
+            const int k = (int)(dis(gen) * (float)buffer_size);
+            omega[i] = buf[k < buffer_size ? k : buffer_size - 1];
+        }
     }
 }
 

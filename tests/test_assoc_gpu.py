@@ -77,6 +77,71 @@ def test_persistent_matching_kernel_vs_launch_sequence(golden, monkeypatch):
     one.close(); many.close()
 
 
+def test_lost_persistent_launch_is_rerun_and_not_sticky(golden):
+    """A persistent matching launch that cannot get through a device-wide barrier (forced: barrier bound 0) is abandoned,
+    reported through the handle's lost-launch counter with Z = NaN, and the Associator re-runs that frame through the launch
+    sequence in the same process; the next frame takes the persistent path again and works (the flag is per launch)."""
+    from odam_amd import _lib, associator, weights
+    z = golden("assoc.npz")
+    cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
+    a = associator.Associator(cfg, max_tracks=64, device=DEV)
+    a.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0))
+    L, h = _lib.lib(), a._handle()
+    on, cap, need = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _lib.check(L.odam_assoc_info(h, ctypes.byref(on), ctypes.byref(cap), ctypes.byref(need)), "info")
+    assert need.value == 256 and cap.value >= need.value and on.value == 1, (on.value, cap.value, need.value)   # a whole MI355X holds the grid
+    tr, de, Zr = z["c0_tracks"], z["c0_det"], z["c0_Z"]
+    T, n = Zr.shape[0] - 1, Zr.shape[1] - 1
+    data = {"tracks": torch.from_numpy(tr), "detections": torch.from_numpy(de), "valid_list": [(T, n)]}
+    good = a(data, 0.1, eval_only=True)
+    seq = a.assignment(torch.from_numpy(tr), torch.from_numpy(de), T, n, sequence=True).cpu().numpy()
+    assert a.lost_launches == 0
+    # the raw entry point: NaN out and the counter moves
+    _lib.check(L.odam_assoc_set_barrier_timeout_us(h, ctypes.c_longlong(0)), "timeout")
+    Zraw = a.assignment(torch.from_numpy(tr), torch.from_numpy(de), T, n).cpu().numpy()
+    cnt = ctypes.c_uint()
+    _lib.check(L.odam_assoc_lost_launches(h, ctypes.byref(cnt)), "lost")
+    assert np.isnan(Zraw).all() and cnt.value == 1
+    a._lost_seen = cnt.value
+    # the Associator call: re-run through the launch sequence, same matches, counted
+    out = a(data, 0.1, eval_only=True)
+    assert a.lost_launches == 1
+    assert np.array_equal(out["pred"][0][0].cpu().numpy(), seq)
+    assert np.array_equal(out["matches"][0], good["matches"][0])
+    # not sticky: with the normal bound the persistent path works again, bit for bit what it gave before
+    _lib.check(L.odam_assoc_set_barrier_timeout_us(h, ctypes.c_longlong(20000)), "timeout")
+    again = a(data, 0.1, eval_only=True)
+    assert a.lost_launches == 1
+    assert np.array_equal(again["pred"][0][0].cpu().numpy(), good["pred"][0][0].cpu().numpy())
+    # the switch of the handle: launch sequence on request
+    _lib.check(L.odam_assoc_set_persistent(h, 0), "set_persistent")
+    off = a(data, 0.1, eval_only=True)
+    assert np.array_equal(off["pred"][0][0].cpu().numpy(), seq)
+    a.close()
+
+
+def test_workspace_growth_respects_native_limit(golden):
+    """growth past max_tracks builds a larger handle (capped at the native 1024); more tracks than that is a clear error and
+    leaves the old handle usable"""
+    from odam_amd import _lib, associator, weights
+    z = golden("assoc.npz")
+    cfg = {"GNN_layers": ["self", "cross"], "self_GNN_layers": ["self"], "sinkhorn_iterations": 10}
+    a = associator.Associator(cfg, max_tracks=300, device=DEV)
+    a.load_state_dict(weights.make_associator_state_dict(1, 2, seed=0))
+    base_t = torch.from_numpy(z["c0_tracks"]); de = torch.from_numpy(z["c0_det"])
+    tr = base_t[torch.arange(601) % base_t.shape[0]].clone()
+    Z = a.assignment(tr, de, 601, 5)
+    assert a.max_tracks == 601 and np.isfinite(Z.cpu().numpy()).all()
+    tr2 = base_t[torch.arange(700) % base_t.shape[0]].clone()
+    a.assignment(tr2, de, 700, 5)
+    assert a.max_tracks == 1024
+    with pytest.raises(_lib.OdamError, match="native limit"):
+        a.assignment(tr2, de, 1025, 5)
+    assert a.max_tracks == 1024
+    assert np.isfinite(a.assignment(tr, de, 601, 5).cpu().numpy()).all()
+    a.close()
+
+
 def test_process_sequence_with_network(golden):
     """The whole per-frame loop (canned detections -> _prepare_tracks -> association network -> Hungarian ->
     track attachment) on the GPU against the reference's OdamProcess + reference Associator run on the CPU.
@@ -95,7 +160,7 @@ def test_process_sequence_with_network(golden):
     plain = net.assignment
     calls, same_decision, decisive = [], [], []
 
-    def forced(tracks, detections, n_tracks, n_det):
+    def forced(tracks, detections, n_tracks, n_det, **kw):
         i = len(calls)
         Zr = ref[f"Z{i}"]
         Z = plain(tracks, detections, n_tracks, n_det).cpu().numpy()
