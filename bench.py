@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="concurrent HIP streams; 0 = by shard size")
     ap.add_argument("--chunk", type=int, default=0, help="frames per device->host copy of detections; 0 = 4 batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (host-resident frames, shard of 8, with association)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] block (R101, bf16, 50 objects)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo + "
                     "--one-device let several ranks share one GPU for a functional check of the N > 1 path")
@@ -123,17 +124,20 @@ def main():
     scene = synth.make_scene(N, args.objects, seed=1, min_views=10, max_views=min(300, N))
     tracks = scene["tracks"]
     owners = [parallel.object_shard([len(t) for t in tracks], r, ws) for r in range(ws)]
-    mine = owners[rank]
+    mine_all = mine = owners[rank]
     frame_ids = scene["img_names"]
 
     det_ms = []
     last = {}
 
-    def step(profile=False):
+    def step(src=None, objs=None, gather=True):
+        """one pass of the hot path; src: this rank's frames (default: the resident shard), objs: the objects it fits"""
+        src = frames if src is None else src
+        mine = mine_all if objs is None else objs
         per_frame = []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for c0, rows16 in detector.detect_resident_chunks(frames, img_size, K, chunk=args.chunk):
+        for c0, rows16 in detector.detect_resident_chunks(src, img_size, K, chunk=args.chunk):
             for i in range(rows16.shape[0]):   # host: threshold + NMS + 79-column rows, overlapped with the GPU
                 sel = detector.select(rows16[i], 0.6, True, 30)
                 objs = {k: [v] for k, v in sel.items()}
@@ -141,9 +145,10 @@ def main():
         e1.record()          # after the last chunk's copy on the issuing stream: end of the detection phase
         det_ms.append((e0, e1))
         blk, cnt = parallel.pack_detections(per_frame)
-        blk, cnt = parallel.allgather_detections(blk, cnt, N, coll_dev, force=args.force_collectives)
+        if gather:
+            blk, cnt = parallel.allgather_detections(blk, cnt, N, coll_dev, force=args.force_collectives)
         n_det = int(cnt.sum())
-        last["blk"], last["cnt"] = blk, cnt
+        last["blk"], last["cnt"], last["per_frame"] = blk, cnt, per_frame
         fitted = None
         for _ in range(2):  # optim -> (merge) -> optim
             out = multi_view.optim_process([tracks[i] for i in mine], frame_ids, scene["T_wcs"], scene["P_cws"],
@@ -152,7 +157,7 @@ def main():
             local = np.concatenate([out["params"].reshape(len(mine), 9),
                                     np.asarray(out["bboxes_qc"], np.float32).reshape(len(mine), 24)], 1) \
                 if mine else np.zeros((0, 33), np.float32)
-            fitted = parallel.allgather_rows(local, len(tracks), owners, coll_dev, force=args.force_collectives)
+            fitted = parallel.allgather_rows(local, len(tracks), owners, coll_dev, force=args.force_collectives) if gather else local
         return n_det, fitted
 
     def sync():
@@ -190,6 +195,9 @@ def main():
         s0 = time.perf_counter(); step(); torch.cuda.synchronize()
         f32_instr = N / (time.perf_counter() - s0)
         _lib.check(_lib.lib().odam_op_conv_f32_mode(2), "odam_op_conv_f32_mode")
+    secondary = {}
+    if rank == 0 and ws == 1 and not args.no_secondary:
+        secondary = secondary_blocks(step, detector, args.chunk, frames, tracks, N, dump["per_frame"], scene, device, dt / args.steps)
     if args.dump and rank == 0:
         np.savez(args.dump, blk=dump["blk"], cnt=dump["cnt"], fitted=dump["fitted"])
     if ws > 1:
@@ -235,6 +243,7 @@ def main():
         "detections_per_frame": n_det / N,
         "detect_only_frames_per_s_per_gpu": (f1 - f0) / t_det,
     }
+    result.update(secondary)
     pmc = pmc_summary()
     if conv_ms > 0 and det_phase_ms > 0:
         # Batches run on several HIP streams at once, so a launch's own duration includes the kernels it shares
@@ -254,6 +263,8 @@ def main():
                               # profiles/pmc_summary.json (per frame; x batch / launches = per launch, like `achieved`)
                               "traffic": (pmc.get("conv_gemm_fp32", {}).get("bytes_per_frame") * args.batch / max(n_launch, 1))
                               if pmc.get("conv_gemm_fp32") else None,
+                              "traffic_source": "profiles/pmc_summary.json -- a rocprofv3 --pmc pass the builder ran with tests/native/run_pmc.sh, "
+                                                "NOT measured inside this run (counters cannot be read from within the process)",
                               "traffic_unit": "HBM-side bytes per launch, average over the %d launches of a forward of %d "
                                               "frames (PMC: 2 x FETCH_SIZE + WRITE_SIZE; %s)" % (
                                                   n_launch, args.batch, pmc.get("conv_gemm_fp32", {}).get("source", "no PMC summary")),
@@ -304,17 +315,19 @@ def main():
             sq_ms = rec["ev"][0].elapsed_time(rec["ev"][1])
             views = rec["views"]
             alg = sum(12000 + 80 * v + 40 for v in views) * 200.0   # streaming-formulation bytes per object-step
+            vu = pmc.get("sq_fit", {}).get("valu_util")
             result["sq_fit_kernel"] = {
-                "bound": "hbm", "achieved": alg / (sq_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-                "frac": alg / (sq_ms * 1e-3) / PEAK_HBM, "objects": len(views), "max_views": max(views),
-                "ms_per_launch": sq_ms, "us_per_adam_step": 1e3 * sq_ms / 200,
-                # the bound that applies: VALU / latency.  Busy fractions from the SQ PMC pass in pmc_summary.json
-                "valu_util": pmc.get("sq_fit", {}).get("valu_util"), "valu_source": pmc.get("sq_fit", {}).get("source"),
-                "hbm_traffic_bytes_per_launch": pmc.get("sq_fit", {}).get("bytes_per_launch"),
-                "measured": "streaming-formulation bytes (12000 + 80 F + 40 per object-step) x 200 steps / launch duration "
-                            "(HIP events); one workgroup per object keeps points, sampler state and gradients in LDS for "
-                            "all 200 steps, so HBM sees each view's 80 bytes through L2 only -- the kernel is bound by "
-                            "per-step latency (VALU + LDS + barriers), not by this figure (DESIGN.md section 4)"}
+                # the bound that applies: the kernel keeps everything in LDS for all 200 steps, so it is
+                # bound by per-step latency / vector issue, not by HBM.  frac = share of wave cycles issuing vector instructions
+                "bound": "valu/latency", "frac": vu, "unit": "share of SQ_WAVE_CYCLES issuing VALU",
+                "frac_from_profiles": pmc.get("sq_fit", {}).get("source"),
+                "objects": len(views), "max_views": max(views), "ms_per_launch": sq_ms, "us_per_adam_step": 1e3 * sq_ms / 200,
+                "hbm_secondary": {"achieved": alg / (sq_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+                                  "frac": alg / (sq_ms * 1e-3) / PEAK_HBM,
+                                  "traffic_bytes_per_launch_from_profiles": pmc.get("sq_fit", {}).get("bytes_per_launch"),
+                                  "measured": "streaming-formulation bytes (12000 + 80 F + 40 per object-step) x 200 steps / launch "
+                                              "duration (HIP events): what an HBM-streaming formulation would move; this kernel "
+                                              "sees each view's 80 bytes through L2 only"}}
     if rank == 0 and ws == 1 and not args.no_config4:
         del frames
         detector.close()
@@ -326,6 +339,78 @@ def main():
         print(json.dumps(result))
     if ws > 1 or args.force_collectives:
         torch.distributed.destroy_process_group()
+
+
+def secondary_blocks(step, detector, chunk, frames, tracks, N, per_frame, scene, device, ms_step_s):
+    """Secondary figures of the one-GPU line (none of them is `value`):
+    host_resident -- the same step with the frames in pinned HOST memory (PCIe-inclusive: uploads overlapped batch by batch);
+    shard_of_8    -- what ONE rank of eight does (125-frame shard + its share of the objects, both fit passes), i.e. the
+                     terms that do not shrink with N (fit latency: one workgroup per object, 200 serial steps) as numbers;
+    with_association -- the sequential association loop the metric leaves out (processor.py:306-345), timed on a sample of
+                     this scene's detections and added to the step (no overlap: an upper bound on its cost)."""
+    out = {}
+    host = frames.cpu().pin_memory()
+    step(src=host); torch.cuda.synchronize()
+    s0 = time.perf_counter(); step(src=host); torch.cuda.synchronize()
+    out["host_resident"] = {"value": N / (time.perf_counter() - s0), "unit": "frames/s",
+                            "note": "frames start in pinned host memory; the uint8 upload (0.92 MB per frame over PCIe) runs on a copy "
+                                    "stream under the previous batch's kernels"}
+    del host
+    f0, f1 = parallel.frame_shard(N, 0, 8)
+    objs8 = parallel.object_shard([len(t) for t in tracks], 0, 8)
+    sub = frames[f0:f1]
+    step(src=sub, objs=objs8, gather=False); torch.cuda.synchronize()
+    s0 = time.perf_counter(); step(src=sub, objs=objs8, gather=False); torch.cuda.synchronize()
+    t8 = time.perf_counter() - s0
+    torch.cuda.synchronize(); s1 = time.perf_counter()
+    for _ in detector.detect_resident_chunks(sub, (synth.IMG_W, synth.IMG_H), synth.K_SCANNET, chunk=chunk):
+        pass
+    torch.cuda.synchronize(); t8_det = time.perf_counter() - s1
+    out["shard_of_8"] = {"frames": f1 - f0, "objects": len(objs8), "ms_per_step": 1e3 * t8, "detect_ms": 1e3 * t8_det,
+                         "fit_ms_two_passes": 1e3 * (t8 - t8_det),
+                         "frames_per_s_if_all_8_ranks_take_this_long": N / t8,
+                         "note": "ONE GPU running rank 0's share of an 8-way split (no collective): NOT a scaling measurement -- no run "
+                                 "on more than one GPU exists; it prices the per-rank step, including the fit latency that does not "
+                                 "shrink when objects are sharded"}
+    try:
+        out["with_association"] = association_block(per_frame, scene, device, N, ms_step_s)
+    except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the line down
+        out["with_association"] = {"error": repr(e)}
+    return out
+
+
+def association_block(per_frame, scene, device, N, ms_step_s, n_sample=200):
+    """OdamProcess.process_frame (track preparation -> association network + Sinkhorn on the device -> Hungarian step ->
+    attach) over the first n_sample frames' detections of this scene, with the hand-written scene association weights of
+    the whole-chain fixture (tests/scene_weights.py).  Sequential over frames and replicated on every rank."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import scene_weights
+    from odam_amd import associator
+    from odam_amd.processor import OdamProcess
+    net = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"],
+                                 "sinkhorn_iterations": 100}, max_tracks=128, device=device)
+    net.load_state_dict(scene_weights.make_scene_associator_state_dict(2, 8, seed=0))
+
+    class _Det:
+        pass
+    d = _Det(); d.device = device
+    proc = OdamProcess(d, net, None, None, fitter=sq.SqFitter(device, 1))
+    proc.init_sequence(synth.K_SCANNET, synth.IMG_H, synth.IMG_W)
+    n = min(n_sample, len(per_frame))
+    ids, T = scene["img_names"], scene["T_wcs"]
+    for i in range(min(8, n)):      # warm-up: handles, first tracks
+        proc.process_frame(None, int(ids[i]), T[i], detections=per_frame[i])
+    torch.cuda.synchronize(); s0 = time.perf_counter()
+    for i in range(8, n):
+        proc.process_frame(None, int(ids[i]), T[i], detections=per_frame[i])
+    torch.cuda.synchronize()
+    per = (time.perf_counter() - s0) / max(1, n - 8)
+    res = {"ms_per_frame": 1e3 * per, "frames_sampled": n - 8, "live_tracks_at_end": len(proc.tracks),
+           "lost_persistent_launches": net.lost_launches,
+           "value": N / (ms_step_s + N * per), "unit": "frames/s",
+           "note": "detect + fit step of this line + the association loop run after it, nothing overlapped"}
+    net.close()
+    return res
 
 
 def config4_block(device, args, pmc):
@@ -394,21 +479,25 @@ def cpu_baseline(scene, tracks, N):
     from conftest import Oracle
     sd = weights.make_state_dict(seed=0, scene=True)
     t = transforms.get_transforms()
-    imgs = [t(f)[0][None] for f in synth.make_frames(3, seed=0)]
+    imgs = [t(f)[0][None] for f in synth.make_frames(6, seed=0)]
     ncpu = os.cpu_count() or 8
     sweep = {}
     keep = torch.get_num_threads()
+
+    def run(xs):
+        s_ = time.perf_counter()
+        for x in xs:
+            out = detr_oracle.detr_forward(sd, x)
+            detr_oracle.postprocess(out, (synth.IMG_W, synth.IMG_H), 0.6, synth.K_SCANNET)
+        return len(xs) / (time.perf_counter() - s_)
     for nt in sorted({n for n in (8, 16, 32, min(64, ncpu)) if n <= ncpu}):   # beyond 64 threads the box only gets slower (256: 0.01 frames/s)
         torch.set_num_threads(nt)
         detr_oracle.detr_forward(sd, imgs[0])          # warm-up at this thread count
-        s = time.perf_counter()
-        for x in imgs[1:]:
-            out = detr_oracle.detr_forward(sd, x)
-            detr_oracle.postprocess(out, (synth.IMG_W, synth.IMG_H), 0.6, synth.K_SCANNET)
-        sweep[nt] = (len(imgs) - 1) / (time.perf_counter() - s)
-    torch.set_num_threads(keep)
+        sweep[nt] = run(imgs[1:3])
     best = max(sweep, key=sweep.get)
-    det_fps = sweep[best]
+    torch.set_num_threads(best)
+    det_fps = run(imgs[1:6])                           # >= 5 frames at the thread count that is reported
+    torch.set_num_threads(keep)
     o = Oracle()
     sample = sorted(range(len(tracks)), key=lambda i: len(tracks[i]))[len(tracks) // 2 - 1: len(tracks) // 2 + 2]
     s = time.perf_counter()
@@ -419,9 +508,10 @@ def cpu_baseline(scene, tracks, N):
               pr["class_id"])
     sq_ops = len(sample) / (time.perf_counter() - s)
     e2e = N / (N / det_fps + 2 * len(tracks) / sq_ops)
-    return {"value": e2e, "unit": "frames/s", "cores": best, "kind": "port",
-            "sample": f"detector oracle (torch CPU fp32, host transform + forward + post-processing): 2 frames per thread count, "
-                      f"best of {sorted(sweep)} threads = {best} threads at {det_fps:.3f} frames/s; SQ oracle (analytic-gradient C "
+    return {"value": e2e, "unit": "frames/s", "cores": ncpu, "threads_used": best, "kind": "port",
+            "sample": f"detector oracle (torch CPU fp32, host transform + forward + post-processing): 2 frames per thread count over "
+                      f"{sorted(sweep)} threads, then 5 frames at the best ({best} threads: {det_fps:.3f} frames/s) on a host with "
+                      f"{ncpu} logical cores; SQ oracle (analytic-gradient C "
                       f"port, 1 thread -- faster than the reference's autograd loop): {len(sample)} median-size objects at "
                       f"{sq_ops:.2f} objects/s; composed as N/(N/det + 2*O/sq) for the {N}-frame, {len(tracks)}-object scene",
             "detector_frames_per_s": det_fps, "detector_frames_per_s_by_threads": {str(k): v for k, v in sweep.items()},

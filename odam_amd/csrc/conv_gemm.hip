@@ -88,15 +88,21 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
             for (int c = 0; c < 8; c++) { sc[c] = (n_ok && a.scale) ? a.scale[n + c] : 1.f; bi[c] = (n_ok && a.bias) ? a.bias[n + c] : 0.f; }
             const unsigned short* resp = reinterpret_cast<const unsigned short*>(a.res);
             unsigned short* outp = reinterpret_cast<unsigned short*>(a.C);
+            // The residual rows of ALL the wave's row tiles are requested before the first one is used: the expand + residual
+            // layers are bound by how many bytes a CU keeps in flight (one workgroup per CU: nothing else covers the epilogue's
+            // HBM latency), and one row tile at a time was 32 KB per CU -- 13 GB/s per CU, 3.1 TB/s over the chip
+            // (layer3's expand).  TM * NIT 16-byte registers per lane (64 at most) are free here: the K loop's fragments are dead.
+            uint4 rv[TM][NIT];
 #pragma unroll
-            for (int i = 0; i < TM; i++) {
-                uint4 rv[NIT];
+            for (int i = 0; i < TM; i++)
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
                     const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
-                    rv[it] = uint4{0u, 0u, 0u, 0u};
-                    if (a.res && n_ok && m < a.M) rv[it] = *reinterpret_cast<const uint4*>(resp + (size_t)m * a.ldc + n);
+                    rv[i][it] = uint4{0u, 0u, 0u, 0u};
+                    if (a.res && n_ok && m < a.M) rv[i][it] = *reinterpret_cast<const uint4*>(resp + (size_t)m * a.ldc + n);
                 }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int j = 0; j < TN; j++)
@@ -113,7 +119,7 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
                     const float4 v0 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c8e]);
                     const float4 v1 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c8e + 4]);
                     const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    const unsigned rw[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+                    const unsigned rw[4] = {rv[i][it].x, rv[i][it].y, rv[i][it].z, rv[i][it].w};
                     unsigned ow[4];
 #pragma unroll
                     for (int c = 0; c < 4; c++) {
@@ -148,23 +154,29 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
         float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
         if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
         if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
+        // residual rows: row tile i + 1's are requested as soon as row tile i's accumulators have gone to LDS (their registers
+        // are free then), i.e. before tile i is read back, combined and stored -- two row tiles of loads in flight per wave
+        // instead of one (the expand + residual layers are bound by the bytes a CU keeps in flight)
+        float4 rv[2][NIT];
+        auto load_res = [&](int i, float4 (&dst)[NIT]) {
 #pragma unroll
-        for (int i = 0; i < TM; i++) {
-            float4 rv[NIT];
-#pragma unroll
-            for (int it = 0; it < NIT; it++) {   // residual rows of this slab: issued before the LDS round trip
+            for (int it = 0; it < NIT; it++) {
                 const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
-                rv[it] = float4{0.f, 0.f, 0.f, 0.f};
+                dst[it] = float4{0.f, 0.f, 0.f, 0.f};
                 if (a.res && n_ok && m < a.M) {
                     const size_t idx = (size_t)m * a.ldc + n;
                     if (res_f32) {
-                        rv[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + idx);
+                        dst[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + idx);
                     } else {
                         const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(a.res) + idx);
-                        rv[it] = float4{bf2f(u.x), bf2f(u.y), bf2f(u.z), bf2f(u.w)};
+                        dst[it] = float4{bf2f(u.x), bf2f(u.y), bf2f(u.z), bf2f(u.w)};
                     }
                 }
             }
+        };
+        load_res(0, rv[0]);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
             // The slab is private to this wavefront and a wavefront's LDS operations execute in order, so the
             // transposition needs no workgroup barrier (the K loop ended with one): waves store as soon as they are done.
             __builtin_amdgcn_wave_barrier();
@@ -173,6 +185,7 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
 #pragma unroll
                 for (int r = 0; r < 16; r++)
                     Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+            if (i + 1 < TM) load_res(i + 1, rv[(i + 1) & 1]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -181,9 +194,10 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
                 const int row = it * RPI + lane / LPR;
                 const int m = m0 + wm * WROWS + i * 32 + row;
                 const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
+                const float4 rr = rv[i & 1][it];
                 float4 o;
                 o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
-                o.x += rv[it].x; o.y += rv[it].y; o.z += rv[it].z; o.w += rv[it].w;
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
                 if (a.relu) {
                     o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
                     o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;

@@ -30,6 +30,14 @@ def frame_shard(n_frames, rank, world_size):
     return start, start + base + (1 if rank < rem else 0)
 
 
+def chunk_spans(n_frames, chunk):
+    """[(first, end)] of consecutive chunks of `chunk` frames (the last one ragged).  Gathering detections chunk by chunk --
+    each chunk dealt over the ranks with frame_shard(end - first, rank, world) and gathered with allgather_detections --
+    hands the sequential, replicated association loop (src/processor.py:306-345) the frames of chunk i while the detectors
+    work on chunk i + 1, instead of after the whole scene."""
+    return [(c0, min(n_frames, c0 + chunk)) for c0 in range(0, n_frames, chunk)]
+
+
 def pack_detections(per_frame_rows):
     """list (per local frame) of lists of 79-float rows -> (float32[F,30,15], int32[F]) truncated to 30 like
     process_frame does"""

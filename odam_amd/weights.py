@@ -156,88 +156,13 @@ def _make_state_dict(backbone, hidden, ffn, enc_layers, dec_layers, num_queries,
     return sd
 
 
-def make_associator_state_dict(n_self=2, n_gnn=8, seed=0, scene=False):
+def make_associator_state_dict(n_self=2, n_gnn=8, seed=0):
     """Deterministic synthetic weights under the reference Associator's key names (src/models/associator.py:163-200;
-    configs/detr_scan_net.yaml: keypoint_encoder [78,256,256], 8 GNN layers, 2 self layers).
-    `scene=False`: random tensors (round-1 goldens): exercises the arithmetic, but every descriptor comes out nearly
-    equal and the assignment is uniform -- nothing is ever matched once a scene has more than a handful of objects.
-    `scene=True`: weights written by hand so that the SAME network associates by position and class (see
-    _scene_associator): whole-pipeline tests and the bench then see real tracks."""
-    sd = _make_associator_state_dict(n_self, n_gnn, seed)
-    if scene:
-        _scene_associator(sd, n_self, n_gnn)
-    return sd
-
-
-def _scene_associator(sd, n_self, n_gnn, S=14.0, G=14.0, PAD=400.0, fp=4.0 / 3.0, z0=3.0, bin_score=10.0):
-    """Hand-written weights for the Associator architecture (associator.py:163-268) that make it a nearest-neighbour
-    matcher on camera-frame position and class:
-      encoder (Conv 78->256, ReLU, Conv 256->256): channels 0-2 = S * (t_co - (0, 0, z0)), channels 3-10 = G * one-hot
-        of the class (0..7; hat functions of the class feature built from ReLU ramps), channel 11 = PAD on padded time
-        steps (class feature -1) and 0 on real ones; every other channel 0;
-      fuser layer 0: every head's attention logit is 0 for real time steps and about -40 for padded ones (the key
-        reads channel 11), value / merge pass channels 0-10 through, and the MLP returns (message - x): after the layer
-        every time step holds the mean descriptor of the track's real steps, so the average pool returns that mean;
-      every other propagation layer: last Conv zeroed (delta = 0);
-      final_proj: fp * (channels 0-10), so score = fp^2 / 16 * <d_track, d_det> -- after the Sinkhorn row / column
-        normalisation that is -fp^2 S^2 / 32 |dt|^2 = -10.9 |dt|^2 per m^2 plus a same-class bonus.
-    The sinusoidal time encoding the network adds to every channel (associator.py:213-220) stays: it perturbs the
-    descriptors by at most 1 / S = 7 cm.
-    S, G and bin_score were picked on the 40-frame fixture of tests/golden/make_golden_e2e.py (reference run on the CPU,
-    grid over S 6-60, G 6-36, bin_score 2-50): with round 2's first choice (60, 36, 5) the scores reached +-1000, new tracks
-    were opened for objects that already had one (61 tracks for ~25 objects), the Sinkhorn loop shared every detection
-    equally among its duplicates (P = 1/k) and EVERY frame's matching hung on the last bits of the detector output.  With
-    (14, 14, 10) the same sequence gives 30 tracks (lengths 40, 36, 35, 32, ...) and the smallest margin of any decision
-    in any frame -- distance of a probability from the 0.1 / 0.8 thresholds, gap between the two best candidates of a
-    detection or a track -- is 2.3e-4, ten times what two fp32 evaluations of the network differ by."""
-    H = 256
-    for k in list(sd):
-        if k.endswith("mlp.2.weight") or k.endswith("mlp.2.bias"):
-            sd[k] = torch.zeros_like(sd[k])
-    # --- encoder ---
-    w0 = torch.zeros(H, 78, 1); b0 = torch.zeros(H)
-    w2 = torch.zeros(H, H, 1); b2 = torch.zeros(H)
-    for m in range(3):                       # t_co: input features 8, 9, 10 (row 9-11 of the 79-vector, first row dropped)
-        off = -z0 if m == 2 else 0.0
-        w0[2 * m, 8 + m, 0] = 1.0; b0[2 * m] = off
-        w0[2 * m + 1, 8 + m, 0] = -1.0; b0[2 * m + 1] = -off
-        w2[m, 2 * m, 0] = S; w2[m, 2 * m + 1, 0] = -S
-    for j, k in enumerate(range(-1, 10)):    # ramps ReLU(class - k), hidden units 6..16
-        w0[6 + j, 0, 0] = 1.0; b0[6 + j] = -float(k)
-    for c in range(8):                       # hat(class - c) = ramp(c-1) - 2 ramp(c) + ramp(c+1)
-        w2[3 + c, 6 + c, 0] = G; w2[3 + c, 6 + c + 1, 0] = -2.0 * G; w2[3 + c, 6 + c + 2, 0] = G
-    w0[17, 0, 0] = -2.0; b0[17] = -1.0       # 1 on padded steps (class = -1), 0 for class >= 0
-    w2[11, 17, 0] = PAD
-    sd["encoder.0.weight"], sd["encoder.0.bias"], sd["encoder.2.weight"], sd["encoder.2.bias"] = w0, b0, w2, b2
-    # --- fuser layer 0 ---
-    p = "fuser.layers.0."
-    nsig = 11
-    wq = torch.zeros(H, H, 1); bq = torch.zeros(H)
-    wk = torch.zeros(H, H, 1); bk = torch.zeros(H)
-    wv = torch.zeros(H, H, 1); bv = torch.zeros(H)
-    wm = torch.zeros(H, H, 1); bm = torch.zeros(H)
-    for h in range(4):                       # channel index = d * 4 + head (associator.py:83)
-        bq[0 * 4 + h] = 1.0
-        wk[0 * 4 + h, 11, 0] = -0.8          # logit = -0.8 * PAD / sqrt(64) = -40 on padded steps
-    for c in range(nsig):
-        wv[c, c, 0] = 1.0; wm[c, c, 0] = 1.0
-    sd[p + "attn.proj.0.weight"], sd[p + "attn.proj.0.bias"] = wq, bq
-    sd[p + "attn.proj.1.weight"], sd[p + "attn.proj.1.bias"] = wk, bk
-    sd[p + "attn.proj.2.weight"], sd[p + "attn.proj.2.bias"] = wv, bv
-    sd[p + "attn.merge.weight"], sd[p + "attn.merge.bias"] = wm, bm
-    m0 = torch.zeros(2 * H, 2 * H, 1); mb0 = torch.zeros(2 * H)
-    m2 = torch.zeros(H, 2 * H, 1)
-    for c in range(nsig):                    # input = cat[x, message]; hidden pairs relu(+-(message - x))
-        m0[2 * c, H + c, 0] = 1.0; m0[2 * c, c, 0] = -1.0
-        m0[2 * c + 1, H + c, 0] = -1.0; m0[2 * c + 1, c, 0] = 1.0
-        m2[c, 2 * c, 0] = 1.0; m2[c, 2 * c + 1, 0] = -1.0
-    sd[p + "mlp.0.weight"], sd[p + "mlp.0.bias"], sd[p + "mlp.2.weight"] = m0, mb0, m2
-    # --- final projection ---
-    wf = torch.zeros(H, H, 1)
-    for c in range(nsig):
-        wf[c, c, 0] = fp
-    sd["final_proj.weight"], sd["final_proj.bias"] = wf, torch.zeros(H)
-    sd["bin_score"] = torch.tensor(float(bin_score))
+    configs/detr_scan_net.yaml: keypoint_encoder [78,256,256], 8 GNN layers, 2 self layers): random tensors.  They exercise
+    the arithmetic, but every descriptor comes out nearly equal and the assignment is uniform.  The hand-written weights
+    that make the same architecture associate by position and class (whole-chain fixture) are test scaffolding and live
+    in tests/scene_weights.py."""
+    return _make_associator_state_dict(n_self, n_gnn, seed)
 
 
 def _make_associator_state_dict(n_self, n_gnn, seed):

@@ -100,3 +100,34 @@ def golden():
 def rel_err(a, b, floor=1e-3):
     a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), floor)))
+
+
+# ---- what the tolerances were measured at: every test may record name -> value; at the end of a GPU session the table is
+# written to gpurun_out/test_measured.json (scratch; a copy of a run is kept under profiles/), so that a tolerance in a
+# test can be checked against what the kernels actually deliver
+_MEASURED = {}
+
+
+def record(name, value):
+    """keep the largest value seen under a name"""
+    v = float(value)
+    if name not in _MEASURED or v > _MEASURED[name]:
+        _MEASURED[name] = v
+
+
+@pytest.fixture(scope="session")
+def measured():
+    return record
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _MEASURED:
+        return
+    import json
+    out = os.path.join(REPO, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "test_measured.json"), "w") as f:
+            json.dump(dict(sorted(_MEASURED.items())), f, indent=1)
+    except OSError:
+        pass

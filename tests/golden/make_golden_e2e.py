@@ -84,6 +84,8 @@ def main():
     from src.models.associator import Associator
     import src.processor as ref_processor
     from odam_amd import weights, synth, transforms
+    sys.path.insert(0, os.path.dirname(HERE))
+    import scene_weights
     rm = patch_run_merge()
     ref_processor.merge_process = rm.merge_process
 
@@ -94,7 +96,7 @@ def main():
     assert not missing.unexpected_keys and all(k.startswith("backbone.0.body.fc") for k in missing.missing_keys), missing
     model.eval()
     net = Associator(CFG)
-    net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0, scene=True), strict=True)
+    net.load_state_dict(scene_weights.make_scene_associator_state_dict(2, 8, seed=0), strict=True)
     net.eval()
     fwd = net.forward
     zs = []

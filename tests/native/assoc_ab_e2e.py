@@ -5,12 +5,14 @@ import numpy as np, torch
 from PIL import Image
 from odam_amd import associator, detector, synth, transforms, weights
 from odam_amd.processor import OdamProcess
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import scene_weights
 DEV = "cuda:0"
 SEQ = dict(n=40, h=256, w=320, seed=11)
 seq = synth.make_sequence(**SEQ)
 det = detector.Detector(max_batch=8, device=DEV, n_streams=1); det.load_state_dict(weights.make_state_dict(seed=0, scene=True))
 cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
-sd = weights.make_associator_state_dict(2, 8, seed=0, scene=True)
+sd = scene_weights.make_scene_associator_state_dict(2, 8, seed=0)
 one = associator.Associator(cfg, max_tracks=64, device=DEV); one.load_state_dict(sd); one._handle()
 os.environ["ODAM_ASSOC_PERSIST"] = "0"
 many = associator.Associator(cfg, max_tracks=64, device=DEV); many.load_state_dict(sd); many._handle()

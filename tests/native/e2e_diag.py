@@ -5,12 +5,14 @@ import numpy as np, torch
 from PIL import Image
 from odam_amd import associator, detector, synth, transforms, weights, merge
 from odam_amd.processor import OdamProcess
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+import scene_weights
 from conftest import rel_err
 z = np.load(os.path.join(ROOT, "tests/golden/e2e.npz"))
 seq = synth.make_sequence(n=40, h=256, w=320, seed=11)
 det = detector.Detector(max_batch=8, device="cuda:0", n_streams=1); det.load_state_dict(weights.make_state_dict(seed=0, scene=True))
 net = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}, max_tracks=64)
-net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0, scene=True))
+net.load_state_dict(scene_weights.make_scene_associator_state_dict(2, 8, seed=0))
 proc = OdamProcess(det, net, transforms.Transforms(size=256), None); proc.init_sequence(seq["K"], 256, 320)
 rows = {}; run = proc.run_detector
 def logged(rgb, fid, T):

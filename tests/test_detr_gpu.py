@@ -401,45 +401,144 @@ def test_conv_gemm_bf16_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
         assert (got - y).abs().max().item() <= tol * max(y.abs().max().item(), 1.0), out_f32
 
 
-def test_bf16_forward_close_to_fp32_oracle():
-    """R101 at a reduced 800x600-like aspect (config 4): documented looser tolerance against the fp32 oracle"""
+def _bf16_check(out, ref_b, ref_f, measured, tag):
+    """A whole bf16 forward against (a) the fp32 oracle and (b) the bf16-faithful restatement
+    (oracle/detr_oracle.py::detr_forward_bf16, which rounds where the kernels round).  Rounding is chaotic over ~120 layers
+    (see test_bf16_layers_teacher_forced, which pins the rounding points layer by layer), so the kernel cannot track (b)
+    closer than two bf16 evaluations track each other; what CAN be required, and is:
+      * the kernel is no farther from the fp32 truth than the faithful bf16 evaluation is (rms within 1.3x, max within 2x):
+        the bf16 mode adds no error beyond bf16 storage itself;
+      * kernel vs (b) stays inside that same noise level (max within 2x of (b) vs fp32);
+      * class labels equal (b)'s wherever (b)'s decision is clear of the noise (top-2 logit gap above twice the largest
+        logit deviation between (b) and fp32), and on at least 98 % of all queries."""
+    def rms(a, b):
+        return ((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-12)).item()
+
+    def mx(a, b):
+        return ((a - b).abs().max() / b.abs().max().clamp_min(1.0)).item()
+    for k in KEYS:
+        assert out[k].dtype == torch.float32
+        g, b_, f = out[k].cpu(), ref_b[k], ref_f[k]
+        for nm, v in (("gpu_vs_fp32_rms", rms(g, f)), ("bf16oracle_vs_fp32_rms", rms(b_, f)), ("gpu_vs_bf16oracle_rms", rms(g, b_)),
+                      ("gpu_vs_fp32_max", mx(g, f)), ("bf16oracle_vs_fp32_max", mx(b_, f)), ("gpu_vs_bf16oracle_max", mx(g, b_))):
+            measured(f"detr_bf16.{tag}.{k}.{nm}", v)
+        assert rms(g, f) <= 1.3 * rms(b_, f) + 1e-4, (k, rms(g, f), rms(b_, f))
+        assert mx(g, f) <= 2.0 * mx(b_, f) + 1e-4, (k, mx(g, f), mx(b_, f))
+        assert mx(g, b_) <= 2.0 * mx(b_, f) + 1e-4, (k, mx(g, b_), mx(b_, f))
+        assert mx(g, f) <= 0.1, (k, mx(g, f))      # sanity cap (bf16 storage through ~120 layers: measured up to 0.09 on the angle head)
+    lab, lab_b = out["pred_logits"].cpu().argmax(-1), ref_b["pred_logits"].argmax(-1)
+    noise = (ref_b["pred_logits"] - ref_f["pred_logits"]).abs().max().item()
+    top2 = ref_b["pred_logits"].topk(2, -1).values
+    decisive = (top2[..., 0] - top2[..., 1]) > 2.0 * noise
+    measured(f"detr_bf16.{tag}.label_disagreement_share", (lab != lab_b).float().mean().item())
+    measured(f"detr_bf16.{tag}.decisive_share", decisive.float().mean().item())
+    assert decisive.float().mean().item() >= 0.2, "fixture without decisive logits"      # measured: 1.0 at 192x256, 0.26 at full size
+    assert torch.equal(lab[decisive], lab_b[decisive])
+    assert (lab == lab_b).float().mean().item() >= 0.98
+
+
+def test_bf16_layers_teacher_forced(measured):
+    """Every contraction of config 4's network (R101 + transformer + heads: 104 convolutions, 86 linear layers) on the
+    bf16-faithful oracle's OWN inputs: the kernel must return the oracle's bf16 bits except for one-ulp ties of the fp32
+    summation order (a sum that lands within ~1e-6 of a bf16 rounding boundary).  This is what pins the rounding points of the
+    bf16 mode -- a whole forward cannot: two evaluations that differ by a fraction of a bf16 ulp round independently from
+    there on, so end to end the kernel and ANY restatement decorrelate to the bf16 noise level (measured below)."""
+    import detr_oracle as O
+    from odam_amd import _lib, weights
+    L = _lib.lib()
+    sd = weights.make_state_dict(backbone="resnet101", seed=0, scene=True)
+    torch.manual_seed(3)
+    img = torch.randn(1, 3, 192, 256)
+    O.TRACE = []
+    try:
+        O.detr_forward_bf16(sd, img, blocks=(3, 4, 23, 3))
+        trace = O.TRACE
+    finally:
+        O.TRACE = None
+    assert len(trace) >= 104 + 80
+    worst_frac, worst_ulp, n_checked = 0.0, 0, 0
+    for rec in trace:
+        x, w, y = rec["x"], rec["w"], rec["y"]
+        if rec["kind"] == "linear":                      # [B, M, K] rows -> a 1 x (B M) image with K channels
+            K_ = x.shape[-1]
+            x = x.reshape(1, -1, K_).permute(0, 2, 1).unsqueeze(2)          # [1, K, 1, BM]
+            w = w.reshape(w.shape[0], K_, 1, 1)
+            y = y.reshape(1, -1, y.shape[-1]).permute(0, 2, 1).unsqueeze(2)
+            res = rec["res"].reshape(1, -1, y.shape[1]).permute(0, 2, 1).unsqueeze(2) if rec["res"] is not None else None
+        else:
+            res = rec["res"]
+        B, Cin, H, W = x.shape
+        Cout, k = w.shape[0], w.shape[2]
+        k_order = 1 if Cin % 64 == 0 and k > 1 else 0
+        wpk, CinP, Kpad = _pack(w, 8, k_order)
+        xh = torch.zeros(B, H, W, CinP); xh[..., :Cin] = x.permute(0, 2, 3, 1)
+        sc = rec["scale"] if rec["scale"] is not None else None
+        dx, dw = _to_bf16_bits(xh).to(DEV), _to_bf16_bits(wpk).to(DEV)
+        dsc = sc.contiguous().to(DEV) if sc is not None else None
+        dbi = rec["bias"].contiguous().to(DEV) if rec["bias"] is not None else None
+        dr = _to_bf16_bits(res.permute(0, 2, 3, 1).contiguous()).to(DEV) if res is not None else None
+        Ho, Wo = y.shape[2], y.shape[3]
+        f32 = bool(rec["out_f32"])
+        dy = torch.empty(B, Ho, Wo, Cout, device=DEV, dtype=torch.float32 if f32 else torch.bfloat16)
+        _lib.check(L.odam_op_conv2d_nhwc_bf16(_lib.ptr(dx), _lib.ptr(dw), _lib.ptr(dsc), _lib.ptr(dbi), _lib.ptr(dr), _lib.ptr(dy),
+                                              B, H, W, CinP, Cout, k, k, rec["stride"], rec["padding"], Kpad, int(rec["relu"]),
+                                              int(f32), k_order, _st()), "conv bf16")
+        want = y.permute(0, 2, 3, 1).contiguous()
+        if f32:       # the head outputs: fp32, summation order only
+            err = (dy.cpu() - want).abs().max().item() / max(1.0, want.abs().max().item())
+            measured("detr_bf16.teacher_forced.f32_out_rel", err)
+            assert err <= 1e-5, (rec["name"], err)
+            continue
+        gb, wb = dy.cpu().view(torch.int16).to(torch.int32), _to_bf16_bits(want).to(torch.int32)
+        diff = (gb - wb).abs()
+        # +0 / -0 (ReLU of a tiny negative vs a tiny positive sum) count as equal
+        zero = ((gb & 0x7fff) == 0) & ((wb & 0x7fff) == 0)
+        diff = torch.where(zero, torch.zeros_like(diff), diff)
+        # near a cancellation (|y| far below the layer's scale) the fp32 summation noise is an ABSOLUTE quantity -- a few 1e-7 of
+        # the terms -- and can span several ulps of a tiny result: such elements must agree to 1e-5 of the layer's range
+        small = (dy.cpu().float() - want).abs() <= 1e-5 * want.abs().max().item()
+        bad = (diff > 1) & ~small
+        frac, ulp = (diff != 0).float().mean().item(), int(torch.where(small, diff.clamp(max=1), diff).max().item())
+        worst_frac, worst_ulp = max(worst_frac, frac), max(worst_ulp, ulp)
+        n_checked += 1
+        assert not bad.any() and frac <= 5e-3, (rec["name"], rec["kind"], tuple(x.shape), frac, int(diff.max().item()))
+    measured("detr_bf16.teacher_forced.worst_mismatch_share", worst_frac)
+    measured("detr_bf16.teacher_forced.worst_ulp", worst_ulp)
+    assert n_checked >= 170
+
+
+def test_bf16_forward_vs_bf16_faithful_oracle(measured):
+    """R101 bf16 (config 4's network) at a reduced size, scene weights (spread logits, 8 live classes)"""
     import detr_oracle as O
     from odam_amd import detector, weights
-    sd = weights.make_state_dict(backbone="resnet101", seed=1)
+    sd = weights.make_state_dict(backbone="resnet101", seed=0, scene=True)
     det = detector.Detector(backbone="resnet101", max_batch=2, device=DEV, dtype="bf16", n_streams=1)
     det.load_state_dict(sd)
     torch.manual_seed(3)
     img = torch.randn(2, 3, 192, 256)
-    ref = O.detr_forward(sd, img, blocks=(3, 4, 23, 3))
+    ref_b = O.detr_forward_bf16(sd, img, blocks=(3, 4, 23, 3))
+    ref_f = O.detr_forward(sd, img, blocks=(3, 4, 23, 3))
     out = det(img.to(DEV))
-    for k in KEYS:
-        assert out[k].dtype == torch.float32
-        err = (out[k].cpu() - ref[k]).abs().max().item()
-        assert err <= 0.05 * max(1.0, ref[k].abs().max().item()), (k, err)
-    agree = (out["pred_logits"].cpu().argmax(-1) == ref["pred_logits"].argmax(-1)).float().mean().item()
-    assert agree >= 0.9, agree
-    feats = out["pred_obj_features"].cpu()
-    assert (feats - ref["pred_obj_features"]).abs().max().item() <= 0.15
+    _bf16_check(out, ref_b, ref_f, measured, "small")
     det.close()
 
 
-def test_bf16_r101_full_size_close_to_fp32_oracle():
-    """BASELINE config 4 at its full size: DETR-R101, one 800x600 frame resized to 3x800x1066, bf16 weights and
-    activations on the bf16 matrix instruction -- same documented tolerance against the fp32 oracle"""
+def test_bf16_r101_full_size_vs_bf16_faithful_oracle(measured):
+    """BASELINE config 4 at its full size: DETR-R101, 800x600 frames resized to 3x800x1066, bf16 weights and activations on
+    the bf16 matrix instruction, batch of 2 (the ring kernel and every large-layer path apply)"""
     import detr_oracle as O
-    from odam_amd import detector, weights
-    sd = weights.make_state_dict(backbone="resnet101", seed=1)
-    det = detector.Detector(backbone="resnet101", max_batch=1, device=DEV, dtype="bf16", n_streams=1)
+    from odam_amd import detector, synth, weights
+    sd = weights.make_state_dict(backbone="resnet101", seed=0, scene=True)
+    det = detector.Detector(backbone="resnet101", max_batch=2, device=DEV, dtype="bf16", n_streams=1)
     det.load_state_dict(sd)
-    torch.manual_seed(4)
-    img = torch.randn(1, 3, 800, 1066)
-    ref = O.detr_forward(sd, img, blocks=(3, 4, 23, 3))
-    out = det(img.to(DEV))
-    for k in KEYS:
-        err = (out[k].cpu() - ref[k]).abs().max().item()
-        assert err <= 0.05 * max(1.0, ref[k].abs().max().item()), (k, err)
-    agree = (out["pred_logits"].cpu().argmax(-1) == ref["pred_logits"].argmax(-1)).float().mean().item()
-    assert agree >= 0.9, agree
+    raw = np.stack(list(synth.make_frames(2, h=600, w=800, seed=4)))
+    img = det.preprocess_u8(torch.from_numpy(raw).to(DEV))
+    assert tuple(img.shape) == (2, 3, 800, 1066)
+    torch.set_num_threads(8)
+    ref_b = O.detr_forward_bf16(sd, img.cpu(), blocks=(3, 4, 23, 3))
+    ref_f = O.detr_forward(sd, img.cpu(), blocks=(3, 4, 23, 3))
+    out = det(img)
+    _bf16_check(out, ref_b, ref_f, measured, "full")
     det.close()
 
 

@@ -6,11 +6,12 @@ reference's own run of it on the CPU (tests/golden/e2e.npz, make_golden_e2e.py):
 
 Asserted: identical detections kept per frame (count, class labels, order), every frame's assignment matrix equal to the
 reference's to 2e-4 in probability and the same association decisions from it in every frame, identical
-track membership and class labels (object IDs) after the 40 frames, identical merge clusters.  Fitted parameters / boxes of both passes, two ways:
-given the reference's own tracks as input the GPU fit reproduces the reference's fit to the north-star tolerance
-(1e-4; measured <= 2e-5 on all fitted objects), or within its ulp-level spread where it has one; at the end of the
-whole chain -- where the fit's inputs already differ by the 1e-5 by which two fp32 detectors differ -- the deviation
-is bounded by the reference's own response to input noise of that size (tests/test_sq_gpu.py::check_against_spread)."""
+track membership and class labels (object IDs) after the 40 frames, identical merge clusters.  Fitted parameters / boxes of
+both passes, two ways: given the reference's own tracks as input, object by object (tests/e2e_lib.py: 25 of the 33 fits within
+5e-5 of the reference, 6 inside the reference's own ulp-level spread, one bistable object shown to have the reference's end
+state one ulp away -- no share of objects is waved through); at the end of the whole chain -- where the fit's inputs already
+differ by the 1e-5 by which two fp32 detectors differ -- the deviation is bounded by the reference's own response to input
+noise of that size (tests/test_sq_gpu.py::check_against_spread), with the number of objects beyond it pinned."""
 import numpy as np
 import pytest
 import torch
@@ -18,6 +19,11 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 SEQ = dict(n=40, h=256, w=320, seed=11)          # make_golden_e2e.py SEQ
+# tolerances: what two correct fp32 evaluations of the chain agree to, measured (gpurun_out/test_measured.json -> profiles/)
+DET_ATOL = 5e-5        # detection rows vs the reference's CPU run (measured 1.7e-5)
+BATCH_ATOL = 1e-4      # a batch of 8 vs the same frames one by one (tile shapes follow the problem size; measured 2.4e-5)
+TRACK_ATOL = 2.5e-3    # track rows after 40 frames of association: pixel coordinates up to 320 (measured 1.1e-3 = 3.4e-6 relative)
+CHAIN_OUTSIDE = {1: 0, 2: 0}      # end of the chain: objects allowed beyond 3x the reference's response to 2e-5 input noise (measured: none)
 
 
 def _params(out):
@@ -35,26 +41,28 @@ def _key(t):
     return tuple(map(tuple, np.asarray(t)[:, :2]))
 
 
-def test_whole_pipeline_matches_the_reference_run(golden):
+def test_whole_pipeline_matches_the_reference_run(golden, measured):
     from PIL import Image
     from odam_amd import associator, detector, synth, transforms, weights
     from odam_amd.processor import OdamProcess
     from conftest import rel_err
     from test_sq_gpu import check_against_spread
+    import e2e_lib
+    import scene_weights
     z = golden("e2e.npz")
     seq = synth.make_sequence(**SEQ)
     det = detector.Detector(max_batch=8, device=DEV, n_streams=1)
     det.load_state_dict(weights.make_state_dict(seed=0, scene=True))
     net = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"],
                                  "sinkhorn_iterations": 100}, max_tracks=64, device=DEV)
-    net.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0, scene=True))
+    net.load_state_dict(scene_weights.make_scene_associator_state_dict(2, 8, seed=0))
     proc = OdamProcess(det, net, transforms.Transforms(size=SEQ["h"]), None)        # reference thresholds 0.6 / 0.1 / 0.8
     proc.init_sequence(seq["K"], SEQ["h"], SEQ["w"])
 
     # Association, frame by frame: our assignment matrix against the reference's own (e2e.npz Z<i>) in every probability,
     # and the decisions taken from it -- Hungarian matches, the 0.1 match threshold, the 0.8 score threshold on matches
     # and on the dustbin row -- against the decisions the reference's matrix gives.  Our own matrix drives the loop.
-    # (The association weights were re-tuned for this: weights._scene_associator explains how round 2's first set left
+    # (The association weights were re-tuned for this: tests/scene_weights.py explains how round 2's first set left
     # every frame's matching on an ulp-level tie; with the present set the smallest decision margin of the reference run is
     # 2.3e-4 in probability.)
     plain = net.assignment
@@ -91,7 +99,8 @@ def test_whole_pipeline_matches_the_reference_run(golden):
         got = np.asarray(rows[fid], np.float64).reshape(-1, 79)
         assert got.shape == ref.shape, (fid, got.shape, ref.shape)
         assert np.array_equal(got[:, :2], ref[:, :2]), fid                  # frame id, class label, NMS order
-        assert np.abs(got - ref).max() <= 2e-3, (fid, np.abs(got - ref).max())
+        measured("e2e.detection_rows_abs", np.abs(got - ref).max())
+        assert np.abs(got - ref).max() <= DET_ATOL, (fid, np.abs(got - ref).max())
         n_det += len(ref)
     assert n_det >= 40 * 15
     # batched: the same detections in the same order; values to fp32 reorder noise, not bit for bit -- the contraction
@@ -100,9 +109,11 @@ def test_whole_pipeline_matches_the_reference_run(golden):
     for fid, r in zip(seq["img_names"], batched):
         b_, s_ = np.asarray(r, np.float64).reshape(-1, 79), np.asarray(rows[fid], np.float64).reshape(-1, 79)
         assert b_.shape == s_.shape and np.array_equal(b_[:, :2], s_[:, :2]), fid
-        assert np.abs(b_ - s_).max() <= 1e-3, (fid, np.abs(b_ - s_).max())
+        measured("e2e.batched_vs_single_abs", np.abs(b_ - s_).max())
+        assert np.abs(b_ - s_).max() <= BATCH_ATOL, (fid, np.abs(b_ - s_).max())
 
     assert len(dP) == int(z["n_calls"])
+    measured("e2e.assignment_dP", max(dP))
     assert max(dP) <= 2e-4, max(dP)
     assert all(same), [i for i, s_ in enumerate(same) if not s_]
 
@@ -112,35 +123,25 @@ def test_whole_pipeline_matches_the_reference_run(golden):
         r = z[f"track{i}"]
         assert t.shape == r.shape, i
         assert np.array_equal(t[:, :2], r[:, :2]), i
-        assert np.abs(t - r).max() <= 5e-3, (i, np.abs(t - r).max())
+        measured("e2e.track_rows_abs", np.abs(t - r).max())
+        assert np.abs(t - r).max() <= TRACK_ATOL, (i, np.abs(t - r).max())
     assert sum(len(t) >= 10 for t in proc.tracks) >= 8
 
-    all_tight = []
-
-    def both(w, ours, refs):
-        """fit pass w on the reference's tracks (pure fit parity) and on our own (end of the chain)"""
-        on_ref = _as_result(proc.optim_process([t.copy() for t in refs]))
-        assert on_ref["fitted"].sum() >= 3
-        check_against_spread(on_ref, z[f"params{w}"], z[f"bboxes_qc{w}"],
-                             {"params": z[f"spread_params{w}"], "bboxes_qc": z[f"spread_bboxes_qc{w}"]}, unfitted_atol=1e-6,
-                             allow_frac=0.2)
-        # north-star tolerance (1e-4) on identical inputs wherever the reference itself is reproducible to 1e-5 under
-        # its six ulp nudges.  Six nudges do not always find an object's tie: the 46-problem survey (test_sq_survey.py)
-        # puts 80 % of the fits inside max(1e-4, own spread), so the pooled requirement below is three quarters
-        # (measured on this fixture: pass 1 three of four -- 3e-7, 1e-7, 1e-6 and one at 2.7e-4)
-        repro = [i for i in np.flatnonzero(on_ref["fitted"])
-                 if max(rel_err(p[i], z[f"params{w}"][i]) for p in z[f"spread_params{w}"]) <= 1e-5]
-        errs = [rel_err(on_ref["params"][i], z[f"params{w}"][i]) for i in repro]
-        tight = [e <= 1e-4 for e in errs]
-        all_tight.extend(tight)
-        if w == 1:
-            assert len(tight) >= 2 and sum(tight) >= 2 and max(errs) <= 1e-2, (repro, errs)
+    def both(w, ours):
+        """fit pass w on the reference's tracks (pure fit parity: object by object, tests/e2e_lib.py -- the same table the CPU
+        suite asserts for the oracle) and on our own (end of the chain)"""
+        rows = e2e_lib.check_fits_on_reference_tracks(z, w, lambda tr: _as_result(proc.optim_process(tr)), measured)
+        assert len(rows) >= 3
         out = proc.optim_process([t.copy() for t in ours])
         noise = {"params": np.concatenate([z[f"spread_params{w}"], z[f"noise_params{w}"]]),
                  "bboxes_qc": np.concatenate([z[f"spread_bboxes_qc{w}"], z[f"noise_bboxes_qc{w}"]])}
-        check_against_spread(_as_result(out), z[f"params{w}"], z[f"bboxes_qc{w}"], noise, unfitted_atol=5e-3, allow_frac=0.2)
+        bad = check_against_spread(_as_result(out), z[f"params{w}"], z[f"bboxes_qc{w}"], noise, unfitted_atol=TRACK_ATOL,
+                                   allow_frac=CHAIN_OUTSIDE[w] / max(1, int(_as_result(out)["fitted"].sum())) + 1e-9)
+        measured(f"e2e.end_of_chain_outside_3x_noise_spread_pass{w}", len(bad))
+        for i, e, s_, iou in bad:
+            measured(f"e2e.end_of_chain_outlier_pass{w}_obj{i}_e", e)
         return out
-    out1 = both(1, proc.tracks, [z[f"track{i}"] for i in range(int(z["n_tracks"]))])
+    out1 = both(1, proc.tracks)
     assert _as_result(out1)["fitted"].sum() >= 8
     merged = proc.merge_process(out1)
     ref_merged = [z[f"merged{i}"] for i in range(int(z["n_merged"]))]
@@ -153,13 +154,10 @@ def test_whole_pipeline_matches_the_reference_run(golden):
         cand = [t for t in rest if t.shape == r.shape and np.array_equal(t[:, :2], r[:, :2])]
         assert cand, "no merged track with the frames / classes of a reference cluster"
         t = min(cand, key=lambda c: np.abs(c - r).max())
-        assert np.abs(t - r).max() <= 5e-3
+        measured("e2e.merged_track_rows_abs", np.abs(t - r).max())
+        assert np.abs(t - r).max() <= TRACK_ATOL
         paired.append(t)
         rest = [c for c in rest if c is not t]
     merged = paired
-    both(2, merged, ref_merged)
-    # pooled over both passes: measured 4 of 6 (pass 1: 3e-7, 1e-7, 2.7e-4, 1e-6).  A sample of six objects under six nudges
-    # each is too small for a population figure -- that is tests/test_sq_survey.py (46 problems, >= 80 % inside
-    # max(1e-4, own spread)); here at least half must be tight and every one passed check_against_spread above
-    assert len(all_tight) >= 4 and np.mean(all_tight) >= 0.5, all_tight
+    both(2, merged)
     net.close(); det.close()

@@ -68,3 +68,55 @@ def test_allgather_gloo(ws):
     for p in procs:
         p.join(timeout=60)
     assert len(res) == ws and all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
+
+
+def _worker8(rank, ws, port, q):
+    """BASELINE configs[2]'s shape: 1000 frames and 30 objects over 8 ranks (125 frames each; objects 4,4,4,4,4,4,3,3), the
+    detections gathered once for the whole scene AND chunk by chunk (256-frame chunks dealt over the ranks, the last one
+    ragged: 232 frames = 29 per rank), which is what lets the replicated association of chunk i run under the detection of
+    chunk i + 1"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from odam_amd import parallel
+    n_frames, n_obj = 1000, 30
+    rs = np.random.RandomState(5)
+    n_per = rs.randint(0, 36, n_frames)                          # some frames above the 30-row cap, some empty
+
+    def rows_of(f):
+        r = -np.ones((n_per[f], 79)); r[:, 0] = f; r[:, 1] = np.arange(n_per[f]) % 8
+        r[:, 2:15] = (f * 0.001 + np.arange(n_per[f])[:, None] * 0.01 + np.arange(13)[None] * 0.1).astype(np.float32)
+        return r
+    want = [rows_of(f)[:30] for f in range(n_frames)]
+    s, e = parallel.frame_shard(n_frames, rank, ws)
+    gb, gc = parallel.allgather_detections(*parallel.pack_detections([rows_of(f) for f in range(s, e)]), n_frames, "cpu")
+    back = parallel.unpack_detections(gb, gc)
+    ok1 = (e - s == 125) and len(back) == n_frames and all(np.array_equal(back[f], want[f]) for f in range(n_frames))
+    # chunk by chunk
+    got, spans = [], parallel.chunk_spans(n_frames, 256)
+    for c0, c1 in spans:
+        a, b = parallel.frame_shard(c1 - c0, rank, ws)
+        cb, cc = parallel.allgather_detections(*parallel.pack_detections([rows_of(f) for f in range(c0 + a, c0 + b)]), c1 - c0, "cpu")
+        got += parallel.unpack_detections(cb, cc)
+    ok2 = spans == [(0, 256), (256, 512), (512, 768), (768, 1000)] and len(got) == n_frames and \
+        all(np.array_equal(got[f], want[f]) for f in range(n_frames))
+    counts = list(rs.randint(10, 300, n_obj))
+    owners = [parallel.object_shard(counts, r, ws) for r in range(ws)]
+    local = np.stack([np.full(33, 7.0 * i, np.float32) for i in owners[rank]])
+    allp = parallel.allgather_rows(local, n_obj, owners, "cpu")
+    ok3 = sorted(len(o) for o in owners) == [3, 3, 4, 4, 4, 4, 4, 4] and np.array_equal(allp[:, 5], 7.0 * np.arange(n_obj))
+    q.put((rank, ok1, ok2, ok3))
+    dist.destroy_process_group()
+
+
+def test_allgather_gloo_world_of_8():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 77) % 2000
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(8)]
+    for p in procs:
+        p.join(timeout=60)
+    assert len(res) == 8 and all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
