@@ -124,6 +124,14 @@ int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const float* scal
 int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* scale, const float* bias,
                              const void* residual, void* y, int B, int H, int W, int Cin, int Cout, int KH, int KW,
                              int stride, int pad, int Kpad, int relu, int out_f32, int k_order, void* stream);
+/* bf16 bottleneck tail as one launch (BASELINE config 4; replaces what torchvision's Bottleneck.forward runs after conv1 --
+ * conv2, bn2, relu, conv3, bn3, += identity, relu -- as instantiated at src/models/backbone.py:90-92, plus optionally the next
+ * block's conv1 / bn1 / relu): x [dev][B,H,W,P] bf16 (P = 64 / 128 / 256), w2 [P][9 P] packed k_order 1, w3 [4 P][P], residual / y
+ * [B,Ho,Wo,4 P] bf16, w1n [PN][4 P] + y_next [B,Ho,Wo,PN] optional (PN = 0: none).  Returns 4 where the fused kernel does not
+ * apply (shape / size); bit-identical to the layers run one by one through odam_op_conv2d_nhwc_bf16. */
+int odam_op_bottleneck_bf16(const void* x, const void* w2, const float* s2, const float* b2, const void* w3, const float* s3,
+                            const float* b3, const void* residual, void* y, const void* w1n, const float* s1n, const float* b1n,
+                            void* y_next, int B, int H, int W, int P, int stride, int PN, void* stream);
 /* which layers the bf16-native 256-row schedule of the contraction kernel takes: 0 none, 1 those large enough to fill
  * the device (default), 2 every eligible layer (parity tests on small shapes).  Process-wide; also ODAM_CG_BIG. */
 int odam_op_conv_bf16_mode(int mode);

@@ -66,6 +66,10 @@ struct ConvGemmArgs {
     const float* G_bias = nullptr;
     float* G_C = nullptr;           // [M, G_N]
     int G_N = 64;                   // 64 (the next block of the same stage) or 128 (layer2's first reduce after layer1's last block)
+    // bf16 mode (dtype ODAM_CG_BF16), the same two fusions with plain bf16 filters: F_Wt [F_ldc][Cout] (the 1x1 expand, K = this
+    // layer's Cout = 64 / 128 / 256), G_Wt [G_N][F_ldc] (the next reduce).  F_res / F_C / G_C then point to bf16 tensors.
+    const void* F_Wt = nullptr;
+    const void* G_Wt = nullptr;
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
@@ -81,6 +85,11 @@ void set_f32_mode(int mode);
 int f32_mode();
 // whether launch_conv_gemm would run `a` (with its F_* fields set) on the fused kernel right now
 bool fused_second_ok(const ConvGemmArgs& a);    // the mode fp32 layers run in right now (0 when the ring kernel is switched off altogether)
+
+// bf16: whether launch_conv_gemm would run `a` (F_Wt [+ G_Wt] set) as one bottleneck launch; set_fuse_bf16: 0 off, 1 expand
+// only, 2 (default) with the chained reduce.  Also read once from ODAM_CG_FUSE_BF16.
+bool fused_bf16_ok(const ConvGemmArgs& a);
+void set_fuse_bf16(int mode);
 
 // host: exact three-way bf16 split (truncation) of packed fp32 filters w[Cout][Kpad] (Kpad % 16 == 0) into the Wt3 layout
 void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out);

@@ -259,19 +259,35 @@ int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, cons
 int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, int B, int H, int W, const void* res, void* y,
                  hipStream_t st, const Conv* next_c1 = nullptr, void* t_next = nullptr, bool* chained = nullptr) {
     if (chained) *chained = false;
-    if (m->dt || !c2.w3 || !c3.w3 || c3.KH != 1 || c3.stride != 1 || c3.Kpad != c2.Cout) return -1;
+    if (c3.KH != 1 || c3.stride != 1 || c3.Kpad != c2.Cout) return -1;
+    if (!m->dt && (!c2.w3 || !c3.w3)) return -1;
     ConvGemmArgs a{};
-    a.dtype = 0; a.out_f32 = 0;
+    a.dtype = m->dt; a.out_f32 = 0;
     a.A = x; a.Wt = c2.w; a.Wt3 = c2.w3; a.scale = c2.scale; a.bias = c2.bias; a.res = nullptr; a.C = nullptr;
     a.B = B; a.H = H; a.W = W; a.Cin = c2.Cin; a.log2Cin = ilog2(c2.Cin);
     a.Ho = conv_out(H, c2.KH, c2.stride, c2.pad); a.Wo = conv_out(W, c2.KW, c2.stride, c2.pad);
     a.Cout = c2.Cout; a.KH = c2.KH; a.KW = c2.KW; a.stride = c2.stride; a.pad = c2.pad; a.Kpad = c2.Kpad;
     a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = c2.Cout; a.k_order = c2.k_order;
-    a.F_Wt3 = c3.w3; a.F_scale = c3.scale; a.F_bias = c3.bias; a.F_res = (const float*)res; a.F_C = (float*)y;
+    a.F_scale = c3.scale; a.F_bias = c3.bias; a.F_res = (const float*)res; a.F_C = (float*)y;
     a.F_ldc = c3.Cout; a.F_relu = 1;
     double flops3 = 0.0;
-    if (next_c1 && t_next && next_c1->w3 && next_c1->KH == 1 && next_c1->stride == 1 && (next_c1->Cout == 64 || next_c1->Cout == 128) &&
-        next_c1->Kpad == c3.Cout && c3.Cout == 256) {
+    const bool next_ok = next_c1 && t_next && next_c1->KH == 1 && next_c1->stride == 1 && next_c1->Kpad == c3.Cout;
+    if (m->dt) {
+        // bf16: 3x3 + expand + residual (+ the next block's reduce where the channel combination is built) as one launch
+        a.F_Wt = c3.w;
+        if (next_ok) {
+            a.G_Wt = next_c1->w; a.G_scale = next_c1->scale; a.G_bias = next_c1->bias; a.G_C = (float*)t_next; a.G_N = next_c1->Cout;
+            if (odam_cg::fused_bf16_ok(a)) {
+                if (chained) *chained = true;
+                flops3 = 2.0 * a.M * (double)next_c1->Cout * c3.Cout;
+            } else {
+                a.G_Wt = nullptr; a.G_scale = a.G_bias = nullptr; a.G_C = nullptr; a.G_N = 64;
+            }
+        }
+        if (!odam_cg::fused_bf16_ok(a)) return -1;
+    } else {
+    a.F_Wt3 = c3.w3;
+    if (next_ok && next_c1->w3 && (next_c1->Cout == 64 || next_c1->Cout == 128) && c3.Cout == 256) {
         a.G_Wt3 = next_c1->w3; a.G_scale = next_c1->scale; a.G_bias = next_c1->bias; a.G_C = (float*)t_next; a.G_N = next_c1->Cout;
         if (odam_cg::fused_second_ok(a)) {
             if (chained) *chained = true;
@@ -281,6 +297,7 @@ int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, in
         }
     }
     if (!odam_cg::fused_second_ok(a)) return -1;
+    }
     if (!m->profile) return odam_cg::launch_conv_gemm(a, st);
     if (m->ev_used + 2 > m->ev.size()) {
         for (int k = 0; k < 2; k++) {
@@ -728,6 +745,28 @@ extern "C" int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, con
     c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
     c.k_order = k_order;
     return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream, 1, out_f32);
+}
+
+// A whole bf16 bottleneck tail as ONE launch (conv_gemm.hip fused_bf16): 3x3 (P -> P channels, stride 1 or 2, pad 1; filters
+// packed k_order 1) + scale / bias / ReLU, 1x1 expand to 4 P channels + scale / bias + residual + ReLU -> y, and optionally the
+// next block's 1x1 reduce (4 P -> PN channels, scale / bias / ReLU) of y -> y_next.  Returns 4 where the fused kernel does
+// not apply to the shape (the caller then runs the layers one by one with odam_op_conv2d_nhwc_bf16; results are bit-identical).
+extern "C" int odam_op_bottleneck_bf16(const void* x, const void* w2, const float* s2, const float* b2, const void* w3,
+                                       const float* s3, const float* b3, const void* residual, void* y, const void* w1n,
+                                       const float* s1n, const float* b1n, void* y_next, int B, int H, int W, int P, int stride,
+                                       int PN, void* stream) {
+    if (!x || !w2 || !w3 || !y) return odam_fail(1, "odam_op_bottleneck_bf16: null pointer");
+    ConvGemmArgs a{};
+    a.dtype = 1;
+    a.A = x; a.Wt = w2; a.scale = s2; a.bias = b2;
+    a.B = B; a.H = H; a.W = W; a.Cin = P; a.log2Cin = ilog2(P);
+    a.Ho = conv_out(H, 3, stride, 1); a.Wo = conv_out(W, 3, stride, 1);
+    a.Cout = P; a.KH = 3; a.KW = 3; a.stride = stride; a.pad = 1; a.Kpad = 9 * P;
+    a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = P; a.k_order = 1;
+    a.F_Wt = w3; a.F_scale = s3; a.F_bias = b3; a.F_res = (const float*)residual; a.F_C = (float*)y; a.F_ldc = 4 * P; a.F_relu = 1;
+    if (w1n && PN > 0) { a.G_Wt = w1n; a.G_scale = s1n; a.G_bias = b1n; a.G_C = (float*)y_next; a.G_N = PN; }
+    if (!odam_cg::fused_bf16_ok(a)) return odam_fail(4, "odam_op_bottleneck_bf16: the fused kernel does not apply to this shape");
+    return odam_cg::launch_conv_gemm(a, (hipStream_t)stream);
 }
 
 // experiment switch of the bf16-native contraction kernel (conv_gemm.h set_big_mode): 0 off, 1 auto, 2 whenever eligible

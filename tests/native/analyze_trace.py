@@ -31,7 +31,9 @@ for l, nb in enumerate(BLOCKS):
         have_c1 = False
         if i == 0: take(f"l{l+1}.{i}.ds", 2.0 * B * ho * wo * pl * 4 * inpl)
         fk = fuse_kind(convs[pos]) if pos < len(convs) else 0
-        if fk in (2, 4):      # 4: the chained reduce is the next STAGE's (twice the planes)
+        if fk >= 6:           # bf16 bottleneck on the tile with the chained reduce: PN = 32 << (fk - 5) output channels
+            take(f"l{l+1}.{i}.c2+c3+c1'", f_c2 + f_c3 + 2.0 * B * ho * wo * (32 << (fk - 5)) * pl * 4); have_c1 = True
+        elif fk in (2, 4):    # 4: the chained reduce is the next STAGE's (twice the planes)
             take(f"l{l+1}.{i}.c2+c3+c1'", f_c2 + f_c3 + 2.0 * B * ho * wo * (pl if fk == 2 else 2 * pl) * pl * 4); have_c1 = True
         elif fk:
             take(f"l{l+1}.{i}.c2+c3", f_c2 + f_c3)

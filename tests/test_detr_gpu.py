@@ -401,6 +401,69 @@ def test_conv_gemm_bf16_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
         assert (got - y).abs().max().item() <= tol * max(y.abs().max().item(), 1.0), out_f32
 
 
+@pytest.mark.parametrize("B,H,W,P,stride,PN,res", [
+    (2, 37, 45, 64, 1, 0, True),       # layer1 shape, ragged last tile (3330 rows)
+    (2, 37, 45, 64, 1, 64, True),      # ... + the next block's reduce on the tile
+    (1, 40, 52, 64, 1, 128, True),     # layer1's last block chained into layer2's first reduce
+    (2, 33, 41, 128, 1, 128, True),
+    (2, 33, 41, 128, 2, 0, True),      # a stage's first block: stride 2 on the 3x3
+    (3, 25, 34, 256, 1, 0, True),      # layer3 shape
+    (2, 26, 35, 256, 2, 0, False),     # stride 2, odd size, no residual
+])
+def test_bf16_bottleneck_on_the_tile_is_bit_identical(B, H, W, P, stride, PN, res):
+    """3x3 + expand + residual (+ next reduce) as ONE launch (conv_gemm.hip fused_bf16) against the same layers launched one by
+    one: same products in the same order, same rounding points -> the same bf16 bits"""
+    from odam_amd import _lib
+    L = _lib.lib()
+    torch.manual_seed(B * 100 + P + PN + stride)
+    Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+    x = torch.randn(B, H, W, P)
+    w2 = torch.randn(P, P, 3, 3) / (9 * P) ** 0.5
+    w3 = torch.randn(4 * P, P, 1, 1) / P ** 0.5
+    w1n = torch.randn(max(PN, 1), 4 * P, 1, 1) / (4 * P) ** 0.5
+    s2, b2 = torch.rand(P) + 0.5, torch.randn(P) * 0.3
+    s3, b3 = torch.rand(4 * P) + 0.5, torch.randn(4 * P) * 0.3
+    s1, b1 = torch.rand(max(PN, 1)) + 0.5, torch.randn(max(PN, 1)) * 0.3
+    r = torch.randn(B, Ho, Wo, 4 * P)
+    w2p, _, K2 = _pack(w2, 8, 1); w3p, _, K3 = _pack(w3, 8, 0); w1p, _, K1 = _pack(w1n, 8, 0)
+    assert K2 == 9 * P and K3 == P and K1 == 4 * P
+    d = lambda t: _to_bf16_bits(t.contiguous()).to(DEV)
+    dx, dw2, dw3, dw1, dr = d(x), d(w2p), d(w3p), d(w1p), d(r) if res else None
+    f = lambda t: t.contiguous().to(DEV)
+    ds2, db2, ds3, db3, ds1, db1 = f(s2), f(b2), f(s3), f(b3), f(s1), f(b1)
+    bf = lambda *shape: torch.full(shape, -1, device=DEV, dtype=torch.int16)
+    # one by one
+    _lib.check(L.odam_op_conv_bf16_mode(2), "mode")
+    try:
+        t = bf(B, Ho, Wo, P); y0 = bf(B, Ho, Wo, 4 * P); n0 = bf(B, Ho, Wo, max(PN, 1))
+        _lib.check(L.odam_op_conv2d_nhwc_bf16(_lib.ptr(dx), _lib.ptr(dw2), _lib.ptr(ds2), _lib.ptr(db2), None, _lib.ptr(t), B, H, W, P, P, 3, 3,
+                                              stride, 1, K2, 1, 0, 1, _st()), "c2")
+        _lib.check(L.odam_op_conv2d_nhwc_bf16(_lib.ptr(t), _lib.ptr(dw3), _lib.ptr(ds3), _lib.ptr(db3), _lib.ptr(dr), _lib.ptr(y0), B, Ho, Wo, P,
+                                              4 * P, 1, 1, 1, 0, K3, 1, 0, 0, _st()), "c3")
+        if PN:
+            _lib.check(L.odam_op_conv2d_nhwc_bf16(_lib.ptr(y0), _lib.ptr(dw1), _lib.ptr(ds1), _lib.ptr(db1), None, _lib.ptr(n0), B, Ho, Wo, 4 * P,
+                                                  PN, 1, 1, 1, 0, K1, 1, 0, 0, _st()), "c1n")
+        y1 = bf(B, Ho, Wo, 4 * P); n1 = bf(B, Ho, Wo, max(PN, 1))
+        _lib.check(L.odam_op_bottleneck_bf16(_lib.ptr(dx), _lib.ptr(dw2), _lib.ptr(ds2), _lib.ptr(db2), _lib.ptr(dw3), _lib.ptr(ds3), _lib.ptr(db3),
+                                             _lib.ptr(dr), _lib.ptr(y1), _lib.ptr(dw1) if PN else None, _lib.ptr(ds1), _lib.ptr(db1),
+                                             _lib.ptr(n1) if PN else None, B, H, W, P, stride, PN, _st()), "bottleneck")
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(L.odam_op_conv_bf16_mode(1), "mode")
+    assert torch.equal(y1, y0), (y1 != y0).float().mean().item()
+    if PN:
+        assert torch.equal(n1, n0), (n1 != n0).float().mean().item()
+    # and the one-by-one result is the convolution (sanity: against torch on the bf16-rounded operands)
+    rb = lambda t_: t_.to(torch.bfloat16).float()
+    mid = rb(F.relu(F.conv2d(rb(x).permute(0, 3, 1, 2), rb(w2), None, stride, 1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1)))
+    out = F.conv2d(mid, rb(w3)) * s3.view(1, -1, 1, 1) + b3.view(1, -1, 1, 1)
+    if res:
+        out = out + rb(r).permute(0, 3, 1, 2)
+    out = F.relu(out)
+    got = y1.view(torch.bfloat16).float().cpu().permute(0, 3, 1, 2)
+    assert (got - out).abs().max().item() <= 1.6e-2 * max(1.0, out.abs().max().item())
+
+
 def _bf16_check(out, ref_b, ref_f, measured, tag):
     """A whole bf16 forward against (a) the fp32 oracle and (b) the bf16-faithful restatement
     (oracle/detr_oracle.py::detr_forward_bf16, which rounds where the kernels round).  Rounding is chaotic over ~120 layers
