@@ -187,7 +187,7 @@ def main():
     detector.profile(H, W, False)
     # the same scene with every fp32 layer on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): one untimed + one timed pass
     from odam_amd import _lib
-    split_mode = os.environ.get("ODAM_CG_BIG_F32", "2") == "2"
+    split_mode = _lib.config()["cg.f32"] == 2
     f32_instr = None
     if split_mode and rank == 0 and ws == 1:
         _lib.check(_lib.lib().odam_op_conv_f32_mode(0), "odam_op_conv_f32_mode")
@@ -239,6 +239,7 @@ def main():
                                f"200-step SQ fit over {len(tracks)} objects (10-300 views), fp32",
                    "frames": N, "objects": len(tracks), "detector_batch": args.batch, "detector_streams": args.streams,
                    "parallelism": f"frames and objects sharded over {ws} GPU(s)" + (", RCCL all-gather" if ws > 1 else "")},
+        "library_config": _lib.config(),      # every kernel-selecting switch in force (include/odam_config.h); defaults unless ODAM_CONFIG says otherwise
         "detections_per_scene": n_det,
         "detections_per_frame": n_det / N,
         "detect_only_frames_per_s_per_gpu": (f1 - f0) / t_det,
@@ -284,7 +285,7 @@ def main():
                                                 "measured": "one forward alone on one stream, HIP event pair around every launch"}}
 
     if att_ms > 0:
-        att_x3 = os.environ.get("ODAM_ATT_X3", "1") != "0"      # fp32 attention through the exact bf16 split (the default)
+        att_x3 = _lib.config()["att.x3"] != 0      # fp32 attention through the exact bf16 split (the default)
         att_peak = PEAK_F32_SPLIT if att_x3 else PEAK_FP32_MFMA
         result["attention_kernel"] = {"achieved": att_flops / (att_ms * 1e-3) / 1e12, "peak": att_peak / 1e12,
                                       "unit": "TFLOP/s", "frac": att_flops / (att_ms * 1e-3) / att_peak,
@@ -461,7 +462,9 @@ def config4_block(device, args, pmc):
             "roofline": {"bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                          "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
                          "frac": conv_flops / (conv_ms * 1e-3) / PEAK_BF16_MFMA if conv_ms > 0 else None,
-                         "kernel": "conv_gemm (bf16: 256-row LDS-DMA ring kernel for long-K layers, 128x128 tiles otherwise)",
+                         "kernel": "conv_gemm (bf16: 256-row LDS-DMA ring kernel; 3x3 stride 1 through one LDS window per three taps; layer1-3 "
+                                   "bottlenecks as one launch each: 3x3 + expand + residual, in layer1 / layer2 also the next reduce; 128x128 "
+                                   "tiles for small layers)",
                          "launches_per_forward": n_launch, "ms_per_forward_of_%d" % B: conv_ms,
                          "algorithmic_gflop_per_frame": conv_flops / B / 1e9,
                          "traffic": pmc.get("conv_gemm_bf16_r101", {}).get("bytes_per_frame"),

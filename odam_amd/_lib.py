@@ -19,6 +19,41 @@ class OdamError(RuntimeError):
     pass
 
 
+# Switches of the HOST program (experiments, the nested test harness): "ODAM_CONFIG=cg.ring=2,cg.f32=0", or the variable
+# names of rounds 1-2, are translated here into odam_config_set calls when the library is loaded.  The library itself never
+# reads the environment; config() returns what is in force so that a program can log it (bench.py does).
+_LEGACY_ENV = {"ODAM_CG_BIG": ("cg.ring", False), "ODAM_CG_BIG_F32": ("cg.f32", False), "ODAM_CG_FUSE": ("cg.fuse", False),
+               "ODAM_CG_FUSE_BF16": ("cg.fuse_bf16", False), "ODAM_CG_S1": ("cg.s1", False), "ODAM_CG_NO_UT": ("cg.ut", True),
+               "ODAM_CG_VARIANT": ("cg.tiles", False), "ODAM_CG_FORCE": ("cg.force", False), "ODAM_CG_NO_PRESPLIT": ("cg.presplit", True),
+               "ODAM_ATT_X3": ("att.x3", False), "ODAM_ATT_FP32": ("att.bf16_mfma", True), "ODAM_STEM_ROWS": ("stem.rows", False),
+               "ODAM_ASSOC_PERSIST": ("assoc.persist", False), "ODAM_SQ_SPLIT": ("sq.split", False),
+               "ODAM_SQ_SPLIT_WAIT": ("sq.split_wait", False), "ODAM_SQ_S": ("sq.lanes", False)}
+
+
+def _apply_env(L):
+    pairs = []
+    for name, (key, presence_means_off) in _LEGACY_ENV.items():
+        if name in os.environ:
+            pairs.append((key, 0 if presence_means_off else int(os.environ[name])))
+    for item in filter(None, os.environ.get("ODAM_CONFIG", "").split(",")):
+        k, v = item.split("=")
+        pairs.append((k.strip(), int(v)))
+    for k, v in pairs:
+        if L.odam_config_set(k.encode(), ctypes.c_int(v)) != 0:
+            raise OdamError(L.odam_last_error().decode("utf-8", "replace"))
+
+
+def config():
+    """the library's switch table as {key: value} (odam_config.h)"""
+    buf = ctypes.create_string_buffer(1024)
+    check(lib().odam_config_describe(buf, 1024), "odam_config_describe")
+    return {k: int(v.rstrip("*")) for k, v in (kv.split("=") for kv in buf.value.decode().split())}
+
+
+def set_config(key, value):
+    check(lib().odam_config_set(key.encode(), ctypes.c_int(int(value))), f"odam_config_set({key})")
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -32,6 +67,7 @@ def lib():
         import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         L.odam_last_error.restype = ctypes.c_char_p
+        _apply_env(L)
         _lib = L
     return _lib
 

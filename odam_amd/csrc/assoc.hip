@@ -21,6 +21,7 @@
 #include "../../include/odam_assoc.h"
 #include "conv_gemm.h"
 #include "detr_kernels.h"
+#include "odam_config.h"
 #include "odam_err.h"
 
 using odam_cg::ConvGemmArgs;
@@ -515,14 +516,6 @@ struct odam_assoc {
     float *feat = nullptr, *h256 = nullptr, *catT = nullptr, *kv = nullptr, *att = nullptr, *h512 = nullptr;
     float *kvX = nullptr, *attX = nullptr, *hX = nullptr;
     float *catTr = nullptr, *featD = nullptr, *mT = nullptr, *scores = nullptr;
-    // graph replay (one captured launch sequence per track count): inputs and the result go through fixed buffers
-    float *in_tracks = nullptr, *in_det = nullptr, *out_Z = nullptr;
-    int* d_ndet = nullptr;
-    int* h_ndet = nullptr;               // pinned ring: the detection count of a frame until its upload has run
-    unsigned ring = 0;
-    std::map<int, hipGraphExec_t> graphs;
-    hipStream_t cap_stream = nullptr;
-    bool use_graph = true;
     // persistent matching kernel: barrier counters (+ error flag), zeroed on the stream before every launch
     unsigned* bar = nullptr;
     bool persist = true;
@@ -633,10 +626,7 @@ extern "C" int odam_assoc_create(int max_tracks, int n_self_layers, const int* g
 
 extern "C" int odam_assoc_destroy(odam_assoc* m) {
     if (!m) return 0;
-    for (auto& kv : m->graphs) (void)hipGraphExecDestroy(kv.second);
-    if (m->h_ndet) (void)hipHostFree(m->h_ndet);
     if (m->lost_count) (void)hipHostFree(m->lost_count);
-    if (m->cap_stream) (void)hipStreamDestroy(m->cap_stream);
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
     return 0;
@@ -690,11 +680,6 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     RC(m->alloc(&m->mT, (T + ND + 2) * D)); RC(m->alloc(&m->scores, T * 32));   // the score block reads 32 detection rows
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    RC(m->alloc(&m->in_tracks, T * NF * NT)); RC(m->alloc(&m->in_det, (size_t)NF * ND)); RC(m->alloc(&m->out_Z, (T + 1) * (ND + 1)));
-    float* nd = nullptr;
-    RC(m->alloc(&nd, 1));
-    m->d_ndet = reinterpret_cast<int*>(nd);
-    ODAM_HIP(hipHostMalloc((void**)&m->h_ndet, 64 * sizeof(int), hipHostMallocDefault));
     {
         float* b = nullptr;
         RC(m->alloc(&b, 32 * (1 + PG_GROUPS)));
@@ -707,9 +692,9 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     }
     ODAM_HIP(hipHostMalloc((void**)&m->lost_count, 64, hipHostMallocDefault));
     *m->lost_count = 0u;
-    // ODAM_ASSOC_PERSIST=0 / odam_assoc_set_persistent(m, 0): the matching GNN as one launch per layer op (the round-1
-    // sequence; tests compare the two)
-    m->persist = m->n_gnn <= PG_MAXL && !(getenv("ODAM_ASSOC_PERSIST") != nullptr && atoi(getenv("ODAM_ASSOC_PERSIST")) == 0);
+    // odam_config assoc.persist = 0 / odam_assoc_set_persistent(m, 0): the matching GNN as one launch per layer op (the
+    // round-1 sequence; tests compare the two)
+    m->persist = m->n_gnn <= PG_MAXL && odam_cfg::get(odam_cfg::ASSOC_PERSIST) != 0;
     {   // The persistent launch is a plain launch whose PG_WG workgroups wait for each other: all of them must be resident at
         // once.  How many fit is asked of the runtime for THIS kernel (246 VGPRs: two workgroups per CU), less one per CU
         // where it says more than one (MI355X_MICROARCH.md: the API reads one high for some SGPR counts), times the CUs;
@@ -722,7 +707,6 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
         if (getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr) m->resident_capacity = 0;
         if (m->resident_capacity < PG_WG) m->persist = false;
     }
-    m->use_graph = getenv("ODAM_ASSOC_GRAPH") != nullptr && atoi(getenv("ODAM_ASSOC_GRAPH")) != 0;   // measured: no gain (the sequence is bound by ~65 dependent kernels of ~10 us on the device, not by host launches)
     m->host.clear();
     m->finalized = true;
     return 0;
@@ -798,42 +782,14 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
     return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, n_dev, st);   // n_dev (graph replay): n_det is the capacity, 30
 }
 
-// One frame.  The sequence above is launch-bound (44 small GEMMs + 18 attention launches + prepare / pooling / Sinkhorn),
-// so it is captured ONCE per track count into a hipGraph and replayed: the inputs are copied into fixed buffers, the
-// frame's detection count travels through a device word the Sinkhorn kernel reads, the result is copied out.  Same
-// kernels, same bits as the eager sequence (ODAM_ASSOC_GRAPH=0 keeps that).
+// One frame (stream-ordered).  (Replaying the launch sequence from a hipGraph per track count was built in round 2 and measured
+// no gain -- the sequence is bound by ~65 dependent kernels of ~10 us on the device, not by host launches -- and is gone.)
 extern "C" int odam_assoc_forward(odam_assoc* m, const float* tracks, int T, const float* detections, int n_det,
                                   float* Z_out, void* stream) {
     if (!m || !tracks || !detections || !Z_out) return odam_fail(1, "odam_assoc_forward: null pointer");
     if (!m->finalized) return odam_fail(1, "odam_assoc_forward: call odam_assoc_finalize first");
     if (T < 1 || T > m->max_tracks || n_det < 1 || n_det > ND) return odam_fail(3, "odam_assoc_forward: T / n_det out of range");
-    hipStream_t st = (hipStream_t)stream;
-    if (!m->use_graph || m->persist) return enqueue_forward(m, tracks, T, detections, n_det, nullptr, Z_out, st);
-    ODAM_HIP(hipMemcpyAsync(m->in_tracks, tracks, sizeof(float) * (size_t)T * NF * NT, hipMemcpyDeviceToDevice, st));
-    ODAM_HIP(hipMemcpyAsync(m->in_det, detections, sizeof(float) * NF * ND, hipMemcpyDeviceToDevice, st));
-    int* slot = m->h_ndet + (m->ring++ & 63);
-    *slot = n_det;
-    ODAM_HIP(hipMemcpyAsync(m->d_ndet, slot, sizeof(int), hipMemcpyHostToDevice, st));
-    auto it = m->graphs.find(T);
-    if (it == m->graphs.end()) {
-        // captured on a stream of the handle (the caller's may be the legacy default stream, which cannot capture);
-        // nothing executes during capture, the instantiated graph is then launched on the caller's stream
-        hipGraph_t g = nullptr;
-        if (!m->cap_stream) ODAM_HIP(hipStreamCreateWithFlags(&m->cap_stream, hipStreamNonBlocking));
-        ODAM_HIP(hipStreamBeginCapture(m->cap_stream, hipStreamCaptureModeRelaxed));
-        const int rc = enqueue_forward(m, m->in_tracks, T, m->in_det, ND, m->d_ndet, m->out_Z, m->cap_stream);   // LDS sized for 30 detections
-        const hipError_t e = hipStreamEndCapture(m->cap_stream, &g);
-        if (rc) { if (g) (void)hipGraphDestroy(g); return rc; }
-        ODAM_HIP(e);
-        hipGraphExec_t ex = nullptr;
-        const hipError_t ei = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(g);
-        ODAM_HIP(ei);
-        it = m->graphs.emplace(T, ex).first;
-    }
-    ODAM_HIP(hipGraphLaunch(it->second, st));
-    ODAM_HIP(hipMemcpyAsync(Z_out, m->out_Z, sizeof(float) * (size_t)(T + 1) * (n_det + 1), hipMemcpyDeviceToDevice, st));
-    return 0;
+    return enqueue_forward(m, tracks, T, detections, n_det, nullptr, Z_out, (hipStream_t)stream);
 }
 
 // The same forward with the matching layers as separate launches (no device-wide barrier, no residency assumption): what

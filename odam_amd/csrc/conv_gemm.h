@@ -70,26 +70,26 @@ struct ConvGemmArgs {
     // layer's Cout = 64 / 128 / 256), G_Wt [G_N][F_ldc] (the next reduce).  F_res / F_C / G_C then point to bf16 tensors.
     const void* F_Wt = nullptr;
     const void* G_Wt = nullptr;
+    int s1_window = 0;              // set by launch_conv_gemm (bf16 ring kernel, 3x3 stride 1): one LDS window per (channel slice, ky)
+                                    //    serves the three horizontal taps (odam_config.h cg.s1)
 };
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 
 // experiments / tests: 0 = never use the bf16-native 256-row kernel, 1 = when the problem is large enough (default),
-// 2 = whenever the layer is eligible (any size).  Also read once from ODAM_CG_BIG.
+// 2 = whenever the layer is eligible (any size).  = odam_config.h cg.ring.
 void set_big_mode(int mode);
 
-// fp32 layers: 0 = v_mfma_f32_32x32x2_f32 on 128x128 tiles, 1 = the same instruction in the 256-row ring kernel,
-// 2 (default) = products on the bf16 matrix instruction through an exact three-way bf16 split of both operands (six
-// MFMAs per 16 k; fp32-class accuracy, different last bits).  Also read once from ODAM_CG_BIG_F32.
+// fp32 layers: 0 = v_mfma_f32_32x32x2_f32 on 128x128 tiles, 2 (default) = products on the bf16 matrix instruction through
+// an exact three-way bf16 split of both operands (six MFMAs per 16 k; fp32-class accuracy, different last bits).
+// = odam_config.h cg.f32.
 void set_f32_mode(int mode);
 int f32_mode();
 // whether launch_conv_gemm would run `a` (with its F_* fields set) on the fused kernel right now
 bool fused_second_ok(const ConvGemmArgs& a);    // the mode fp32 layers run in right now (0 when the ring kernel is switched off altogether)
 
-// bf16: whether launch_conv_gemm would run `a` (F_Wt [+ G_Wt] set) as one bottleneck launch; set_fuse_bf16: 0 off, 1 expand
-// only, 2 (default) with the chained reduce.  Also read once from ODAM_CG_FUSE_BF16.
+// bf16: whether launch_conv_gemm would run `a` (F_Wt [+ G_Wt] set) as one bottleneck launch (odam_config.h: cg.fuse_bf16)
 bool fused_bf16_ok(const ConvGemmArgs& a);
-void set_fuse_bf16(int mode);
 
 // host: exact three-way bf16 split (truncation) of packed fp32 filters w[Cout][Kpad] (Kpad % 16 == 0) into the Wt3 layout
 void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out);

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <type_traits>
 
+#include "odam_config.h"
 #include "odam_err.h"
 
 namespace odam_cg {
@@ -1383,7 +1384,9 @@ constexpr int big_lds_bytes() {
     const int wm = MODE == 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
     const int wn = NTH / 64 / wm;
     const int slab = (NTH / 64) * 32 * (BN / wn) * 4;
-    return ring > slab ? ring : slab;
+    const int s1 = (MODE == 0 && NTH == 512) ? (BN == 256 ? 2 : (BN == 128 ? 3 : 4)) * (384 * 64 + 3 * BN * 64) : 0;   // the 3x3 stride-1 window ring (bf16)
+    const int m = ring > slab ? ring : slab;
+    return m > s1 ? m : s1;
 }
 
 template <int MODE, int BN, int NST, int NTH = 512, int FUSE = 0>     // FUSE: 1 = second layer on the tile (F_*), 2 = and a third (G_*)
@@ -1392,6 +1395,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                       (FUSE >= 5 && FUSE <= 8 && MODE == 0 && NTH == 512 && NST == 4),
                   "fused layers: pre-split filters with 64-column tiles (FUSE 1, 2, 4) or 128-column tiles (FUSE 3); bf16 (FUSE 5 + "
                   "log2(PN / 32), 5 = no chained reduce)");
+    static_assert(MODE == 0 || MODE == 2 || MODE == 3, "bf16 operands, fp32 split, fp32 split with pre-split filters");
     constexpr bool BF16 = MODE == 0;
     // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
     // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
@@ -1497,15 +1501,8 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     }
 
     // One tile's DMAs are LPT instructions per thread; tile_prep computes what is wave-uniform about them, dma_part issues
-    // the p-th.  The main loop spreads the parts between MFMA groups (a DMA instruction costs the issuing wave ~100
-    // cycles of issue; issued in one block right after the barrier those cycles leave the matrix pipe idle on both
-    // waves of the SIMD, which run in lock step).
-    // Measured: spreading changes nothing (fp32 split) or costs 3 % (bf16) -- the PMC split of a wave's cycles is one third
-    // issuing, one third waiting for the matrix pipe it shares with its SIMD partner, one third parked at s_waitcnt /
-    // the barrier, and the DMA issue is not what the parked third waits for.  Kept as a switch.
-#ifndef CG_SPREAD_DMA
-#define CG_SPREAD_DMA 0
-#endif
+    // the p-th (all of them right after the first fragment reads; spreading them between the matrix instructions was
+    // measured at no gain in the split mode and -3 % in bf16, and is gone).
     struct TilePrep { int tap, soff_a, soff_b; };
     auto tile_prep = [&](int kt) {
         int tap, cbase;
@@ -1587,48 +1584,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     auto mma_tile = [&](int st, auto&& issue_next) {
         const char* Ab = lds_c + st * STAGE + a_off;
         const char* Bb = lds_c + st * STAGE + b_off;
-        if constexpr (PRE) {
-            const char* B3 = lds_c + st * STAGE + b3_off;
-            uint4 bh[TN], bm[TN], bl[TN];
-            float4 a0, a1;
-            a0 = *reinterpret_cast<const float4*>(Ab + fq[0]);
-            a1 = *reinterpret_cast<const float4*>(Ab + fq[1]);
-#pragma unroll
-            for (int j = 0; j < TN; j++) {
-                bh[j] = *reinterpret_cast<const uint4*>(B3 + j * 32 * 32);
-                bm[j] = *reinterpret_cast<const uint4*>(B3 + BN * 32 + j * 32 * 32);
-                bl[j] = *reinterpret_cast<const uint4*>(B3 + 2 * BN * 32 + j * 32 * 32);
-            }
-            int part = 0;
-            issue_next(part++);
-            if (!CG_SPREAD_DMA) {
-#pragma unroll
-                for (; part < LPT; part++) issue_next(part);
-            }
-            CG_STAMP_AT(1);
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-                uint4 ah, am, al;
-                split8(a0, a1, ah, am, al);
-                if (i + 1 < TM) {
-                    a0 = *reinterpret_cast<const float4*>(Ab + (i + 1) * 32 * ROWB + fq[0]);
-                    a1 = *reinterpret_cast<const float4*>(Ab + (i + 1) * 32 * ROWB + fq[1]);
-                }
-#define ODAM_MM(x, y) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc[i][j], 0, 0, 0)
-#pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    ODAM_MM(al, bh[j]); ODAM_MM(am, bm[j]); ODAM_MM(ah, bl[j]);
-                    ODAM_MM(am, bh[j]); ODAM_MM(ah, bm[j]);
-                    ODAM_MM(ah, bh[j]);
-                    if (part < LPT) issue_next(part++);      // one DMA under every six matrix instructions
-                }
-#undef ODAM_MM
-                if (i == 0) CG_STAMP_AT(2);
-            }
-#pragma unroll
-            for (; part < LPT; part++) issue_next(part);
-            return;
-        }
+        static_assert(!PRE || NST == 4, "pre-split filters run the register-pipelined loop below");
         if constexpr (MODE == 2) {
             uint4 bh[TN], bm[TN], bl[TN];
             float4 b0[TN], b1[TN], a0, a1;
@@ -1641,10 +1597,8 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
             a1 = *reinterpret_cast<const float4*>(Ab + fq[1]);
             int part = 0;
             issue_next(part++);
-            if (!CG_SPREAD_DMA) {
 #pragma unroll
-                for (; part < LPT; part++) issue_next(part);
-            }
+            for (; part < LPT; part++) issue_next(part);
 #pragma unroll
             for (int j = 0; j < TN; j++) split8(b0[j], b1[j], bh[j], bm[j], bl[j]);
 #pragma unroll
@@ -1661,12 +1615,9 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                     ODAM_MM(al, bh[j]); ODAM_MM(am, bm[j]); ODAM_MM(ah, bl[j]);
                     ODAM_MM(am, bh[j]); ODAM_MM(ah, bm[j]);
                     ODAM_MM(ah, bh[j]);
-                    if (part < LPT) issue_next(part++);
                 }
 #undef ODAM_MM
             }
-#pragma unroll
-            for (; part < LPT; part++) issue_next(part);
             return;
         }
         float4 af[2][TM], bf[2][TN];
@@ -1676,10 +1627,8 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[0]);
         int part = 0;
         issue_next(part++);
-        if (!CG_SPREAD_DMA) {
 #pragma unroll
-            for (; part < LPT; part++) issue_next(part);
-        }
+        for (; part < LPT; part++) issue_next(part);
 #pragma unroll
         for (int i = 0; i < TM; i++) af[1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[1]);
 #pragma unroll
@@ -1690,27 +1639,14 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
             for (int i = 0; i < TM; i++) {
 #pragma unroll
                 for (int j = 0; j < TN; j++) {
-                    if constexpr (BF16) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
-                                                                            __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
-                    } else {   // the chunk's four values are the k slots of four steps (A and B pair up the same way)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].x, bf[q][j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].y, bf[q][j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].z, bf[q][j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q][i].w, bf[q][j].w, acc[i][j], 0, 0, 0);
-                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
+                                                                        __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
                 }
-                if (part < LPT) issue_next(part++);          // one DMA under every row of matrix instructions
             }
-#pragma unroll
-        for (; part < LPT; part++) issue_next(part);
     };
 
     const int nk = a.Kpad / BKE;
-#ifndef CG_PRE_PIPE
-#define CG_PRE_PIPE 1
-#endif
-    if constexpr (PRE && CG_PRE_PIPE && NST == 4) {
+    if constexpr (PRE) {
         // Pre-split filters, software-pipelined across the barrier.  Tile kt is consumed from REGISTERS: its fragments were
         // read from the ring during iteration kt - 1 -- the filter fragments of column tile j into the registers that
         // column's last matrix instruction has just released, the activation fragments into a second set, row tile 0
@@ -1853,94 +1789,135 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         // before the epilogue stages its output there (the compiler does not count DMAs issued from inline assembly)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef ODAM_MM
-#ifndef CG_BF16_PIPE
-#define CG_BF16_PIPE 0   // measured on the same box (R50 / R101 bf16 forwards, B = 32): 13.87 / 20.3 ms with, 13.72 / 20.3 ms without
-#endif
-    } else if constexpr (BF16 && CG_BF16_PIPE && NST == 4) {
-        // bf16 operands, the same pipeline (experiment, off: no gain -- a bf16 k-tile is 16 matrix instructions per wave
-        // against 4 DMA instructions and 12 fragment reads, and the phase stamps show their issue, not the barrier, pacing it): tile kt's fragments sit in registers (af / bf), and every fragment register is
-        // re-read from tile kt + 1's ring slot right after the last matrix instruction that uses it (row fragment (q, i) after
-        // its TN products, column fragment (q, j) in the last row); the DMAs of tile kt + 3 are spread over the 2 TM rows.
-        float4 af[2][TM], bf[2][TN];
-        auto read_af = [&](int s_, int q, int i) { af[q][i] = *reinterpret_cast<const float4*>(lds_c + s_ * STAGE + a_off + i * 32 * ROWB + fq[q]); };
-        auto read_bf = [&](int s_, int q, int j) { bf[q][j] = *reinterpret_cast<const float4*>(lds_c + s_ * STAGE + b_off + j * 32 * ROWB + fq[q]); };
-        auto dma_ok = [&](const TilePrep& tp, int s_, int part, bool ok) {
-            const unsigned sb = lds_base + (unsigned)(s_ * STAGE + wave_u * 16 * ROWB);
-            if (part < A_LD) {
-                const unsigned vo = (ok && ((a_mask[part] >> tp.tap) & 1u)) ? a_voff[part] : OOB_VOFF;
-                lds_dma16(a_rs4, sb + (unsigned)(RPP * part * ROWB), vo, tp.soff_a);
-            } else if (b_wave) {
-                const int i = part - A_LD;
-                lds_dma16(w_rs4, sb + (unsigned)((BM + RPP * i) * ROWB), ok ? w_voff[i < B_LD ? i : 0] : OOB_VOFF, tp.soff_b);
-            }
-        };
-#pragma unroll
-        for (int s0 = 0; s0 < 3; s0++) {
-            const TilePrep tp = tile_prep(s0 < nk ? s0 : 0);
-#pragma unroll
-            for (int part = 0; part < LPT; part++) dma_ok(tp, s0, part, s0 < nk);
-        }
-        if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPT) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * A_LD) : "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int q = 0; q < 2; q++) {
-#pragma unroll
-            for (int i = 0; i < TM; i++) read_af(0, q, i);
-#pragma unroll
-            for (int j = 0; j < TN; j++) read_bf(0, q, j);
-        }
-#if CG_STAMP
-        st_prev = __builtin_readcyclecounter();
-#endif
-        auto body = [&](auto next_c, int sn, const TilePrep& tp, int sf, bool ok) {
-            constexpr bool NEXT = decltype(next_c)::value;
-            constexpr int NR = 2 * TM;      // rows of TN matrix instructions per k-tile
-            int part = 0;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-#pragma unroll
-                for (int i = 0; i < TM; i++) {
-                    const int r = q * TM + i;
-#pragma unroll
-                    for (int j = 0; j < TN; j++) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
-                                                                            __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
-                        if constexpr (NEXT) {
-                            if (i == TM - 1) read_bf(sn, q, j);
-                        }
-                    }
-                    if constexpr (NEXT) {
-                        read_af(sn, q, i);
-#pragma unroll
-                        for (; part < ((r + 1) * LPT + NR - 1) / NR; part++) dma_ok(tp, sf, part, ok);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (r == TM - 1) CG_STAMP_AT(2);
-                }
-            }
-        };
-        int sn = 1, sf = 3;
-        for (int kt = 0; kt + 1 < nk; ++kt) {
-            CG_STAMP_AT(3);
-            if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_LD) : "memory");
-            CG_STAMP_AT(1);
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            CG_STAMP_AT(0);
-            const bool ok = kt + 3 < nk;
-            const TilePrep tp = tile_prep(ok ? kt + 3 : 0);
-            body(std::true_type{}, sn, tp, sf, ok);
-            sn = (sn + 1) & 3; sf = (sf + 1) & 3;
-        }
-        CG_STAMP_AT(3);
-        body(std::false_type{}, 0, TilePrep{0, 0, 0}, 0, false);
-        // the out-of-bounds DMAs issued past the last tile still write (zeros) into the ring: they must have landed
-        // before the epilogue stages its output there (the compiler does not count DMAs issued from inline assembly)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
+    bool s1_done = false;
+    if constexpr (BF16) {
+        // ---- 3x3, stride 1, pad 1 in bf16: one LDS window serves the three horizontal taps ------------------------------------
+        // The bf16 ring is bound by LDS-DMA issue, not by the matrix pipe (layer3's 3x3: 71 us per 256 x 256 tile for 2.3 MB of
+        // DMA, 37 us of matrix instructions).  With stride 1 and H x W preserved, tap (ky, kx) of output pixel m is input pixel
+        // m + (ky - 1) W + (kx - 1) of the flattened [B H W] pixel array -- a pure shift; only validity (image borders) depends on
+        // the pixel.  So a stage holds, for one 32-channel slice and one ky, the 258 consecutive input pixels m0 - 1 + (ky - 1) W
+        // ... (rows 0 .. 257 of a 384-row region: three uniform DMA passes, rows past 263 are requested out of range = no
+        // traffic) and the THREE filter k-tiles kx = 0, 1, 2: the A fragments of tap kx are the same rows read at row offset kx
+        // (the 64-byte-row swizzle stays conflict-free under a shift of 1 or 2 rows), zeroed per lane where the tap falls outside
+        // the image.  A-side DMA bytes and instructions drop 3x.  Stages per ring: 4 / 3 / 2 for BN = 64 / 128 / 256 (144 KB).
+        // The k order differs from the generic loop's (ky outside the two 32-channel halves of a chunk): same products, a
+        // different but fixed summation order.
+        const long tensor_bytes = (long)a.B * a.H * a.W * lda * 2;
+        const bool s1 = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.k_order == 1 && a.Ho == a.H && a.Wo == a.W &&
+                        tensor_bytes < 0x7fffffffL && a.s1_window != 0;
+        if (s1) {
+            constexpr int NSS = BN == 256 ? 2 : (BN == 128 ? 3 : 4);
+            constexpr int AW_BYTES = 384 * ROWB;                  // window region: 3 passes of 128 rows
+            constexpr int STG = AW_BYTES + 3 * BN * ROWB;
+            static_assert(NSS * STG <= 160 * 1024, "S1 ring fits");
+            constexpr int LPT_S = 3 + 3 * B_LD, LPT_S_LO = 3;      // DMA instructions per thread and stage (waves without filter rows: 3)
+            const int n_stage = (a.Cin / 32) * 3;                  // (chunk, ky, half) triples
+            const int npix = a.B * a.H * a.W;
+            // descriptor over the input, rebased one row + one pixel before the tensor so that the wave-uniform window offset is >= 0
+            const unsigned long long pw1 = (unsigned long long)(Ag - (size_t)(a.W + 1) * lda);
+            const u32x4 aw_rs = u32x4{(unsigned)pw1, (unsigned)(pw1 >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+            int prow[3];                                           // window row of this lane in pass p, as a pixel index for ky = 0
+            unsigned aw_voff[3];
+#pragma unroll
+            for (int p_ = 0; p_ < 3; p_++) {
+                const int wr = RPP * p_ + r0;                      // window row 0 .. 383
+                prow[p_] = wr < 264 ? m0 - 1 - a.W + wr : -0x40000000;
+                aw_voff[p_] = (unsigned)(wr * lda * 2 + csrc * 16);
+            }
+            // validity of the nine taps for the rows this lane holds as A fragments
+            unsigned tmask[TM];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                const int m = m0 + wm * (BM / WM) + i * 32 + frow;
+                unsigned mk = 0u;
+                if (m < a.M) {
+                    const int rem = m % hw, y = rem / a.W, x = rem - y * a.W;
+#pragma unroll
+                    for (int t = 0; t < 9; t++) {
+                        const int ky = t / 3, kx = t - 3 * ky;
+                        if ((unsigned)(y + ky - 1) < (unsigned)a.H && (unsigned)(x + kx - 1) < (unsigned)a.W) mk |= 1u << t;
+                    }
+                }
+                tmask[i] = mk;
+            }
+            auto stage_of = [&](int s_, int& chunk, int& ky, int& hf) { chunk = s_ / 6; const int r_ = s_ - 6 * chunk; ky = r_ >> 1; hf = r_ & 1; };
+            auto dma_stage = [&](int s_, int slot) {
+                int chunk, ky, hf;
+                stage_of(s_, chunk, ky, hf);
+                const int cbase = chunk * 64 + hf * 32;
+                const unsigned sbase = lds_base + (unsigned)(slot * STG);
+                const int soff_a = ((m0 + ky * a.W) * lda + cbase) * 2;
+#pragma unroll
+                for (int p_ = 0; p_ < 3; p_++) {
+                    const int pix = prow[p_] + ky * a.W;
+                    const unsigned vo = (pix >= 0 && pix < npix) ? aw_voff[p_] : OOB_VOFF;
+                    lds_dma16(aw_rs, sbase + (unsigned)((wave_u * 16 + RPP * p_) * ROWB), vo, soff_a);
+                }
+                if (b_wave) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        const int kt = ((chunk * 9 + ky * 3 + kx) << 1) + hf;
+#pragma unroll
+                        for (int i = 0; i < B_LD; i++)
+                            lds_dma16(w_rs4, sbase + (unsigned)(AW_BYTES + (kx * BN + wave_u * 16 + RPP * i) * ROWB), w_voff[i], kt * BKE * 2);
+                    }
+                }
+            };
+#pragma unroll
+            for (int s0 = 0; s0 < NSS - 1; s0++)
+                if (s0 < n_stage) dma_stage(s0, s0);
+            int slot = 0, slot_next = NSS - 1;
+            for (int s_ = 0; s_ < n_stage; ++s_) {
+                if (s_ + NSS - 1 <= n_stage) {
+                    if (b_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSS - 2) * LPT_S) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSS - 2) * LPT_S_LO) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                if (s_ + NSS - 1 < n_stage) dma_stage(s_ + NSS - 1, slot_next);
+                int chunk, ky, hf;
+                stage_of(s_, chunk, ky, hf);
+                const char* Sb = lds_c + slot * STG;
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    const int tap = ky * 3 + kx;
+                    const int sw_k = (((frow + kx) >> 2) & 3);
+                    float4 af[2][TM], bf[2][TN];
+#pragma unroll
+                    for (int q = 0; q < 2; q++) {
+#pragma unroll
+                        for (int i = 0; i < TM; i++) {
+                            float4 v = *reinterpret_cast<const float4*>(Sb + (wm * (BM / WM) + i * 32 + frow + kx) * ROWB + (((2 * q + (lane >> 5)) ^ sw_k) << 4));
+                            const unsigned ok = ((tmask[i] >> tap) & 1u) ? 0xffffffffu : 0u;
+                            v.x = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.x) & ok);
+                            v.y = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.y) & ok);
+                            v.z = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.z) & ok);
+                            v.w = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v.w) & ok);
+                            af[q][i] = v;
+                        }
+#pragma unroll
+                        for (int j = 0; j < TN; j++)
+                            bf[q][j] = *reinterpret_cast<const float4*>(Sb + AW_BYTES + (kx * BN + wn * (BN / WN) + j * 32 + frow) * ROWB + fq[q]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; q++)
+#pragma unroll
+                        for (int i = 0; i < TM; i++)
+#pragma unroll
+                            for (int j = 0; j < TN; j++)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
+                                                                                    __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
+                }
+                slot = slot + 1 == NSS ? 0 : slot + 1;
+                slot_next = slot_next + 1 == NSS ? 0 : slot_next + 1;
+            }
+            s1_done = true;
+        }
+    }
+    if (!s1_done) {
 #pragma unroll
     for (int s0 = 0; s0 < NST - 1; s0++)
         if (s0 < nk) load_tile(s0, s0);
@@ -1966,6 +1943,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         mma_tile(st, [&](int part) { if (more) dma_part(tp, st_next, part); });
         st = st + 1 == NST ? 0 : st + 1;
         st_next = st_next + 1 == NST ? 0 : st_next + 1;
+    }
     }
     }
 #if CG_STAMP
@@ -2002,8 +1980,12 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
 }
 
+#define g_s1_window odam_cfg::get(odam_cfg::CG_S1)      // bf16 3x3 stride 1: window main loop (0: the generic tap gather)
+
 template <int MODE, int BN, int NST, int NTH = 512>
-static int launch_big(const ConvGemmArgs& a, hipStream_t stream) {
+static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
+    ConvGemmArgs a = a_in;
+    a.s1_window = (MODE == 0 && NTH == 512) ? g_s1_window : 0;
     constexpr int bytes = big_lds_bytes<MODE, BN, NST, NTH>();
     static const bool attr_ok = [] {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
@@ -2039,7 +2021,9 @@ static int launch_fused_bf16_as(const ConvGemmArgs& a, hipStream_t stream) {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<0, P, 4, 512, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL((conv_gemm_big_kernel<0, P, 4, 512, FUSE>), dim3((a.M + 255) / 256), dim3(512), FUSE_LDS_BYTES, stream, a);
+    ConvGemmArgs b = a;
+    b.s1_window = g_s1_window;
+    hipLaunchKernelGGL((conv_gemm_big_kernel<0, P, 4, 512, FUSE>), dim3((a.M + 255) / 256), dim3(512), FUSE_LDS_BYTES, stream, b);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -2054,8 +2038,8 @@ static int launch_fused_bf16(const ConvGemmArgs& a, hipStream_t stream) {
     return odam_fail(1, "conv_gemm: fused bf16 bottleneck: channel combination not built");
 }
 
-static int g_big_mode = getenv("ODAM_CG_BIG") ? atoi(getenv("ODAM_CG_BIG")) : 1;   // 0 off, 1 auto, 2 whenever eligible
-void set_big_mode(int mode) { g_big_mode = mode; }
+#define g_big_mode odam_cfg::get(odam_cfg::CG_RING)      // 0 off, 1 auto, 2 whenever eligible
+void set_big_mode(int mode) { odam_cfg::set(odam_cfg::CG_RING, mode); }
 
 void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out) {
     const int nk = Kpad / 16;
@@ -2079,11 +2063,12 @@ void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out) {
 
 // the bf16-native kernel takes a layer when its gather is uniform-tap at k-tile 32 and the problem is large enough
 // to give every CU a 256-row tile with a K loop worth pipelining
-// fp32 layers on the 256-row kernel: 0 = no (128x128 tiles on the fp32 matrix instruction), 1 = MODE 1 (measured slower than
-// those tiles), 2 = MODE 2 (products on the bf16 matrix instruction through the exact three-way split; the default: same
-// accuracy class as the fp32 instruction, every parity test unchanged, 1.26x the R50 forward)
-static int g_big_f32 = getenv("ODAM_CG_BIG_F32") ? atoi(getenv("ODAM_CG_BIG_F32")) : 2;
-void set_f32_mode(int mode) { g_big_f32 = mode; }
+// fp32 layers on the 256-row kernel: 0 = no (128x128 tiles on the fp32 matrix instruction), 2 = products on the bf16 matrix
+// instruction through the exact three-way split (the default: same accuracy class as the fp32 instruction, every parity test
+// unchanged, 1.26x the R50 forward).  (1, the fp32 instruction inside the ring schedule, was measured slower than the 128x128
+// tiles and is gone.)
+#define g_big_f32 odam_cfg::get(odam_cfg::CG_F32)
+void set_f32_mode(int mode) { odam_cfg::set(odam_cfg::CG_F32, mode == 1 ? 0 : mode); }
 int f32_mode() { return g_big_mode ? g_big_f32 : 0; }
 static bool big_eligible(const ConvGemmArgs& a, int bn) {
     const bool bf = a.dtype == ODAM_CG_BF16;
@@ -2107,8 +2092,7 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
     // first image a tile touches (a tile spans at most BM / (Ho*Wo) + 2 images)
     const long esz = bf ? 2 : 4, lda = a.lda > 0 ? a.lda : a.Cin;
     const long span = ((long)BM / ((long)a.Ho * a.Wo) + 2) * a.H * a.W * lda + (long)(a.pad * a.W + a.pad) * lda + a.Cin;
-    static const bool no_ut = getenv("ODAM_CG_NO_UT") != nullptr;
-    const bool ut = !no_ut && a.Cin % (bf ? 64 : 32) == 0 && a.KH * a.KW <= 32 && span * esz < 0x7fffffffL &&
+    const bool ut = odam_cfg::get(odam_cfg::CG_UT) != 0 && a.Cin % (bf ? 64 : 32) == 0 && a.KH * a.KW <= 32 && span * esz < 0x7fffffffL &&
                     (long)a.Cout * a.Kpad * esz < 0x7fffffffL;
     const dim3 g(tiles), b(64 * WM * WN);
     if (bf) {
@@ -2124,21 +2108,19 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
 
 // the fused kernel applies: fp32 split mode with pre-split filters on both layers, 64 -> 256 channels, a full device
 bool fused_second_ok(const ConvGemmArgs& a) {
-    static const bool on = !(getenv("ODAM_CG_FUSE") != nullptr && atoi(getenv("ODAM_CG_FUSE")) == 0);
-    if (!on || !g_big_mode || g_big_f32 != 2 || a.dtype != ODAM_CG_F32) return false;
+    const int fuse = odam_cfg::get(odam_cfg::CG_FUSE);
+    if (!fuse || !g_big_mode || g_big_f32 != 2 || a.dtype != ODAM_CG_F32) return false;
     if (!a.F_Wt3 || !a.F_C || !a.Wt3 || a.Kpad % 16 != 0) return false;
     const bool l1 = a.Cout == 64 && a.F_ldc == 256, l2 = a.Cout == 128 && a.F_ldc == 512 && !a.G_Wt3;     // the two shapes built
     if (!l1 && !l2) return false;
     if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL) return false;
-    static const bool chain_on = !(getenv("ODAM_CG_FUSE") != nullptr && atoi(getenv("ODAM_CG_FUSE")) == 1);   // 1: second layer only
-    if (a.G_Wt3 && (!chain_on || !a.G_C || (a.G_N != 64 && a.G_N != 128))) return false;
+    if (a.G_Wt3 && (fuse < 2 || !a.G_C || (a.G_N != 64 && a.G_N != 128))) return false;      // fuse 1: second layer only
     return big_eligible(a, a.Cout);
 }
 
 // bf16: the 3x3 + expand (+ next reduce) kernel applies -- ring kernel eligible for the 3x3, the channel combination built,
 // residual / output tensors inside 31-bit byte offsets
-static int g_fuse_bf16 = getenv("ODAM_CG_FUSE_BF16") ? atoi(getenv("ODAM_CG_FUSE_BF16")) : 2;   // 0 off, 1 expand only, 2 with the chained reduce
-void set_fuse_bf16(int mode) { g_fuse_bf16 = mode; }
+#define g_fuse_bf16 odam_cfg::get(odam_cfg::CG_FUSE_BF16)      // 0 off, 1 expand only, 2 with the chained reduce
 bool fused_bf16_ok(const ConvGemmArgs& a) {
     if (!g_fuse_bf16 || !g_big_mode || a.dtype != ODAM_CG_BF16 || !a.F_Wt || !a.F_C) return false;
     if (a.Cout != 64 && a.Cout != 128 && a.Cout != 256) return false;
@@ -2170,31 +2152,25 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (g_big_mode) {
         const bool bf = a.dtype == ODAM_CG_BF16;
         const bool x3 = !bf && g_big_f32 == 2;
-        static const int two_wg = getenv("ODAM_CG_TWO_WG") ? atoi(getenv("ODAM_CG_TWO_WG")) : 0;   // experiment: 1 = fp32 split, 2 = bf16 too
-        if (a.Cout >= 128 && ((x3 && two_wg == 1) || (bf && two_wg == 2)) && big_eligible(a, 128))
-            return bf ? launch_big<0, 128, 3, 256>(a, stream) : launch_big<2, 128, 3, 256>(a, stream);
-        if (x3 && two_wg == 3 && (a.Cout % 256 == 0 || a.Cout >= 384) && big_eligible(a, 256))   // one wave per SIMD, 128 x 128 each
-            return launch_big<2, 256, 4, 256>(a, stream);
-        static const bool use_pre = getenv("ODAM_CG_NO_PRESPLIT") == nullptr;
-        const bool pre = x3 && a.Wt3 != nullptr && use_pre && a.Kpad % 16 == 0 && (long)a.Cout * a.Kpad * 6 < 0x7fffffffL;
+        const bool pre = x3 && a.Wt3 != nullptr && odam_cfg::get(odam_cfg::CG_PRESPLIT) != 0 && a.Kpad % 16 == 0 && (long)a.Cout * a.Kpad * 6 < 0x7fffffffL;
         if (a.Cout % 256 == 0 || a.Cout >= 384) {
             if (big_eligible(a, 256))
-                return bf ? launch_big<0, 256, 4>(a, stream)
-                          : (pre ? launch_big<3, 256, 4>(a, stream) : (x3 ? launch_big<2, 256, 4>(a, stream) : launch_big<1, 256, 4>(a, stream)));
+                return bf ? launch_big<0, 256, 4>(a, stream) : (pre ? launch_big<3, 256, 4>(a, stream) : launch_big<2, 256, 4>(a, stream));
 #ifndef CG_NO_BN128_FALLBACK
             // too few 256-wide tiles to fill the device (the encoder's N = 256 layers at M = 27,200: 107) but enough 128-wide
             // ones: the ring kernel on 256 x 128 tiles instead of the 128 x 128 tiles of the fp32 matrix instruction
             if (pre && big_eligible(a, 128)) return launch_big<3, 128, 4>(a, stream);
 #endif
         } else if (a.Cout > 64 && (g_big_mode >= 2 || x3) && big_eligible(a, 128)) {   // bf16 / fp32: measured slower than the 128x128 tiles (tests only)
-            return bf ? launch_big<0, 128, 4>(a, stream)
-                      : (pre ? launch_big<3, 128, 4>(a, stream) : (x3 ? launch_big<2, 128, 4>(a, stream) : launch_big<1, 128, 4>(a, stream)));
+            return bf ? launch_big<0, 128, 4>(a, stream) : (pre ? launch_big<3, 128, 4>(a, stream) : launch_big<2, 128, 4>(a, stream));
         } else if (x3 && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
             return pre ? launch_big<3, 64, 4>(a, stream) : launch_big<2, 64, 4>(a, stream);
+        } else if (bf && (g_big_mode >= 2 || (a.lda > 0 && a.lda < a.Cin)) && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
+            return launch_big<0, 64, 4>(a, stream);     // conv1 as a row convolution (pixel stride < row length); tests: layer1's 3x3 alone
         }
     }
-    static const int variant = getenv("ODAM_CG_VARIANT") ? atoi(getenv("ODAM_CG_VARIANT")) : 7;  // 8-wave tiles (+2-3 %)
-    static const int force = getenv("ODAM_CG_FORCE") ? atoi(getenv("ODAM_CG_FORCE")) : 0;   // experiments: pin one tile shape
+    const int variant = odam_cfg::get(odam_cfg::CG_TILES);      // 8-wave tiles (+2-3 %)
+    const int force = odam_cfg::get(odam_cfg::CG_FORCE);        // tests: pin one tile shape
     if (force == 1) return launch_cfg<128, 64, 4, 2>(a, stream);
     if (force == 2) return launch_cfg<64, 64, 2, 2, 4>(a, stream);
     if (force == 3) return launch_cfg<128, 128, 2, 2>(a, stream);

@@ -27,17 +27,12 @@ int launch_add_pos(const void* x, const float* pos, int L, void* out, int M, int
 
 // fp32 [B,3,H,W] -> [B,H,W,4] fp32 (4th channel zero) or [B,H,W,8] bf16 (one 16-byte chunk per pixel)
 int launch_nchw_to_nhwc4(const float* in, void* out, int B, int H, int W, int dtype, hipStream_t stream);
-// fp32 only: NHWC4 with a zero frame of 3 rows / 3 + 5 columns, [B][H + 6][W + 8][4] (the stem as a 7x1 convolution over 8-pixel rows)
-int launch_nchw_to_nhwc4_framed(const float* in, float* out, int B, int H, int W, hipStream_t stream);
+// NHWC4 (fp32 or bf16) with a zero frame of 3 rows / 3 + 5 columns, [B][H + 6][W + 8][4] (the stem as a 7x1 convolution over 8-pixel rows)
+int launch_nchw_to_nhwc4_framed(const float* in, void* out, int B, int H, int W, int dtype, hipStream_t stream);
 
 // NHWC max-pool 3x3 stride 2 pad 1 (torchvision ResNet stem)
 int launch_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, int Ho, int Wo, int dtype,
                         hipStream_t stream);
-
-// Fused stem (conv 7x7/2 + FrozenBN + ReLU + max-pool 3x3/2): img fp32 NCHW [B,3,H,W], w148 [64][148] fp32 with
-// k = (c*7 + ky)*7 + kx (147, one zero pad), scale / bias [64] -> out NHWC [B,H2,W2,64] in the activation type
-int launch_stem_pool(const float* img, const float* w148, const float* scale, const float* bias, void* out, int B, int H,
-                     int W, int dtype, hipStream_t stream);
 
 // NHWC [B,H,W,C] -> NCHW [B,C,H,W]  (only for exposing intermediate features to tests)
 int launch_nhwc_to_nchw(const void* in, float* out, int B, int H, int W, int C, int dtype, hipStream_t stream);

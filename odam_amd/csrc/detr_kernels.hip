@@ -3,6 +3,7 @@
 
 #include <cstdlib>
 
+#include "odam_config.h"
 #include "odam_err.h"
 
 namespace odam_dk {
@@ -520,7 +521,7 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
     if (Lq <= 0 || Lk <= 0 || B <= 0) return 0;
     dim3 grid((Lq + 127) / 128, H, B);
     const float scale = (float)0.1767766952966369;   // sqrt(1/32) as torch computes it in float64, then float32
-    static const bool bf16_mfma = getenv("ODAM_ATT_FP32") == nullptr;   // experiments: keep bf16 mode on the fp32 kernel
+    const bool bf16_mfma = odam_cfg::get(odam_cfg::ATT_BF16_MFMA) != 0;   // 0: keep bf16 mode on the fp32-instruction kernel
     if (dtype == 1 && bf16_mfma && (ldq % 8) == 0 && (ldk % 8) == 0 && (ldv % 8) == 0 && (ldo % 4) == 0) {
         hipLaunchKernelGGL(attention_bf16_kernel, grid, dim3(256), 0, stream, (const bf16_t*)Q, ldq, (const bf16_t*)K, ldk,
                            (const bf16_t*)V, ldv, (bf16_t*)O, ldo, Lq, Lk, scale * 1.44269504088896341f, key_mask);
@@ -528,7 +529,7 @@ int launch_attention(const void* Q, int ldq, const void* K, int ldk, const void*
         return 0;
     }
     // fp32: products through the exact three-way bf16 split (ODAM_ATT_X3=0 keeps the fp32 matrix instruction)
-    static const bool x3 = !(getenv("ODAM_ATT_X3") != nullptr && atoi(getenv("ODAM_ATT_X3")) == 0);
+    const bool x3 = odam_cfg::get(odam_cfg::ATT_X3) != 0;
     if (dtype == 0 && x3 && (ldq % 4) == 0 && (ldk % 4) == 0 && (ldv % 4) == 0 && (ldo % 4) == 0) {
         hipLaunchKernelGGL(attention_x3_kernel, grid, dim3(256), 0, stream, (const float*)Q, ldq, (const float*)K, ldk,
                            (const float*)V, ldv, (float*)O, ldo, Lq, Lk, scale, key_mask);
@@ -647,7 +648,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_kernel(const float* __restr
 
 // fp32 NCHW -> NHWC4 with a zero frame: out [B][H + 6][W + 8][4], the image at rows 3 .. H + 2, columns 3 .. W + 2.
 // What the stem-as-rows convolution reads (detr_model.hip, stem_rows): 8 consecutive pixels = 32 floats per filter row.
-__global__ __launch_bounds__(256) void nchw_to_nhwc4_framed_kernel(const float* __restrict__ in, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_framed_kernel(const float* __restrict__ in, T* __restrict__ out,
                                                                    int H, int W, size_t total) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // pixel index over B*(H+6)*(W+8)
     if (i >= total) return;
@@ -666,10 +668,12 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc4_framed_kernel(const float* 
     st4(out + i * 4, v);
 }
 
-int launch_nchw_to_nhwc4_framed(const float* in, float* out, int B, int H, int W, hipStream_t stream) {
+int launch_nchw_to_nhwc4_framed(const float* in, void* out, int B, int H, int W, int dtype, hipStream_t stream) {
     const size_t total = (size_t)B * (H + 6) * (W + 8);
     if (!total) return 0;
-    hipLaunchKernelGGL(nchw_to_nhwc4_framed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, out, H, W, total);
+#define ODAM_K(T, ...) hipLaunchKernelGGL(nchw_to_nhwc4_framed_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, in, (T*)out, H, W, total)
+    ODAM_DISPATCH(dtype, ODAM_K, 0);
+#undef ODAM_K
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -721,166 +725,6 @@ int launch_maxpool3x3s2(const void* in, void* out, int B, int H, int W, int C, i
     return 0;
 }
 
-// =================================================================================================
-// Fused stem: conv 7x7 / 2 (3 -> 64) + FrozenBN + ReLU + max-pool 3x3 / 2, reading the NCHW fp32 image as the
-// transform produces it and writing the pooled NHWC map (torchvision ResNet conv1 / bn1 / relu / maxpool through
-// backbone.py:69-94).  Replaces nchw_to_nhwc4 -> conv_gemm (K = 147 padded to 196 -> 224) -> maxpool: the 64 x 400 x
-// 533 stem output (1.75 GB per 32 frames in fp32) never goes to HBM and no matrix work is spent on padding.
-//
-// Persistent workgroups (one per CU, four waves) walk over tiles of 8 x 14 pooled pixels = 17 x 29 conv pixels = 16
-// M-tiles of 32 conv pixels (4 per wave).  The tile's input window (3 x 39 x 63 floats) sits in LDS; the filters
-// (64 x 148 fp32: K = (c, ky, kx), 147 padded to 148) live in registers for the whole launch: lane (n = lane & 31,
-// half) holds W[n + 32 j][2 s + half], the B operand of step s, so the main loop is per step ONE ds_read_b32 (the A
-// operand: pixel m's input value for k = 2 s + half) and two v_mfma_f32_32x32x2_f32.  The A address is
-// base(m) + off(k): off is a compile-time constant per step; the two lane halves differ by off(2 s + 1) - off(2 s),
-// which takes only three values (next column / next row / next channel), so three per-lane base registers and an
-// immediate offset address every read without any vector arithmetic.  Results go through BN + ReLU into an LDS map
-// of the 17 x 29 conv pixels (invalid pixels as 0: exact under the max because every window holds a valid value
-// >= 0 after ReLU), the pool phase reads 3 x 3 neighbourhoods as float4 over channels and stores 16 bytes per lane.
-// =================================================================================================
-constexpr int ST_PH = 8, ST_PW = 14;                  // pooled tile
-constexpr int ST_CH = 2 * ST_PH + 1, ST_CW = 2 * ST_PW + 1;   // conv tile 17 x 29
-constexpr int ST_IH = 2 * ST_CH + 5, ST_IW = 2 * ST_CW + 5;   // input window 39 x 63
-constexpr int ST_MT = (ST_CH * ST_CW + 31) / 32;      // 16 M-tiles (493 -> 512 pixels)
-constexpr int ST_K = 148, ST_NS = ST_K / 2;           // 74 steps of two k
-static_assert(ST_MT == 16, "four M-tiles per wave");
-
-__host__ __device__ constexpr int st_koff(int k) {    // float offset of filter tap k = (c, ky, kx) inside the input window
-    return k >= 147 ? 0 : (k / 49) * (ST_IH * ST_IW) + ((k % 49) / 7) * ST_IW + (k % 7);
-}
-
-// the 74 A-operand values of one M-tile for this lane: value S is pixel m's input at tap k = 2 S + half
-template <int S>
-__device__ __forceinline__ void stem_load_a(float (&av)[ST_NS], const float* in_lds, int b0, int b1, int b2, int b3) {
-    if constexpr (S < ST_NS) {
-        constexpr int e = st_koff(2 * S), d = st_koff(2 * S + 1) - e;
-        // half 0 reads off(2 S), half 1 off(2 S + 1) = off(2 S) + d with d = 1, IW - 6 or IH IW - 6 IW - 6; for the zero
-        // pad (k = 147) half 1 re-reads half 0's value (finite; its filter value is 0)
-        constexpr int D1 = 1, D2 = ST_IW - 6, D3 = ST_IH * ST_IW - 6 * ST_IW - 6;
-        static_assert(2 * S + 1 >= 147 || d == D1 || d == D2 || d == D3, "three kinds of neighbours");
-        const int base = (2 * S + 1 >= 147) ? b0 : (d == D1 ? b1 : (d == D2 ? b2 : b3));
-        av[S] = in_lds[base + e];
-        stem_load_a<S + 1>(av, in_lds, b0, b1, b2, b3);
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void stem_pool_kernel(const float* __restrict__ img, const float* __restrict__ w148,
-                                                        const float* __restrict__ scale, const float* __restrict__ bias,
-                                                        T* __restrict__ out, int B, int H, int W, int H1, int W1, int H2,
-                                                        int W2, int tiles_y, int tiles_x) {
-    extern __shared__ __align__(16) float sm[];
-    float* in_lds = sm;                                     // [3][ST_IH][ST_IW]
-    float* conv = sm + 3 * ST_IH * ST_IW + 1;               // [ST_CH * ST_CW][64], 16-byte aligned (7371 + 1 floats)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, n = lane & 31;
-    float w0[ST_NS], w1[ST_NS];
-#pragma unroll
-    for (int s = 0; s < ST_NS; s++) {
-        w0[s] = w148[n * ST_K + 2 * s + half];
-        w1[s] = w148[(n + 32) * ST_K + 2 * s + half];
-    }
-    const float sc0 = scale[n], sc1 = scale[n + 32], bi0 = bias[n], bi1 = bias[n + 32];
-    const int n_tiles = B * tiles_y * tiles_x;
-    for (int t = blockIdx.x; t < n_tiles; t += gridDim.x) {
-        const int b = t / (tiles_y * tiles_x), ty = (t / tiles_x) % tiles_y, tx = t % tiles_x;
-        const int py0 = ty * ST_PH, px0 = tx * ST_PW;
-        const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;     // first conv pixel of the tile
-        const int iy0 = 2 * cy0 - 3, ix0 = 2 * cx0 - 3;     // first input pixel of the window
-        __syncthreads();                                     // the previous tile's pool phase is done with `conv`
-        const float* ib = img + (size_t)b * 3 * H * W;
-        for (int i = tid; i < 3 * ST_IH * ST_IW; i += 256) {
-            const int c = i / (ST_IH * ST_IW), r = (i / ST_IW) % ST_IH, q = i % ST_IW;
-            const int y = iy0 + r, x = ix0 + q;
-            in_lds[i] = ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) ? ib[((size_t)c * H + y) * W + x] : 0.0f;
-        }
-        __syncthreads();
-        // A values of an M-tile are fetched one tile ahead (74 registers each): with one wave per SIMD nothing else
-        // hides the LDS latency, and a read in front of every four MFMAs stalled the matrix pipe a third of the time
-        constexpr int D2 = ST_IW - 6, D3 = ST_IH * ST_IW - 6 * ST_IW - 6;
-        auto bases = [&](int mt, int& b0, int& b1, int& b2, int& b3) {
-            const int m = (wave * (ST_MT / 4) + mt) * 32 + n;                 // this lane's conv pixel of the M-tile
-            const int mm = m < ST_CH * ST_CW ? m : 0;
-            const int cy = mm / ST_CW, cx = mm - cy * ST_CW;
-            b0 = (2 * cy) * ST_IW + 2 * cx;
-            b1 = b0 + half; b2 = b0 + half * D2; b3 = b0 + half * D3;
-        };
-        float av[2][ST_NS];
-        {
-            int b0, b1, b2, b3;
-            bases(0, b0, b1, b2, b3);
-            stem_load_a<0>(av[0], in_lds, b0, b1, b2, b3);
-        }
-#pragma unroll
-        for (int mt = 0; mt < ST_MT / 4; mt++) {
-            if (mt + 1 < ST_MT / 4) {
-                int b0, b1, b2, b3;
-                bases(mt + 1, b0, b1, b2, b3);
-                stem_load_a<0>(av[(mt + 1) & 1], in_lds, b0, b1, b2, b3);
-            }
-            floatx16 a0, a1;
-#pragma unroll
-            for (int r = 0; r < 16; r++) { a0[r] = 0.0f; a1[r] = 0.0f; }
-#pragma unroll
-            for (int st = 0; st < ST_NS; st++) {
-                a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt & 1][st], w0[st], a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt & 1][st], w1[st], a1, 0, 0, 0);
-            }
-            // accumulator register r of lane (channel n, half) is conv pixel acc_row(r, half) of this M-tile
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int pm = (wave * (ST_MT / 4) + mt) * 32 + acc_row(r, half);
-                if (pm < ST_CH * ST_CW) {
-                    const int y = cy0 + pm / ST_CW, x = cx0 + pm % ST_CW;
-                    const bool ok = (unsigned)y < (unsigned)H1 && (unsigned)x < (unsigned)W1;
-                    const float v0 = a0[r] * sc0 + bi0, v1 = a1[r] * sc1 + bi1;
-                    conv[pm * 64 + n] = ok ? fmaxf(v0, 0.0f) : 0.0f;
-                    conv[pm * 64 + 32 + n] = ok ? fmaxf(v1, 0.0f) : 0.0f;
-                }
-            }
-        }
-        __syncthreads();
-        for (int i = tid; i < ST_PH * ST_PW * 16; i += 256) {             // (pooled pixel, 4-channel group)
-            const int c4 = i & 15, pp = i >> 4, py = pp / ST_PW, px = pp - py * ST_PW;
-            const int oy = py0 + py, ox = px0 + px;
-            if (oy >= H2 || ox >= W2) continue;
-            float4 m4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-                for (int dx = 0; dx < 3; dx++) {
-                    const float4 v = *reinterpret_cast<const float4*>(&conv[((2 * py + dy) * ST_CW + 2 * px + dx) * 64 + c4 * 4]);
-                    m4.x = fmaxf(m4.x, v.x); m4.y = fmaxf(m4.y, v.y); m4.z = fmaxf(m4.z, v.z); m4.w = fmaxf(m4.w, v.w);
-                }
-            st4(out + (((size_t)b * H2 + oy) * W2 + ox) * 64 + c4 * 4, m4);
-        }
-    }
-}
-
-int launch_stem_pool(const float* img, const float* w148, const float* scale, const float* bias, void* out, int B, int H,
-                     int W, int dtype, hipStream_t stream) {
-    const int H1 = (H + 6 - 7) / 2 + 1, W1 = (W + 6 - 7) / 2 + 1, H2 = (H1 + 2 - 3) / 2 + 1, W2 = (W1 + 2 - 3) / 2 + 1;
-    const int tiles_y = (H2 + ST_PH - 1) / ST_PH, tiles_x = (W2 + ST_PW - 1) / ST_PW;
-    const size_t lds = (size_t)(3 * ST_IH * ST_IW + 1 + ST_CH * ST_CW * 64) * sizeof(float);
-    static_assert((3 * ST_IH * ST_IW + 1) % 4 == 0, "the conv map starts 16-byte aligned");
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ODAM_HIP(hipGetDevice(&dev));
-        ODAM_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        ODAM_HIP(hipFuncSetAttribute((const void*)stem_pool_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ODAM_HIP(hipFuncSetAttribute((const void*)stem_pool_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    }
-    const int n_tiles = B * tiles_y * tiles_x;
-    const int grid = n_tiles < n_cu ? n_tiles : n_cu;
-    if (dtype == 1)
-        hipLaunchKernelGGL(stem_pool_kernel<bf16_t>, dim3(grid), dim3(256), lds, stream, img, w148, scale, bias, (bf16_t*)out, B, H, W, H1, W1, H2, W2, tiles_y, tiles_x);
-    else
-        hipLaunchKernelGGL(stem_pool_kernel<float>, dim3(grid), dim3(256), lds, stream, img, w148, scale, bias, (float*)out, B, H, W, H1, W1, H2, W2, tiles_y, tiles_x);
-    ODAM_HIP(hipGetLastError());
-    return 0;
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ in, float* __restrict__ out,

@@ -18,6 +18,7 @@
 #include "../../include/odam_detr.h"
 #include "conv_gemm.h"
 #include "detr_kernels.h"
+#include "odam_config.h"
 #include "odam_err.h"
 
 using odam_cg::ConvGemmArgs;
@@ -70,8 +71,6 @@ struct odam_detr {
     Conv class_embed;
     Conv mlp[5][3];  // bbox, offset, angle, size, depth
     Conv stem_rows;              // fp32: conv1 as a 7x1 convolution over 32-float rows of the framed NHWC4 image (see forward_impl)
-    float* stem_w148 = nullptr;  // fused stem: conv1 filters [64][148], k = (c*7 + ky)*7 + kx (odam_dk::launch_stem_pool)
-    bool stem_fused = true;
     float* pos = nullptr;        // [L, 256]
     float* query_pos = nullptr;  // [Q, 256]
 
@@ -321,12 +320,12 @@ int stem_rows_t(odam_detr* m, int B, hipStream_t st) {
     const Conv& c = m->stem_rows;
     const odam_detr_cfg& g = m->cfg;
     ConvGemmArgs a{};
-    a.dtype = 0; a.out_f32 = 0;
+    a.dtype = m->dt; a.out_f32 = 0;
     a.A = m->x4; a.Wt = c.w; a.Wt3 = c.w3; a.scale = c.scale; a.bias = c.bias; a.res = nullptr; a.C = m->stem_out;
     a.B = B; a.H = g.img_h + 6; a.W = g.img_w + 8; a.Cin = 32; a.log2Cin = 5; a.lda = 4;
     a.Ho = m->H1; a.Wo = m->W1;
     a.Cout = c.Cout; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0; a.Kpad = c.Kpad;
-    a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = c.Cout; a.k_order = 1;
+    a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = c.Cout; a.k_order = c.k_order;
     if (!m->profile) return odam_cg::launch_conv_gemm(a, st);
     if (m->ev_used + 2 > m->ev.size()) {
         for (int k = 0; k < 2; k++) {
@@ -430,32 +429,24 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
         NEED(w, bb + "conv1.weight");
         RC(pack_conv(m, m->stem, *w, 2, 3));
         RC(fold_bn(m, m->stem, bb + "bn1"));
-        if (w->shape.size() == 4 && w->shape[0] == 64 && w->shape[1] == 3 && w->shape[2] == 7 && w->shape[3] == 7) {
-            std::vector<float> p148((size_t)64 * 148, 0.0f);
-            for (int o = 0; o < 64; o++)
-                for (int k = 0; k < 147; k++) p148[(size_t)o * 148 + k] = w->data[(size_t)o * 147 + k];   // [o][c][ky][kx] is already (c, ky, kx)-major
-            RC(m->upload(&m->stem_w148, p148));
-        }
-        // Experiment, off unless ODAM_STEM_FUSED=1: measured at B = 32, 800x1066 the fused kernel ties the three-kernel stem in
-        // fp32 (36.5 vs 36.4 ms per forward) and loses 1 ms in bf16 -- one 156 KB workgroup per CU runs its window load,
-        // matrix and pooling phases one after another, while the separate kernels overlap across workgroups.
-        if (!m->dt) {
-            // conv1 as KH = 7, KW = 1, Cin = 32: filter row ky of output channel o is the 28 floats w[o][c][ky][kx] at
-            // position 4 kx + c (what 7 consecutive NHWC4 pixels hold), then 4 zeros; K = 7 * 32 = 224
+        {
+            // conv1 as KH = 7, KW = 1, Cin = 32: filter row ky of output channel o is the 28 values w[o][c][ky][kx] at
+            // position 4 kx + c (what 7 consecutive NHWC4 pixels hold), then 4 zeros; K = 7 * 32 = 224.  fp32: k_order 1 (one
+            // 32-channel chunk); bf16: the k-tile is 32 elements = one filter row, tap-major (k_order 0)
             const int Cout = (int)w->shape[0];
-            std::vector<float> pr((size_t)Cout * 224, 0.0f);
+            const int Kp = m->dt ? 256 : 224;          // bf16: the dispatcher's k-tile is 64 elements (an eighth, all-zero filter row)
+            std::vector<float> pr((size_t)Cout * Kp, 0.0f);
             for (int o = 0; o < Cout; o++)
                 for (int ci = 0; ci < 3; ci++)
                     for (int ky = 0; ky < 7; ky++)
                         for (int kx = 0; kx < 7; kx++)
-                            pr[(size_t)o * 224 + ky * 32 + kx * 4 + ci] = w->data[(((size_t)o * 3 + ci) * 7 + ky) * 7 + kx];
+                            pr[(size_t)o * Kp + ky * 32 + kx * 4 + ci] = w->data[(((size_t)o * 3 + ci) * 7 + ky) * 7 + kx];
             Conv& r = m->stem_rows;
-            r.Cin = 32; r.Cout = Cout; r.KH = 7; r.KW = 1; r.stride = 2; r.pad = 0; r.Kpad = 224; r.k_order = 1;
-            RC(m->upload_w3(&r.w3, pr, Cout, 224));
+            r.Cin = 32; r.Cout = Cout; r.KH = 7; r.KW = 1; r.stride = 2; r.pad = 0; r.Kpad = Kp; r.k_order = m->dt ? 0 : 1;
+            RC(m->upload_w3(&r.w3, pr, Cout, Kp));
             RC(m->upload_w(&r.w, pr));
             r.scale = m->stem.scale; r.bias = m->stem.bias;
         }
-        m->stem_fused = m->stem_w148 != nullptr && getenv("ODAM_STEM_FUSED") != nullptr && atoi(getenv("ODAM_STEM_FUSED")) != 0;
     }
     for (int l = 0; l < 4; l++) {
         for (int i = 0; i < c.resnet_blocks[l]; i++) {
@@ -583,18 +574,18 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
     auto off = [&](char* p, size_t n) { return p + n * es; };   // element offset in the activation type
 
     // ---- backbone (backbone.py:59-94) ----------------------------------------------------------
-    if (m->stem_fused) {   // conv1 + bn1 + relu + maxpool in one kernel, straight from the NCHW image
-        RC(odam_dk::launch_stem_pool(img, m->stem_w148, m->stem.scale, m->stem.bias, m->bufA, B, c.img_h, c.img_w, dt, st));
-    } else {
+    {
         // fp32, split contraction mode, enough rows to fill the device: conv1 on the ring kernel.  With Cin = 4 the 7x7
         // filter cannot use its gather (a k-tile must sit inside one tap), but seven consecutive NHWC4 pixels ARE 28
         // contiguous floats: over an image framed with zeros (3 rows above / below, 3 + 5 columns) conv1 is a 7x1
         // convolution with "Cin" = 32 floats per row, pixel stride lda = 4, no padding, K = 224 instead of 147 + pad --
         // a third of the products are zeros, on a path that is 2-3x faster than the 128x64 tiles of the fp32 instruction.
-        static const bool rows_ok = !(getenv("ODAM_STEM_ROWS") != nullptr && atoi(getenv("ODAM_STEM_ROWS")) == 0);
+        const bool rows_ok = odam_cfg::get(odam_cfg::STEM_ROWS) != 0;
         const long Mst = (long)B * m->H1 * m->W1;
-        if (!dt && rows_ok && m->stem_rows.w3 && odam_cg::f32_mode() == 2 && Mst >= 192L * 256) {
-            RC(odam_dk::launch_nchw_to_nhwc4_framed(img, (float*)m->x4, B, c.img_h, c.img_w, st));
+        const bool rows_mode = dt ? (m->stem_rows.w != nullptr && odam_cfg::get(odam_cfg::CG_RING) != 0)
+                                  : (m->stem_rows.w3 != nullptr && odam_cg::f32_mode() == 2);
+        if (rows_ok && rows_mode && Mst >= 192L * 256) {
+            RC(odam_dk::launch_nchw_to_nhwc4_framed(img, m->x4, B, c.img_h, c.img_w, dt, st));
             RC(stem_rows_t(m, B, st));
         } else {
             RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, dt, st));
@@ -772,14 +763,14 @@ extern "C" int odam_op_bottleneck_bf16(const void* x, const void* w2, const floa
 // experiment switch of the bf16-native contraction kernel (conv_gemm.h set_big_mode): 0 off, 1 auto, 2 whenever eligible
 extern "C" int odam_op_conv_bf16_mode(int mode) {
     if (mode < 0 || mode > 2) return odam_fail(1, "odam_op_conv_bf16_mode: mode must be 0, 1 or 2");
-    odam_cg::set_big_mode(mode);
+    odam_cg::set_big_mode(mode);      // = odam_config_set("cg.ring", mode)
     return 0;
 }
 
 // fp32 contraction mode of the 256-row kernel (conv_gemm.h set_f32_mode): 0 fp32 matrix instruction on 128x128 tiles,
 // 1 the same instruction in the ring kernel, 2 bf16 matrix instruction through the exact three-way split
 extern "C" int odam_op_conv_f32_mode(int mode) {
-    if (mode < 0 || mode > 2) return odam_fail(1, "odam_op_conv_f32_mode: mode must be 0, 1 or 2");
+    if (mode != 0 && mode != 2) return odam_fail(1, "odam_op_conv_f32_mode: mode must be 0 or 2");
     odam_cg::set_f32_mode(mode);
     return 0;
 }

@@ -1,0 +1,29 @@
+// odam_config.h -- the library's process-wide switches in ONE table (include/odam_config.h is the C ABI over it).
+// The library never reads the environment for them: a switch that changes which kernel runs -- and with it the order of an
+// fp32 summation -- is set through odam_config_set by the host program, which can log what it set (bench.py prints the
+// table in its JSON line).  Defaults below are what every measurement in DESIGN.md was taken with.
+#pragma once
+
+namespace odam_cfg {
+enum Key {
+    CG_RING,        // 256-row LDS-DMA ring kernel: 0 never, 1 for layers that fill the device (default), 2 whenever eligible
+    CG_F32,         // fp32 layers on the ring kernel: 0 = fp32 matrix instruction on 128x128 tiles, 2 = exact three-way bf16 split (default)
+    CG_FUSE,        // fp32 bottlenecks on the tile: 0 off, 1 expand only, 2 with the chained reduce (default)
+    CG_FUSE_BF16,   // bf16 bottlenecks on the tile: same values
+    CG_S1,          // bf16 3x3 stride 1: one LDS window per (channel slice, ky) serves the three horizontal taps (default 1)
+    CG_UT,          // uniform-tap LDS-DMA gather of the 128x128 / 128x64 / 64x64 tiles (default 1; 0 = register-staged gather)
+    CG_TILES,       // bit 0: 8-wave 128x128 tiles, bit 1: 8-wave 128x64, bit 2: four-stage 64x64 (default 7)
+    CG_FORCE,       // tests: pin one small tile shape (1: 128x64, 2: 64x64, 3: 4-wave 128x128; default 0)
+    CG_PRESPLIT,    // fp32 split mode takes pre-split filters where the caller supplies them (default 1)
+    ATT_X3,         // fp32 attention through the exact bf16 split (default 1; 0 = fp32 matrix instruction)
+    ATT_BF16_MFMA,  // bf16 attention on the bf16 matrix instruction (default 1)
+    STEM_ROWS,      // conv1 as a 7x1 row convolution on the ring kernel where it fills the device (default 1)
+    ASSOC_PERSIST,  // association: matching GNN as one persistent launch where the residency gate allows (default 1)
+    SQ_SPLIT,       // super-quadric fit: workgroups per object at most (default 16)
+    SQ_SPLIT_WAIT,  // ... bounded wait for a partner's rows, 100 MHz ticks (default 3000; 0 = never wait)
+    SQ_LANES,       // ... lanes per view in the extent search (default 0 = chosen by the cost model)
+    N_KEYS
+};
+int get(Key k);
+void set(Key k, int v);
+}  // namespace odam_cfg

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../../include/odam_sq.h"
+#include "odam_config.h"
 #include "odam_err.h"
 #include "sq_core.h"
 
@@ -764,9 +765,9 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     A.adam_tab = ctx->d_adam;
     // View split: only when every workgroup of the grid can be resident at once (one 1024-thread workgroup per CU),
     // the objects are large enough to gain, and the exchange history fits a modest buffer.
-    static const int split_env = getenv("ODAM_SQ_SPLIT") ? atoi(getenv("ODAM_SQ_SPLIT")) : 16;
-    static const int wait_env = getenv("ODAM_SQ_SPLIT_WAIT") ? atoi(getenv("ODAM_SQ_SPLIT_WAIT")) : 3000;   // 0: never wait (tests)
-    static const int s_env = getenv("ODAM_SQ_S") ? atoi(getenv("ODAM_SQ_S")) : 0;
+    const int split_env = odam_cfg::get(odam_cfg::SQ_SPLIT);
+    const int wait_env = odam_cfg::get(odam_cfg::SQ_SPLIT_WAIT);   // 0: never wait (tests)
+    const int s_env = odam_cfg::get(odam_cfg::SQ_LANES);
     A.force_lanes_per_view = s_env;
     A.n_obj = n_obj; A.split = 1; A.split_min_views = 64; A.max_views = max_views; A.split_wait_ticks = (unsigned)wait_env;
     int grid = n_obj;

@@ -43,20 +43,23 @@ def test_forward_vs_reference_associator(golden):
     a.close()
 
 
-def test_persistent_matching_kernel_vs_launch_sequence(golden, monkeypatch):
+def test_persistent_matching_kernel_vs_launch_sequence(golden):
     """the one-launch matching GNN (grid barriers between the stages, Sinkhorn in workgroup 0) against the same layers as
-    ~50 separate launches (ODAM_ASSOC_PERSIST=0): same assignment matrix to fp32 reorder noise, for few and many tracks"""
+    ~50 separate launches (config assoc.persist = 0): same assignment matrix to fp32 reorder noise, for few and many tracks"""
     from odam_amd import associator, weights
     z = golden("assoc.npz")
     sd = weights.make_associator_state_dict(2, 8, seed=0)
     cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
     one = associator.Associator(cfg, max_tracks=320, device=DEV)
     one.load_state_dict(sd)
-    monkeypatch.setenv("ODAM_ASSOC_PERSIST", "0")
-    many = associator.Associator(cfg, max_tracks=320, device=DEV)
-    many.load_state_dict(sd)
-    many._handle()                                     # the switch is read when the handle is finalised
-    monkeypatch.delenv("ODAM_ASSOC_PERSIST")
+    from odam_amd import _lib
+    _lib.set_config("assoc.persist", 0)
+    try:
+        many = associator.Associator(cfg, max_tracks=320, device=DEV)
+        many.load_state_dict(sd)
+        many._handle()                                     # the switch is read when the handle is finalised
+    finally:
+        _lib.set_config("assoc.persist", 1)
     g = torch.Generator().manual_seed(5)
     base_t = torch.from_numpy(z["c0_tracks"]); base_d = torch.from_numpy(z["c0_det"])
     for T, n in ((1, 1), (3, 30), (17, 9), (40, 21), (70, 30), (96, 5), (300, 30), (129, 17)):    # > 64 tracks: several key chunks
