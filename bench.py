@@ -197,7 +197,8 @@ def main():
         _lib.check(_lib.lib().odam_op_conv_f32_mode(2), "odam_op_conv_f32_mode")
     secondary = {}
     if rank == 0 and ws == 1 and not args.no_secondary:
-        secondary = secondary_blocks(step, detector, args.chunk, frames, tracks, N, dump["per_frame"], scene, device, dt / args.steps)
+        secondary = secondary_blocks(step, detector, args.chunk, frames, tracks, N, dump["per_frame"], scene, device, dt / args.steps,
+                                     det_phase_ms / args.steps)
     if args.dump and rank == 0:
         np.savez(args.dump, blk=dump["blk"], cnt=dump["cnt"], fitted=dump["fitted"])
     if ws > 1:
@@ -342,7 +343,7 @@ def main():
         torch.distributed.destroy_process_group()
 
 
-def secondary_blocks(step, detector, chunk, frames, tracks, N, per_frame, scene, device, ms_step_s):
+def secondary_blocks(step, detector, chunk, frames, tracks, N, per_frame, scene, device, ms_step_s, det_phase_ms_step):
     """Secondary figures of the one-GPU line (none of them is `value`):
     host_resident -- the same step with the frames in pinned HOST memory (PCIe-inclusive: uploads overlapped batch by batch);
     shard_of_8    -- what ONE rank of eight does (125-frame shard + its share of the objects, both fit passes), i.e. the
@@ -375,21 +376,20 @@ def secondary_blocks(step, detector, chunk, frames, tracks, N, per_frame, scene,
                                  "shrink when objects are sharded"}
     try:
         out["with_association"] = association_block(per_frame, scene, device, N, ms_step_s)
+        fit_ms = 1e3 * ms_step_s - det_phase_ms_step
+        out["with_association"]["overlapped"] = association_overlapped(detector, frames, chunk, scene, device, N, fit_ms)
     except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the line down
-        out["with_association"] = {"error": repr(e)}
+        out.setdefault("with_association", {})["error"] = repr(e)
     return out
 
 
-def association_block(per_frame, scene, device, N, ms_step_s, n_sample=200):
-    """OdamProcess.process_frame (track preparation -> association network + Sinkhorn on the device -> Hungarian step ->
-    attach) over the first n_sample frames' detections of this scene, with the hand-written scene association weights of
-    the whole-chain fixture (tests/scene_weights.py).  Sequential over frames and replicated on every rank."""
+def _new_process(device, tracks_cap=128):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import scene_weights
     from odam_amd import associator
     from odam_amd.processor import OdamProcess
     net = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"],
-                                 "sinkhorn_iterations": 100}, max_tracks=128, device=device)
+                                 "sinkhorn_iterations": 100}, max_tracks=tracks_cap, device=device)
     net.load_state_dict(scene_weights.make_scene_associator_state_dict(2, 8, seed=0))
 
     class _Det:
@@ -397,6 +397,14 @@ def association_block(per_frame, scene, device, N, ms_step_s, n_sample=200):
     d = _Det(); d.device = device
     proc = OdamProcess(d, net, None, None, fitter=sq.SqFitter(device, 1))
     proc.init_sequence(synth.K_SCANNET, synth.IMG_H, synth.IMG_W)
+    return proc, net
+
+
+def association_block(per_frame, scene, device, N, ms_step_s, n_sample=200):
+    """OdamProcess.process_frame (track preparation -> association network + Sinkhorn on the device -> Hungarian step ->
+    attach) over the first n_sample frames' detections of this scene, with the hand-written scene association weights of
+    the whole-chain fixture (tests/scene_weights.py).  Sequential over frames and replicated on every rank."""
+    proc, net = _new_process(device)
     n = min(n_sample, len(per_frame))
     ids, T = scene["img_names"], scene["T_wcs"]
     for i in range(min(8, n)):      # warm-up: handles, first tracks
@@ -410,6 +418,52 @@ def association_block(per_frame, scene, device, N, ms_step_s, n_sample=200):
            "lost_persistent_launches": net.lost_launches,
            "value": N / (ms_step_s + N * per), "unit": "frames/s",
            "note": "detect + fit step of this line + the association loop run after it, nothing overlapped"}
+    net.close()
+    return res
+
+
+def association_overlapped(detector, frames, chunk, scene, device, N, fit_ms):
+    """detections leave the detector chunk by chunk (on N > 1 ranks: one all-gather per chunk), and the
+    sequential association of chunk i runs on a second host thread while the detector works on chunk i + 1.  One GPU here:
+    the association's small kernels share the device with the detector's.  value = frames / (overlapped detect + associate
+    wall time + the two fit passes of the headline step)."""
+    import queue
+    import threading
+    proc, net = _new_process(device)
+    ids, T = scene["img_names"], scene["T_wcs"]
+    q = queue.Queue()
+    err = []
+
+    def worker():
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                c0, rows = item
+                for i, r in enumerate(rows):
+                    proc.process_frame(None, int(ids[c0 + i]), T[c0 + i], detections=r)
+        except Exception as e:      # noqa: BLE001
+            err.append(repr(e))
+    th = threading.Thread(target=worker)
+    torch.cuda.synchronize(); s0 = time.perf_counter()
+    th.start()
+    for c0, rows16 in detector.detect_resident_chunks(frames, (synth.IMG_W, synth.IMG_H), synth.K_SCANNET, chunk=chunk):
+        rows = []
+        for i in range(rows16.shape[0]):
+            sel = detector.select(rows16[i], 0.6, True, 30)
+            rows.append(detection_array({k: [v] for k, v in sel.items()}, 0, ids[c0 + i], synth.IMG_W, synth.IMG_H))
+        q.put((c0, rows))
+    t_det = time.perf_counter() - s0
+    q.put(None)
+    th.join()
+    torch.cuda.synchronize()
+    t_all = time.perf_counter() - s0
+    res = {"detect_and_associate_ms": 1e3 * t_all, "detector_done_after_ms": 1e3 * t_det, "live_tracks_at_end": len(proc.tracks),
+           "lost_persistent_launches": net.lost_launches, "value": N / (t_all + fit_ms * 1e-3), "unit": "frames/s",
+           "chunk_frames": chunk, "errors": err or None,
+           "note": "association of chunk i on a second host thread under the detection of chunk i + 1 (one GPU shared), then the "
+                   "two fit passes of the headline step"}
     net.close()
     return res
 

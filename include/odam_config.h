@@ -5,7 +5,7 @@
  * (src/models/backbone.py:59-94, src/models/transformer.py:132-238 run through torch.nn.functional).  Here every choice that
  * changes which kernel runs -- and with it the order of an fp32 summation -- is an explicit, named switch of the process, set
  * by the host program; the library never reads the environment for them.  Keys, defaults and ranges: odam_amd/csrc/odam_config.h.
- *   cg.ring cg.f32 cg.fuse cg.fuse_bf16 cg.s1 cg.ut cg.tiles cg.force cg.presplit att.x3 att.bf16_mfma stem.rows
+ *   cg.ring cg.f32 cg.fuse cg.fuse_bf16 cg.s1 cg.ut cg.tiles cg.force cg.presplit cg.mfma16 att.x3 att.bf16_mfma stem.rows
  *   assoc.persist sq.split sq.split_wait sq.lanes
  * Return codes as in odam_sq.h (0 = OK; odam_last_error() has the message).  Setting a switch affects launches made after
  * the call; handles created earlier keep what they sized from it (assoc.persist is read when a handle is finalised).

@@ -73,6 +73,12 @@ int odam_sq_fit_batch(odam_sq_ctx* ctx, int n_obj, const float* init_params, con
 /* Surface points of n super-quadrics: params [dev][n][9] -> out_points [dev][n][1000][3]. */
 int odam_sq_points_batch(odam_sq_ctx* ctx, int n, const float* params, float* out_points, void* stream);
 
+/* Projected extent of n super-quadric surfaces in one camera -- what OdamProcess._prepare_tracks (src/processor.py:181-207)
+ * computes per live track and frame: params [dev][n][9] -> surface points (as odam_sq_points_batch) -> float64
+ * [p, 1] T_cw^T K^T, divide by depth, min / max.  T_cw12_K9 [host][21]: rows 0..2 of inv(T_wc) (12 values, row-major), then K
+ * (9, row-major); out_px [dev][n][4] float64 = x_min, y_min, x_max, y_max.  Stream-ordered. */
+int odam_sq_project_extents(odam_sq_ctx* ctx, int n, const float* params, const double* T_cw12_K9, double* out_px, void* stream);
+
 /* The reference's one native symbol under its own name and signature
  * (learnable_primitives/fast_sampler/sampling.hpp:5-15; bound by _sampler.pyx:430-439, which passes
  * buffer_size = 201, seed = 0):  shapes [host][B][M][3], epsilons [host][B][M][2] -> etas, omegas [host][B][M][N].

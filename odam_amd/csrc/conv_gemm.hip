@@ -11,6 +11,7 @@
 namespace odam_cg {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // One k-tile is 8 chunks of 16 bytes per row in both precisions: 32 fp32 or 64 bf16 values; LDS rows are
@@ -1380,8 +1381,8 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
-    const int ring = NST * (MODE == 3 ? 256 * 64 + 96 * BN : (256 + BN) * 64);
-    const int wm = MODE == 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
+    const int ring = NST * (MODE >= 3 ? 256 * 64 + 96 * BN : (256 + BN) * 64);
+    const int wm = MODE >= 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
     const int wn = NTH / 64 / wm;
     const int slab = (NTH / 64) * 32 * (BN / wn) * 4;
     const int s1 = (MODE == 0 && NTH == 512) ? (BN == 256 ? 2 : (BN == 128 ? 3 : 4)) * (384 * 64 + 3 * BN * 64) : 0;   // the 3x3 stride-1 window ring (bf16)
@@ -1395,13 +1396,16 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                       (FUSE >= 5 && FUSE <= 8 && MODE == 0 && NTH == 512 && NST == 4),
                   "fused layers: pre-split filters with 64-column tiles (FUSE 1, 2, 4) or 128-column tiles (FUSE 3); bf16 (FUSE 5 + "
                   "log2(PN / 32), 5 = no chained reduce)");
-    static_assert(MODE == 0 || MODE == 2 || MODE == 3, "bf16 operands, fp32 split, fp32 split with pre-split filters");
+    static_assert(MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4,
+                  "bf16 operands, fp32 split, fp32 split with pre-split filters (3: 32x32x16 matrix instruction, 4: 16x16x32)");
+    static_assert(MODE != 4 || FUSE == 0, "the 16x16x32 schedule has its own epilogue only");
     constexpr bool BF16 = MODE == 0;
     // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
     // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
     // split in registers; the wave grid is 4 x 2 (64 x 128 per wave), so a wave splits 2 row tiles instead of 4 + 2
     // -- a third of the vector work of MODE 2.
-    constexpr bool PRE = MODE == 3;
+    constexpr bool PRE = MODE == 3 || MODE == 4;
+    constexpr bool X16 = MODE == 4;          // pre-split filters, v_mfma_f32_16x16x32_bf16: see the main loop
     static_assert(!PRE || NTH == 512, "pre-split filters: eight-wave workgroups");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
@@ -1445,7 +1449,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     const int kw_inv = (65536 + a.KW - 1) / a.KW;
     const int nt_inv = (65536 + ntaps - 1) / ntaps;
     const int b0 = m0 / hw;
-    const int csrc = c4 ^ ((lane >> 4) & 3);
+    const int csrc = X16 ? (c4 ^ ((lane >> 4) & 1)) : (c4 ^ ((lane >> 4) & 3));     // 16-row fragments: rows r, r + 4 differ in the key (see X16)
     const int margin = (a.pad * a.W + a.pad) * lda;
     const unsigned long long pa = (unsigned long long)(Ag + (size_t)b0 * a.H * a.W * lda - margin), pw = (unsigned long long)Wg;
     const u32x4 a_rs4 = u32x4{(unsigned)pa, (unsigned)(pa >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
@@ -1495,7 +1499,7 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
             const int pl = q / (BN / 32), rb = q - pl * (BN / 32);
             const int row = rb * 32 + (lane >> 1);
             const int n = n0 + row;
-            const int cs = (lane & 1) ^ ((lane >> 4) & 1);
+            const int cs = X16 ? (lane & 1) : ((lane & 1) ^ ((lane >> 4) & 1));
             w3_voff[j] = (q < NB3 && n < a.Cout) ? (unsigned)(n * (a.Kpad / 16) * 96 + pl * 32 + cs * 16) : OOB_VOFF;
         }
     }
@@ -1646,7 +1650,167 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     };
 
     const int nk = a.Kpad / BKE;
-    if constexpr (PRE) {
+    if constexpr (X16) {
+        // ---- pre-split filters on v_mfma_f32_16x16x32_bf16 -------------------------------------------------------------------
+        // Same products as MODE 3, issued as 16x16x32 instructions: this loop is paced by the matrix pipe at the clock the chip
+        // holds under load, and it holds a higher clock on this shape (tests/native/mfma_shape_probe.hip, the split loop out of
+        // LDS on random data: 1.97 vs 1.72 GHz at equal cycles per product = 1.15-1.19x; MI355X_MICROARCH.md, DVFS give-back 7).
+        // State (round 3, interleaved same-box A/B, tests/native/ab_config.py cg.mfma16 0 1): a TIE with MODE 3 -- R50 forward
+        // 32.76 vs 32.41 ms, R101 53.05 vs 53.28 -- i.e. this loop's issue stream is ~10 % less dense than MODE 3's hand-tuned
+        // one and the clock pays that back.  Off by default (odam_config cg.mfma16); what is left to try is listed in DESIGN.md.
+        // One instruction spans 32 k = TWO 16-k ring stages: lane (row l & 15, k-group l >> 4) takes its 8 consecutive k from
+        // stage (l >> 5) of the pair, so the ring is two pairs -- the pair being multiplied and the pair in flight -- with one
+        // barrier per pair.  A fragments: two 16-byte chunks 2 (kq & 1), + 1 of the lane's row, key (row >> 2) & 1 (the read
+        // groups of ds_read_b128 then see rows 0-3 / 12-15 with chunk c and rows 4-11 with chunk c + 2 on 16 distinct slots);
+        // filter planes: 16 bytes at half kq & 1 of the 32-byte row, no key needed.  Per pair and wave: the column tiles in
+        // groups of four (their 12 fragment registers held), every row tile read and split once per group.
+        constexpr int MI = BM / WM / 16, NJ = BN / WN / 16;
+        static_assert(NJ % 4 == 0, "column tiles in groups of four");
+        floatx4 c16[MI][NJ];
+#pragma unroll
+        for (int i = 0; i < MI; i++)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) c16[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+        const int r16 = lane & 15, kq = lane >> 4;
+        const int akey = (r16 >> 2) & 1;
+        const int a_lane = (kq >> 1) * STAGE + (wm * (BM / WM) + r16) * ROWB;
+        const int a_c0 = ((2 * (kq & 1)) ^ akey) << 4, a_c1 = ((2 * (kq & 1) + 1) ^ akey) << 4;
+        const int b_lane = (kq >> 1) * STAGE + A_BYTES + (wn * (BN / WN) + r16) * 32 + (kq & 1) * 16;
+        auto dma_tile = [&](int kt, int st) {
+            if (kt >= nk) return;
+            const TilePrep tp = tile_prep(kt);
+#pragma unroll
+            for (int part = 0; part < A_LD; part++) {
+                const unsigned vo = ((a_mask[part] >> tp.tap) & 1u) ? a_voff[part] : OOB_VOFF;
+                lds_dma16(a_rs4, lds_base + (unsigned)(st * STAGE + wave_u * 16 * ROWB + RPP * part * ROWB), vo, tp.soff_a);
+            }
+#pragma unroll
+            for (int j = 0; j < B3_HI; j++)
+                if (j + 1 < B3_HI || b_wave)
+                    lds_dma16(w3_rs4, lds_base + (unsigned)(st * STAGE + A_BYTES + (wave_u + NW * j) * 1024), w3_voff[j], tp.soff_b);
+        };
+        // One block = one row tile x four column tiles = 24 matrix instructions.  Software pipeline, one block ahead: while
+        // block b's instructions run, the wave reads and splits block b + 1's row fragment, refills the filter registers a
+        // finished column group has released (in place), and issues its share of the next pair's DMAs.
+        constexpr int NBLK = MI * (NJ / 4);                  // blocks per pair, column group outer, row tile inner
+        constexpr int NDMA = 2 * (A_LD + B3_HI);             // DMA instructions per thread for a pair
+        auto dma_part16 = [&](int kt, int st, int part) {    // the part-th DMA of tile kt (A rows first, then filter pieces)
+            if (kt >= nk) return;
+            const TilePrep tp = tile_prep(kt);
+            if (part < A_LD) {
+                const unsigned vo = ((a_mask[part] >> tp.tap) & 1u) ? a_voff[part] : OOB_VOFF;
+                lds_dma16(a_rs4, lds_base + (unsigned)(st * STAGE + wave_u * 16 * ROWB + RPP * part * ROWB), vo, tp.soff_a);
+            } else {
+                const int j = part - A_LD;
+                if (j + 1 < B3_HI || b_wave)
+                    lds_dma16(w3_rs4, lds_base + (unsigned)(st * STAGE + A_BYTES + (wave_u + NW * j) * 1024), w3_voff[j < B3_HI ? j : 0], tp.soff_b);
+            }
+        };
+        dma_tile(0, 0); dma_tile(1, 1);
+#define ODAM_MM16(accv, x, y) accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
+        for (int kp = 0; 2 * kp < nk; ++kp) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this pair has landed (the next one is issued below)
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int s0 = (2 * kp) & 3;
+            const char* Sa = lds_c + s0 * STAGE + a_lane;
+            const char* Sb = lds_c + s0 * STAGE + b_lane;
+            uint4 bh[4], bm[4], bl[4];
+            auto read_b = [&](int jh, int j) {
+                const char* bp = Sb + (jh + j) * 16 * 32;
+                bh[j] = *reinterpret_cast<const uint4*>(bp);
+                bm[j] = *reinterpret_cast<const uint4*>(bp + BN * 32);
+                bl[j] = *reinterpret_cast<const uint4*>(bp + 2 * BN * 32);
+            };
+            struct Ops { uint4 h, m, l; };
+            Ops A2[2];
+            auto read_split_a = [&](int mi, Ops& o) {
+                const float4 a0 = *reinterpret_cast<const float4*>(Sa + mi * 16 * ROWB + a_c0);
+                const float4 a1 = *reinterpret_cast<const float4*>(Sa + mi * 16 * ROWB + a_c1);
+                split8(a0, a1, o.h, o.m, o.l);
+            };
+#pragma unroll
+            for (int j = 0; j < 4; j++) read_b(0, j);
+            read_split_a(0, A2[0]);
+            int dpart = 0;
+#pragma unroll
+            for (int b = 0; b < NBLK; b++) {
+                const int jh = (b / MI) * 4, mi = b % MI;
+                const Ops& o = A2[b & 1];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {      // smallest products first, as MODE 3
+                    ODAM_MM16(c16[mi][jh + j], o.l, bh[j]); ODAM_MM16(c16[mi][jh + j], o.m, bm[j]); ODAM_MM16(c16[mi][jh + j], o.h, bl[j]);
+                    ODAM_MM16(c16[mi][jh + j], o.m, bh[j]); ODAM_MM16(c16[mi][jh + j], o.h, bm[j]);
+                    ODAM_MM16(c16[mi][jh + j], o.h, bh[j]);
+                    if (mi == MI - 1 && jh + 4 < NJ) read_b(jh + 4, j);      // this column tile is done: its registers take the next group's
+                }
+                if (b + 1 < NBLK) read_split_a((b + 1) % MI, A2[(b + 1) & 1]);
+#pragma unroll
+                for (; dpart < ((b + 1) * NDMA + NBLK - 1) / NBLK; dpart++) {      // spread over the pair (all of them in its first half: measured 3 % slower)
+                    const int half_ = dpart / (A_LD + B3_HI), part = dpart - half_ * (A_LD + B3_HI);
+                    dma_part16(2 * kp + 2 + half_, (s0 ^ 2) + half_, part);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#undef ODAM_MM16
+        __syncthreads();
+        // epilogue of the 16x16 accumulators (lane: column l & 15, rows 4 (l >> 4) + r): scale / bias (+ residual) (ReLU), fp32
+        // out; a row tile of 16 rows goes through a per-wave LDS slab (rows padded by 4 floats: the four row groups of a
+        // ds_write_b32 land on different banks) and leaves as 16-byte stores
+        {
+            constexpr int WROWS = BM / WM, WCOLS = BN / WN, EP_LD = WCOLS + 4;
+            static_assert(NW * 16 * EP_LD * 4 <= NST * STAGE, "epilogue slabs fit the ring");
+            float* Ep = smem + wave * (16 * EP_LD);
+            constexpr int LPR = WCOLS / 4, RPI = 64 / LPR, NIT = 16 / RPI;
+            const int c4e = (lane % LPR) * 4;
+            const int n = n0 + wn * WCOLS + c4e;
+            const bool n_ok = n < a.Cout;
+            float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+            if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+            if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
+            const float* resp = reinterpret_cast<const float*>(a.res);
+            float* outp = reinterpret_cast<float*>(a.C);
+            float4 rv[2][NIT];
+            auto load_res = [&](int mi, float4 (&dst)[NIT]) {
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int m = m0 + wm * WROWS + mi * 16 + it * RPI + lane / LPR;
+                    dst[it] = float4{0.f, 0.f, 0.f, 0.f};
+                    if (resp && n_ok && m < a.M) dst[it] = *reinterpret_cast<const float4*>(resp + (size_t)m * a.ldc + n);
+                }
+            };
+            load_res(0, rv[0]);
+#pragma unroll
+            for (int mi = 0; mi < MI; mi++) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) Ep[(4 * kq + r) * EP_LD + j * 16 + r16] = c16[mi][j][r];
+                if (mi + 1 < MI) load_res(mi + 1, rv[(mi + 1) & 1]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int row = it * RPI + lane / LPR;
+                    const int m = m0 + wm * WROWS + mi * 16 + row;
+                    const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
+                    const float4 rr = rv[mi & 1][it];
+                    float4 o;
+                    o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
+                    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                    if (a.relu) {
+                        o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                        o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                    }
+                    if (n_ok && m < a.M) *reinterpret_cast<float4*>(outp + (size_t)m * a.ldc + n) = o;
+                }
+            }
+        }
+        return;
+    } else if constexpr (PRE) {
         // Pre-split filters, software-pipelined across the barrier.  Tile kt is consumed from REGISTERS: its fragments were
         // read from the ring during iteration kt - 1 -- the filter fragments of column tile j into the registers that
         // column's last matrix instruction has just released, the activation fragments into a second set, row tile 0
@@ -2153,18 +2317,21 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         const bool bf = a.dtype == ODAM_CG_BF16;
         const bool x3 = !bf && g_big_f32 == 2;
         const bool pre = x3 && a.Wt3 != nullptr && odam_cfg::get(odam_cfg::CG_PRESPLIT) != 0 && a.Kpad % 16 == 0 && (long)a.Cout * a.Kpad * 6 < 0x7fffffffL;
+        const bool x16 = pre && odam_cfg::get(odam_cfg::CG_MFMA16) != 0 && (a.Cout & 3) == 0 && (a.ldc & 3) == 0 && a.Kpad % 32 == 0;   // 16x16x32 schedule
         if (a.Cout % 256 == 0 || a.Cout >= 384) {
             if (big_eligible(a, 256))
-                return bf ? launch_big<0, 256, 4>(a, stream) : (pre ? launch_big<3, 256, 4>(a, stream) : launch_big<2, 256, 4>(a, stream));
+                return bf ? launch_big<0, 256, 4>(a, stream)
+                          : (pre ? (x16 ? launch_big<4, 256, 4>(a, stream) : launch_big<3, 256, 4>(a, stream)) : launch_big<2, 256, 4>(a, stream));
 #ifndef CG_NO_BN128_FALLBACK
             // too few 256-wide tiles to fill the device (the encoder's N = 256 layers at M = 27,200: 107) but enough 128-wide
             // ones: the ring kernel on 256 x 128 tiles instead of the 128 x 128 tiles of the fp32 matrix instruction
-            if (pre && big_eligible(a, 128)) return launch_big<3, 128, 4>(a, stream);
+            if (pre && big_eligible(a, 128)) return x16 ? launch_big<4, 128, 4>(a, stream) : launch_big<3, 128, 4>(a, stream);
 #endif
         } else if (a.Cout > 64 && (g_big_mode >= 2 || x3) && big_eligible(a, 128)) {   // bf16 / fp32: measured slower than the 128x128 tiles (tests only)
-            return bf ? launch_big<0, 128, 4>(a, stream) : (pre ? launch_big<3, 128, 4>(a, stream) : launch_big<2, 128, 4>(a, stream));
+            return bf ? launch_big<0, 128, 4>(a, stream)
+                      : (pre ? (x16 ? launch_big<4, 128, 4>(a, stream) : launch_big<3, 128, 4>(a, stream)) : launch_big<2, 128, 4>(a, stream));
         } else if (x3 && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
-            return pre ? launch_big<3, 64, 4>(a, stream) : launch_big<2, 64, 4>(a, stream);
+            return pre ? (x16 ? launch_big<4, 64, 4>(a, stream) : launch_big<3, 64, 4>(a, stream)) : launch_big<2, 64, 4>(a, stream);
         } else if (bf && (g_big_mode >= 2 || (a.lda > 0 && a.lda < a.Cin)) && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
             return launch_big<0, 64, 4>(a, stream);     // conv1 as a row convolution (pixel stride < row length); tests: layer1's 3x3 alone
         }

@@ -690,6 +690,10 @@ struct odam_sq_ctx {
     unsigned* d_done = nullptr;
     size_t done_n = 0;
     int n_cu = 256;
+    // odam_sq_project_extents: surface points of the tracks of one frame (grow-only)
+    float* d_proj_pts = nullptr;
+    size_t proj_pts_n = 0;
+    double* d_cam = nullptr;      // [21]: T_cw rows 0..2 (12), K (9)
 };
 
 static std::vector<float> sampler_draws() {
@@ -747,6 +751,11 @@ extern "C" int odam_sq_create(int max_iters, odam_sq_ctx** out) {
 }
 
 extern "C" int odam_sq_destroy(odam_sq_ctx* c) {
+    if (c) {
+        if (c->d_proj_pts) (void)hipFree(c->d_proj_pts);
+        if (c->d_cam) (void)hipFree(c->d_cam);
+        c->d_proj_pts = nullptr; c->d_cam = nullptr;
+    }
     if (!c) return ODAM_OK;
     (void)hipFree(c->d_draws);
     (void)hipFree(c->d_omega_idx);
@@ -848,6 +857,67 @@ extern "C" int odam_sq_points_batch(odam_sq_ctx* ctx, int n, const float* params
     A.out_params = nullptr;
     A.out_points = out_points;
     return launch_fit(ctx, n, A, 1, (hipStream_t)stream);
+}
+
+// ---- projected extent of n super-quadric surfaces in one camera (OdamProcess._prepare_tracks, src/processor.py:181-207) --------
+// The reference samples each live track's surface (1000 points, float32), moves them to the camera with T_cw and to the image
+// with K in float64 numpy, divides by depth and takes min / max of u and v: the box the track is expected to fill in this
+// frame.  One workgroup per track: points from odam_sq_points_batch's kernel, then the same float64 products per point and a
+// min / max reduction -- 32 bytes per track come back instead of 12 KB of points and 48,000 host flops.
+namespace {
+__global__ __launch_bounds__(256) void project_extent_kernel(const float* __restrict__ pts, const double* __restrict__ cam, double* __restrict__ out) {
+    __shared__ double red[4][4];
+    const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* p = pts + (size_t)t * N_PTS * 3;
+    double T[12], K[9];
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = cam[i];
+#pragma unroll
+    for (int i = 0; i < 9; i++) K[i] = cam[12 + i];
+    double umin = INFINITY, vmin = INFINITY, umax = -INFINITY, vmax = -INFINITY;
+    for (int i = tid; i < N_PTS; i += 256) {
+        const double x = (double)p[3 * i], y = (double)p[3 * i + 1], z = (double)p[3 * i + 2];
+        const double c0 = x * T[0] + y * T[1] + z * T[2] + T[3];
+        const double c1 = x * T[4] + y * T[5] + z * T[6] + T[7];
+        const double c2 = x * T[8] + y * T[9] + z * T[10] + T[11];
+        const double q0 = c0 * K[0] + c1 * K[1] + c2 * K[2];
+        const double q1 = c0 * K[3] + c1 * K[4] + c2 * K[5];
+        const double q2 = c0 * K[6] + c1 * K[7] + c2 * K[8];
+        const double u = q0 / q2, v = q1 / q2;
+        umin = fmin(umin, u); umax = fmax(umax, u); vmin = fmin(vmin, v); vmax = fmax(vmax, v);
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        umin = fmin(umin, __shfl_xor(umin, o)); vmin = fmin(vmin, __shfl_xor(vmin, o));
+        umax = fmax(umax, __shfl_xor(umax, o)); vmax = fmax(vmax, __shfl_xor(vmax, o));
+    }
+    if (lane == 0) { red[wave][0] = umin; red[wave][1] = vmin; red[wave][2] = umax; red[wave][3] = vmax; }
+    __syncthreads();
+    if (tid < 4) {
+        double r = red[0][tid];
+        for (int w = 1; w < 4; w++) r = tid < 2 ? fmin(r, red[w][tid]) : fmax(r, red[w][tid]);
+        out[(size_t)t * 4 + tid] = r;      // x_min, y_min, x_max, y_max
+    }
+}
+}  // namespace
+
+extern "C" int odam_sq_project_extents(odam_sq_ctx* ctx, int n, const float* params, const double* T_cw12_K9, double* out_px,
+                                       void* stream) {
+    if (!ctx || !params || !T_cw12_K9 || !out_px || n < 0) return odam_fail(ODAM_E_INVALID, "odam_sq_project_extents: bad arguments");
+    if (n == 0) return ODAM_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if ((size_t)n > ctx->proj_pts_n) {
+        if (ctx->d_proj_pts) { ODAM_HIP(hipStreamSynchronize(st)); ODAM_HIP(hipFree(ctx->d_proj_pts)); ctx->d_proj_pts = nullptr; }
+        const size_t cap = (size_t)n > 64 ? (size_t)n * 2 : 128;
+        ODAM_HIP(hipMalloc((void**)&ctx->d_proj_pts, cap * N_PTS * 3 * sizeof(float)));
+        ctx->proj_pts_n = cap;
+    }
+    if (!ctx->d_cam) ODAM_HIP(hipMalloc((void**)&ctx->d_cam, 21 * sizeof(double)));
+    ODAM_HIP(hipMemcpyAsync(ctx->d_cam, T_cw12_K9, 21 * sizeof(double), hipMemcpyHostToDevice, st));   // pageable source: staged by the runtime before it returns
+    if (int rc = odam_sq_points_batch(ctx, n, params, ctx->d_proj_pts, stream)) return rc;
+    hipLaunchKernelGGL(project_extent_kernel, dim3(n), dim3(256), 0, st, ctx->d_proj_pts, ctx->d_cam, out_px);
+    ODAM_HIP(hipGetLastError());
+    return ODAM_OK;
 }
 
 // host sampler: same leaf arithmetic as the device path, serial walk with an explicit work list

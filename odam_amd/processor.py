@@ -217,10 +217,14 @@ class OdamProcess:
             params[i, 4:7] = np.maximum(np.add.reduce(track[:, 6:9], axis=0) / n, 0.05)    # np.clip(., 0.05, inf)
         params[:, 4:7] = np.sqrt(params[:, 4:7] / 2)
         params = params.astype(np.float32)
-        pts_all = self._fitter().points(params).cpu().numpy() if len(tracks) else np.zeros((0, 1000, 3))
-        if len(tracks):
-            # projected extent of every track's surface in this camera, all tracks at once (the reference loops over
-            # tracks; same float64 products, and min / max do not depend on the order of the points)
+        fitter = self._fitter()
+        if len(tracks) and hasattr(fitter, "project_extents"):
+            # surface points, camera transform, projection and min / max on the device (odam_sq_project_extents): the same
+            # float64 products per point as below; 32 bytes per track come back
+            proj_px = fitter.project_extents(params, np.linalg.inv(T_wc), self.sequence_meta.K)
+        elif len(tracks):
+            # (a fitter without the device projection -- the oracle-backed test double: tests/test_processor.py)
+            pts_all = fitter.points(params).cpu().numpy()
             T_cw = np.linalg.inv(T_wc)
             cam = (np.concatenate([pts_all, np.ones_like(pts_all[..., 2:])], axis=2) @ T_cw.T)[..., :3]
             pix = cam @ np.asarray(self.sequence_meta.K).T

@@ -213,6 +213,30 @@ class SqFitter:
         return out
 
 
+def _project_extents(self, params, T_cw, K):
+    """[n,9] parameter rows -> [n,4] float64 (x_min, y_min, x_max, y_max) of each surface projected with K @ T_cw[:3]
+    (OdamProcess._prepare_tracks, processor.py:181-207), computed on the device"""
+    dev = self.device
+    d_p = torch.as_tensor(np.asarray(params)).to(device=dev, dtype=torch.float32).reshape(-1, 9).contiguous()
+    n = d_p.shape[0]
+    out = torch.empty(n, 4, device=dev, dtype=torch.float64)
+    cam = np.ascontiguousarray(np.concatenate([np.asarray(T_cw, np.float64)[:3].reshape(-1), np.asarray(K, np.float64)[:3, :3].reshape(-1)]))
+    with torch.cuda.device(dev), self._lock:
+        cur = torch.cuda.current_stream(dev)
+        stream = cur.cuda_stream
+        if self._last is not None and self._last[0] != stream:
+            cur.wait_event(self._last[1])
+        _lib.check(_lib.lib().odam_sq_project_extents(self._h, ctypes.c_int(n), _lib.ptr(d_p), cam.ctypes.data_as(ctypes.c_void_p),
+                                                      _lib.ptr(out), ctypes.c_void_p(stream)), "odam_sq_project_extents")
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._last = (stream, ev)
+    return out.cpu().numpy()
+
+
+SqFitter.project_extents = _project_extents
+
+
 def host_sample(a, e):
     """odam_sq_sample: (a[3], e[2]) -> etas[1000], omegas[1000] float32 (host)."""
     a = np.ascontiguousarray(a, np.float32)
