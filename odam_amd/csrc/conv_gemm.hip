@@ -564,6 +564,28 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 // 256 output channels leave in four groups of 64 through the same slab: scale, bias, residual, ReLU, 16-byte stores.
 // Why: a bottleneck's 3x3 is matrix-bound and its expand + residual HBM-bound; as two launches each leaves the other
 // resource idle (one workgroup per CU), fused the CUs run out of phase and the two overlap across the chip.
+// The wave's 32-row accumulator tile as (row, column, value) triples, 64 columns at a time, for either matrix-instruction
+// shape: 32x32 blocks (lane: column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)) or 16x16 blocks (lane: column l & 15,
+// rows 4 (l >> 4) + r).  f(row 0..31, column 0..63 inside the group, channel = 64 h2 + column, value).
+template <int TN, class F>
+__device__ __forceinline__ void acc_cols64(floatx16 (&acc)[1][TN], int h2, int lane, F&& f) {
+    const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) f((r & 3) + 8 * (r >> 2) + 4 * half, j * 32 + l32, h2 * 64 + j * 32 + l32, acc[0][2 * h2 + j][r]);
+}
+template <int NJ, class F>
+__device__ __forceinline__ void acc_cols64(floatx4 (&acc)[2][NJ], int h2, int lane, F&& f) {
+    const int kq = lane >> 4, r16 = lane & 15;
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) f(mi * 16 + 4 * kq + r, j * 16 + r16, h2 * 64 + j * 16 + r16, acc[mi][4 * h2 + j][r]);
+}
+
 __device__ __forceinline__ void cg_split8(const float4& c0, const float4& c1, uint4& hi, uint4& mid, uint4& lo) {
     const float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
     unsigned uh[8], um[8], ul[8];
@@ -582,7 +604,8 @@ __device__ __forceinline__ void cg_split8(const float4& c0, const float4& c1, ui
 
 constexpr int FUSE_W3_BYTES = 4 * 3 * 256 * 32, FUSE_LDS_BYTES = FUSE_W3_BYTES + 8 * 32 * 64 * 4;    // 96 KB + 64 KB = all of it
 
-__device__ __forceinline__ void fused_second(const ConvGemmArgs& a, floatx16 (&acc)[1][2], float* smem, unsigned lds_base,
+template <class ACC>
+__device__ __forceinline__ void fused_second(const ConvGemmArgs& a, ACC& acc, float* smem, unsigned lds_base,
                                              int m0, int wave, int lane) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     const int half = lane >> 5, l32 = lane & 31;
@@ -618,17 +641,11 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, floatx16 (&a
     // (2) this layer's epilogue in registers, tile -> slab
     float* slab = smem + FUSE_W3_BYTES / 4 + wave * (32 * 64);
     auto slab_at = [](int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); };
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = j * 32 + l32;
-        const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float v = acc[0][j][r] * sc + bi;
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, n)] = v;
-        }
-    }
+    acc_cols64(acc, 0, lane, [&](int row, int c64, int n, float x) {
+        float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        slab[slab_at(row, c64)] = v;
+    });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -700,7 +717,8 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, floatx16 (&a
 // values go back into the slab, come out as A fragments and are multiplied into a 32 x 64 accumulator of the reduce;
 // after the fourth group that accumulator is the next block's 3x3 input tile.  Saves the launch that re-reads the
 // 256-channel tensor (the largest read of layer1).
-__device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&acc)[1][2], float* smem, unsigned lds_base,
+template <class ACC>
+__device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, float* smem, unsigned lds_base,
                                             int m0, int wave, int lane) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     constexpr int SLABS = 8 * 32 * 64 * 4, GB = 4 * 3 * 64 * 32;      // 64 KB of slabs; 24 KB per filter group
@@ -725,14 +743,22 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&ac
     };
     const int c4 = lane & 15;
     const int m_base = m0 + wave * 32;
+    // residual rows and output rows through buffer descriptors: a row past M gets an out-of-range offset (zeros / dropped),
+    // so every wave issues every load and store and the group loop can wait with a COUNT (see its top)
+    const size_t out_bytes = (size_t)a.M * a.F_ldc * 4;
+    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F_res), 0, a.F_res ? (int)out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.F_C, 0, (int)out_bytes, 0x00020000);
+    unsigned row_off[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int m = m_base + it * 4 + (lane >> 4);
+        row_off[it] = m < a.M ? (unsigned)((size_t)m * a.F_ldc * 4 + c4 * 16) : OOB_VOFF;
+    }
     float4 rv[8];              // residual rows of one output group, requested one group ahead
     auto load_res = [&](int g) {
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int m = m_base + it * 4 + (lane >> 4);
-            rv[it] = float4{0.f, 0.f, 0.f, 0.f};
-            if (a.F_res && m < a.M) rv[it] = *reinterpret_cast<const float4*>(a.F_res + (size_t)m * a.F_ldc + g * 64 + c4 * 4);
-        }
+        for (int it = 0; it < 8; it++)
+            rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0));
     };
     load_res(0);
     dma_group(0);
@@ -751,17 +777,11 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&ac
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = j * 32 + l32;
-        const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float v = acc[0][j][r] * sc + bi;
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, n)] = v;
-        }
-    }
+    acc_cols64(acc, 0, lane, [&](int row, int c64, int n, float x) {
+        float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        slab[slab_at(row, c64)] = v;
+    });
     wave_sync();
     uint4 ah[4], am[4], al[4];
     frags(ah, am, al);
@@ -775,7 +795,10 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&ac
 #define ODAM_MM2(accv, x, y) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
 #pragma unroll
     for (int g = 0; g < 4; g++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // my pieces of group g's filters have landed
+        // my pieces of group g's filters have landed: they were issued at the top of group g - 1, and exactly 8 stores + 8
+        // residual loads (buffer instructions, never branched around) are younger -- those may stay in flight
+        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __syncthreads();                                        // ... and everybody's; everybody is done with group g - 1's buffers
         if (g + 1 < 4) dma_group(g + 1);
         const char* wf = lds_c + SLABS + (g & 1) * GB;
@@ -815,7 +838,7 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&ac
             float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
                         v.w * sc.w + bi.w + rv[it].w};
             if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
-            if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0);
             *sp_ = o;                                           // the final values: this group's slice of the reduce's input
         }
         if (g + 1 < 4) load_res(g + 1);
@@ -863,7 +886,8 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, floatx16 (&ac
 // buffer (slabs 64 + expand filters 2 x 24 + reduce slice 48 = 160 KB): it is fetched at the top of its own group and
 // awaited (with one more workgroup barrier) before the group's second half; its A fragments are split one k-step at a time
 // to stay inside 256 registers.
-__device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, floatx16 (&acc)[1][2], float* smem, unsigned lds_base,
+template <class ACC>
+__device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, float* smem, unsigned lds_base,
                                                int m0, int wave, int lane) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     constexpr int SLABS = 8 * 32 * 64 * 4, GB = 4 * 3 * 64 * 32, GB2 = 4 * 3 * 128 * 32;      // 64 KB; 24 KB; 48 KB
@@ -914,17 +938,11 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, floatx16 (
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        const int n = j * 32 + l32;
-        const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            float v = acc[0][j][r] * sc + bi;
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, n)] = v;
-        }
-    }
+    acc_cols64(acc, 0, lane, [&](int row, int c64, int n, float x) {
+        float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
+        if (a.relu) v = v > 0.f ? v : 0.f;
+        slab[slab_at(row, c64)] = v;
+    });
     wave_sync();
     uint4 ah[4], am[4], al[4];
 #pragma unroll
@@ -1046,7 +1064,8 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, floatx16 (
 // The 3x3's tile goes through the 8 KB slab in two 64-channel halves (eight k-steps of A fragments stay in registers); the
 // expand filters of an output group are 48 KB as three planes, double-buffered beside the slabs (64 + 2 x 48 = 160 KB);
 // eight output groups of 64 channels.  No chained reduce here: its filter slices would need another 96 KB.
-__device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, floatx16 (&acc)[1][4], float* smem, unsigned lds_base,
+template <class ACC>
+__device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc, float* smem, unsigned lds_base,
                                                 int m0, int wave, int lane) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     constexpr int SLABS = 8 * 32 * 64 * 4, KS = 8, GB = KS * 3 * 64 * 32;      // 64 KB of slabs; 48 KB per filter group
@@ -1069,14 +1088,22 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, floatx16 
     };
     const int c4 = lane & 15;
     const int m_base = m0 + wave * 32;
-    float4 rv[8];
+    // residual rows and output rows through buffer descriptors: a row past M gets an out-of-range offset (zeros / dropped),
+    // so every wave issues every load and store and the group loop can wait with a COUNT (see its top)
+    const size_t out_bytes = (size_t)a.M * a.F_ldc * 4;
+    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F_res), 0, a.F_res ? (int)out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.F_C, 0, (int)out_bytes, 0x00020000);
+    unsigned row_off[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int m = m_base + it * 4 + (lane >> 4);
+        row_off[it] = m < a.M ? (unsigned)((size_t)m * a.F_ldc * 4 + c4 * 16) : OOB_VOFF;
+    }
+    float4 rv[8];              // residual rows of one output group, requested one group ahead
     auto load_res = [&](int g) {
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int m = m_base + it * 4 + (lane >> 4);
-            rv[it] = float4{0.f, 0.f, 0.f, 0.f};
-            if (a.F_res && m < a.M) rv[it] = *reinterpret_cast<const float4*>(a.F_res + (size_t)m * a.F_ldc + g * 64 + c4 * 4);
-        }
+        for (int it = 0; it < 8; it++)
+            rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0));
     };
     load_res(0);
     dma_group(0);
@@ -1090,17 +1117,11 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, floatx16 
     uint4 ah[KS], am[KS], al[KS];
 #pragma unroll
     for (int h2 = 0; h2 < 2; h2++) {                        // channels 64 h2 .. + 63 of the 3x3's tile
-#pragma unroll
-        for (int j = 0; j < 2; j++) {
-            const int n = h2 * 64 + j * 32 + l32;
-            const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                float v = acc[0][2 * h2 + j][r] * sc + bi;
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, j * 32 + l32)] = v;
-            }
-        }
+        acc_cols64(acc, h2, lane, [&](int row, int c64, int n, float x) {
+            float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
+            if (a.relu) v = v > 0.f ? v : 0.f;
+            slab[slab_at(row, c64)] = v;
+        });
         wave_sync();
 #pragma unroll
         for (int s_ = 0; s_ < 4; s_++) {
@@ -1115,7 +1136,10 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, floatx16 
 #define ODAM_MM2(accv, x, y) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
 #pragma unroll 1
     for (int g = 0; g < NG; g++) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // group g's filters were issued at the top of group g - 1; exactly 8 stores + 8 residual loads (buffer instructions, never
+        // branched around) are younger -- those may stay in flight
+        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __syncthreads();
         if (g + 1 < NG) dma_group(g + 1);
         const char* wf = lds_c + SLABS + (g & 1) * GB;
@@ -1153,7 +1177,7 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, floatx16 
             float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
                         v.w * sc.w + bi.w + rv[it].w};
             if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
-            if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0);
         }
         if (g + 1 < NG) load_res(g + 1);
         __builtin_amdgcn_wave_barrier();
@@ -1392,13 +1416,13 @@ constexpr int big_lds_bytes() {
 
 template <int MODE, int BN, int NST, int NTH = 512, int FUSE = 0>     // FUSE: 1 = second layer on the tile (F_*), 2 = and a third (G_*)
 __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
-    static_assert(!FUSE || (FUSE <= 4 && MODE == 3 && NTH == 512 && ((FUSE != 3 && BN == 64) || (FUSE == 3 && BN == 128))) ||
+    static_assert(!FUSE || (FUSE <= 4 && (MODE == 3 || MODE == 4) && NTH == 512 && ((FUSE != 3 && BN == 64) || (FUSE == 3 && BN == 128))) ||
                       (FUSE >= 5 && FUSE <= 8 && MODE == 0 && NTH == 512 && NST == 4),
                   "fused layers: pre-split filters with 64-column tiles (FUSE 1, 2, 4) or 128-column tiles (FUSE 3); bf16 (FUSE 5 + "
                   "log2(PN / 32), 5 = no chained reduce)");
     static_assert(MODE == 0 || MODE == 2 || MODE == 3 || MODE == 4,
                   "bf16 operands, fp32 split, fp32 split with pre-split filters (3: 32x32x16 matrix instruction, 4: 16x16x32)");
-    static_assert(MODE != 4 || FUSE == 0, "the 16x16x32 schedule has its own epilogue only");
+    static_assert(MODE != 4 || FUSE <= 4, "the 16x16x32 schedule: its own epilogue, or the fp32 bottleneck tails");
     constexpr bool BF16 = MODE == 0;
     // MODE 3 = MODE 2 with the FILTERS split ahead of time (a.Wt3: [Cout][Kpad / 16][3][16] bf16 = hi | mid | lo of every
     // 16-k group): they arrive in LDS as three bf16 planes and go to the matrix pipe as they are, only the activations are
@@ -1655,9 +1679,12 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         // Same products as MODE 3, issued as 16x16x32 instructions: this loop is paced by the matrix pipe at the clock the chip
         // holds under load, and it holds a higher clock on this shape (tests/native/mfma_shape_probe.hip, the split loop out of
         // LDS on random data: 1.97 vs 1.72 GHz at equal cycles per product = 1.15-1.19x; MI355X_MICROARCH.md, DVFS give-back 7).
-        // State (round 3, interleaved same-box A/B, tests/native/ab_config.py cg.mfma16 0 1): a TIE with MODE 3 -- R50 forward
-        // 32.76 vs 32.41 ms, R101 53.05 vs 53.28 -- i.e. this loop's issue stream is ~10 % less dense than MODE 3's hand-tuned
-        // one and the clock pays that back.  Off by default (odam_config cg.mfma16); what is left to try is listed in DESIGN.md.
+        // Measured (interleaved same-box A/B, tests/native/ab_config.py cg.mfma16 0 3): R50 forward 31.5 vs 32.5 ms (-3 to -4 %):
+        // -2.7 % from the plain layers (layer3 / layer4, encoder, downsample / first-reduce layers), -1.3 % more with the fused
+        // layer1 / layer2 launches on this loop (their tails take either accumulator layout through acc_cols64).  CG_STAMP: the
+        // blocks run at 3,700 cycles per wave and 16 k against the pipe's 3,072 (MODE 3: 3,150) -- a 16x16x32 instruction leaves
+        // 8 issue cycles where 32x32x16 leaves 24, and ten ~150-cycle DMA issues per pair sit in them -- so the clock gain
+        // (1.15x in the bare loop) is only partly realised.  Default: all layers (odam_config cg.mfma16 = 3).
         // One instruction spans 32 k = TWO 16-k ring stages: lane (row l & 15, k-group l >> 4) takes its 8 consecutive k from
         // stage (l >> 5) of the pair, so the ring is two pairs -- the pair being multiplied and the pair in flight -- with one
         // barrier per pair.  A fragments: two 16-byte chunks 2 (kq & 1), + 1 of the lane's row, key (row >> 2) & 1 (the read
@@ -1689,10 +1716,15 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                 if (j + 1 < B3_HI || b_wave)
                     lds_dma16(w3_rs4, lds_base + (unsigned)(st * STAGE + A_BYTES + (wave_u + NW * j) * 1024), w3_voff[j], tp.soff_b);
         };
-        // One block = one row tile x four column tiles = 24 matrix instructions.  Software pipeline, one block ahead: while
-        // block b's instructions run, the wave reads and splits block b + 1's row fragment, refills the filter registers a
-        // finished column group has released (in place), and issues its share of the next pair's DMAs.
-        constexpr int NBLK = MI * (NJ / 4);                  // blocks per pair, column group outer, row tile inner
+        // One block = one row tile x ONE column tile = six matrix instructions.  A 16x16x32 instruction holds the SIMD's vector
+        // issue for 8 of its 16 cycles (32x32x16: 8 of 32), so per product there is half the room for everything else -- and
+        // the split of the activations is 44 vector instructions per fragment.  (First version: four column tiles per block,
+        // every row fragment split once per group of four = 8 splits per pair: 3,729 cycles per wave and 16 k against a pipe
+        // floor of 3,072, CG_STAMP; MODE 3 runs its blocks at 3,123.)  Here a row fragment is split ONCE per pair (4 splits)
+        // and the filter fragments of the column tiles are re-read from LDS instead (3 ds_read_b128 per block, one block
+        // ahead, two register sets): LDS issue replaces vector issue.  The next row tile's raw fragment is read in block 1 of
+        // the current one and split in two halves in blocks 3 and 5; the next pair's DMAs are spread over the blocks.
+        constexpr int NBLK = MI * NJ;
         constexpr int NDMA = 2 * (A_LD + B3_HI);             // DMA instructions per thread for a pair
         auto dma_part16 = [&](int kt, int st, int part) {    // the part-th DMA of tile kt (A rows first, then filter pieces)
             if (kt >= nk) return;
@@ -1708,53 +1740,95 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
         };
         dma_tile(0, 0); dma_tile(1, 1);
 #define ODAM_MM16(accv, x, y) accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
+#if CG_STAMP
+        unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+#endif
         for (int kp = 0; 2 * kp < nk; ++kp) {
+            CG_STAMP_AT(3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this pair has landed (the next one is issued below)
+            CG_STAMP_AT(1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            CG_STAMP_AT(0);
             const int s0 = (2 * kp) & 3;
             const char* Sa = lds_c + s0 * STAGE + a_lane;
             const char* Sb = lds_c + s0 * STAGE + b_lane;
-            uint4 bh[4], bm[4], bl[4];
-            auto read_b = [&](int jh, int j) {
-                const char* bp = Sb + (jh + j) * 16 * 32;
-                bh[j] = *reinterpret_cast<const uint4*>(bp);
-                bm[j] = *reinterpret_cast<const uint4*>(bp + BN * 32);
-                bl[j] = *reinterpret_cast<const uint4*>(bp + 2 * BN * 32);
-            };
             struct Ops { uint4 h, m, l; };
-            Ops A2[2];
-            auto read_split_a = [&](int mi, Ops& o) {
-                const float4 a0 = *reinterpret_cast<const float4*>(Sa + mi * 16 * ROWB + a_c0);
-                const float4 a1 = *reinterpret_cast<const float4*>(Sa + mi * 16 * ROWB + a_c1);
-                split8(a0, a1, o.h, o.m, o.l);
+            constexpr int BD = 2;      // filter fragments BD blocks ahead (one block = 96 pipe cycles: less than an LDS round trip under load; 3 and 4 measured the same)
+            Ops A2[2], B2[BD + 1];
+            float4 ar0, ar1;
+            auto read_b = [&](int nj, Ops& o) {
+                const char* bp = Sb + nj * 16 * 32;
+                o.h = *reinterpret_cast<const uint4*>(bp);
+                o.m = *reinterpret_cast<const uint4*>(bp + BN * 32);
+                o.l = *reinterpret_cast<const uint4*>(bp + 2 * BN * 32);
             };
+            auto read_a = [&](int mi) {
+                ar0 = *reinterpret_cast<const float4*>(Sa + mi * 16 * ROWB + a_c0);
+                ar1 = *reinterpret_cast<const float4*>(Sa + mi * 16 * ROWB + a_c1);
+            };
+            auto half_split = [](const float4& c, Ops& o, int hf) {      // the four values of one 16-byte chunk -> elements (2 hf, 2 hf + 1)
+                const float v[4] = {c.x, c.y, c.z, c.w};
+                unsigned uh[4], um[4], ul[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) read_b(0, j);
-            read_split_a(0, A2[0]);
+                for (int e = 0; e < 4; e++) {
+                    uh[e] = __builtin_bit_cast(unsigned, v[e]);
+                    const float r1 = v[e] - __builtin_bit_cast(float, uh[e] & 0xffff0000u);
+                    um[e] = __builtin_bit_cast(unsigned, r1);
+                    ul[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, um[e] & 0xffff0000u));
+                }
+                auto pk = [](unsigned lo_, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo_, 0x07060302u); };
+                if (hf == 0) {
+                    o.h.x = pk(uh[0], uh[1]); o.h.y = pk(uh[2], uh[3]); o.m.x = pk(um[0], um[1]); o.m.y = pk(um[2], um[3]);
+                    o.l.x = pk(ul[0], ul[1]); o.l.y = pk(ul[2], ul[3]);
+                } else {
+                    o.h.z = pk(uh[0], uh[1]); o.h.w = pk(uh[2], uh[3]); o.m.z = pk(um[0], um[1]); o.m.w = pk(um[2], um[3]);
+                    o.l.z = pk(ul[0], ul[1]); o.l.w = pk(ul[2], ul[3]);
+                }
+            };
+            read_a(0);
+#pragma unroll
+            for (int j = 0; j < BD; j++) read_b(j % NJ, B2[j]);
+            half_split(ar0, A2[0], 0); half_split(ar1, A2[0], 1);
             int dpart = 0;
 #pragma unroll
             for (int b = 0; b < NBLK; b++) {
-                const int jh = (b / MI) * 4, mi = b % MI;
-                const Ops& o = A2[b & 1];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {      // smallest products first, as MODE 3
-                    ODAM_MM16(c16[mi][jh + j], o.l, bh[j]); ODAM_MM16(c16[mi][jh + j], o.m, bm[j]); ODAM_MM16(c16[mi][jh + j], o.h, bl[j]);
-                    ODAM_MM16(c16[mi][jh + j], o.m, bh[j]); ODAM_MM16(c16[mi][jh + j], o.h, bm[j]);
-                    ODAM_MM16(c16[mi][jh + j], o.h, bh[j]);
-                    if (mi == MI - 1 && jh + 4 < NJ) read_b(jh + 4, j);      // this column tile is done: its registers take the next group's
+                const int mi = b / NJ, nj = b % NJ;
+                const Ops& oa = A2[mi & 1];
+                const Ops& ob = B2[b % (BD + 1)];
+                // smallest products first, as MODE 3
+                ODAM_MM16(c16[mi][nj], oa.l, ob.h); ODAM_MM16(c16[mi][nj], oa.m, ob.m); ODAM_MM16(c16[mi][nj], oa.h, ob.l);
+                ODAM_MM16(c16[mi][nj], oa.m, ob.h); ODAM_MM16(c16[mi][nj], oa.h, ob.m);
+                ODAM_MM16(c16[mi][nj], oa.h, ob.h);
+                if (b + BD < NBLK) read_b((b + BD) % NJ, B2[(b + BD) % (BD + 1)]);
+                if (mi + 1 < MI) {
+                    if (nj == 1) read_a(mi + 1);
+                    if (nj == 3) half_split(ar0, A2[(mi + 1) & 1], 0);
+                    if (nj == (NJ > 5 ? 5 : 3)) half_split(ar1, A2[(mi + 1) & 1], 1);
                 }
-                if (b + 1 < NBLK) read_split_a((b + 1) % MI, A2[(b + 1) & 1]);
 #pragma unroll
-                for (; dpart < ((b + 1) * NDMA + NBLK - 1) / NBLK; dpart++) {      // spread over the pair (all of them in its first half: measured 3 % slower)
+                for (; dpart < ((b + 1) * NDMA + NBLK - 1) / NBLK; dpart++) {
                     const int half_ = dpart / (A_LD + B3_HI), part = dpart - half_ * (A_LD + B3_HI);
                     dma_part16(2 * kp + 2 + half_, (s0 ^ 2) + half_, part);
                 }
-                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_sched_barrier(0);      // (without the fence: +2 % time; static priority for waves 4-7: no change)
+                if (b == NBLK / 2 - 1) CG_STAMP_AT(2);
             }
         }
+#if CG_STAMP
+        CG_STAMP_AT(3);
+        if (lane == 0) {
+            for (int i = 0; i < 4; i++) atomicAdd(&g_stamps[i], st_acc[i]);
+            atomicAdd(&g_stamps[4], (unsigned long long)nk);
+            atomicAdd(&g_stamps[5], 1ull);
+        }
+#endif
 #undef ODAM_MM16
         __syncthreads();
+        if constexpr (FUSE == 1) { fused_second(a, c16, smem, lds_base, m0, wave, lane); return; }
+        if constexpr (FUSE == 2) { fused_chain(a, c16, smem, lds_base, m0, wave, lane); return; }
+        if constexpr (FUSE == 3) { fused_second128(a, c16, smem, lds_base, m0, wave, lane); return; }
+        if constexpr (FUSE == 4) { fused_chain128(a, c16, smem, lds_base, m0, wave, lane); return; }
         // epilogue of the 16x16 accumulators (lane: column l & 15, rows 4 (l >> 4) + r): scale / bias (+ residual) (ReLU), fp32
         // out; a row tile of 16 rows goes through a per-wave LDS slab (rows padded by 4 floats: the four row groups of a
         // ds_write_b32 land on different banks) and leaves as 16-byte stores
@@ -2161,21 +2235,27 @@ static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
     return 0;
 }
 
-static int launch_big_fused(const ConvGemmArgs& a, hipStream_t stream) {
+template <int MODE>
+static int launch_big_fused_as(const ConvGemmArgs& a, hipStream_t stream) {
     static const bool attr_ok = [] {
-        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 128, 4, 512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
-               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<3, 64, 4, 512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
+        return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, 64, 4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, 64, 4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, 128, 4, 512, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
+               hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, 64, 4, 512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     const int tiles = (a.M + 255) / 256;
-    if (a.Cout == 128) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 128, 4, 512, 3>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
-    else if (a.G_Wt3 && a.G_N == 128) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 4>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
-    else if (a.G_Wt3) hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 2>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
-    else hipLaunchKernelGGL((conv_gemm_big_kernel<3, 64, 4, 512, 1>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    if (a.Cout == 128) hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, 128, 4, 512, 3>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    else if (a.G_Wt3 && a.G_N == 128) hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, 64, 4, 512, 4>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    else if (a.G_Wt3) hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, 64, 4, 512, 2>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
+    else hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, 64, 4, 512, 1>), dim3(tiles), dim3(512), FUSE_LDS_BYTES, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
+}
+static int launch_big_fused(const ConvGemmArgs& a, hipStream_t stream) {
+    const int m16 = odam_cfg::get(odam_cfg::CG_MFMA16);      // 2: the 128-column bottleneck launches too, 3: the 64-column ones as well
+    const bool x16 = a.Kpad % 32 == 0 && (m16 >= 3 || (m16 == 2 && a.Cout == 128));
+    return x16 ? launch_big_fused_as<4>(a, stream) : launch_big_fused_as<3>(a, stream);
 }
 
 // bf16 bottleneck on the tile: (P, PN) combinations built -- P = 64: PN 0 / 64 / 128; P = 128: PN 0 / 128; P = 256: PN 0
@@ -2277,7 +2357,7 @@ bool fused_second_ok(const ConvGemmArgs& a) {
     if (!a.F_Wt3 || !a.F_C || !a.Wt3 || a.Kpad % 16 != 0) return false;
     const bool l1 = a.Cout == 64 && a.F_ldc == 256, l2 = a.Cout == 128 && a.F_ldc == 512 && !a.G_Wt3;     // the two shapes built
     if (!l1 && !l2) return false;
-    if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL) return false;
+    if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL || (long)a.M * a.F_ldc * 4 >= 0x7fffffffL) return false;      // buffer descriptors over the output / residual
     if (a.G_Wt3 && (fuse < 2 || !a.G_C || (a.G_N != 64 && a.G_N != 128))) return false;      // fuse 1: second layer only
     return big_eligible(a, a.Cout);
 }

@@ -15,7 +15,8 @@ enum Key {
     CG_TILES,       // bit 0: 8-wave 128x128 tiles, bit 1: 8-wave 128x64, bit 2: four-stage 64x64 (default 7)
     CG_FORCE,       // tests: pin one small tile shape (1: 128x64, 2: 64x64, 3: 4-wave 128x128; default 0)
     CG_PRESPLIT,    // fp32 split mode takes pre-split filters where the caller supplies them (default 1)
-    CG_MFMA16,      // fp32 split mode on v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it) instead of 32x32x16
+    CG_MFMA16,      // fp32 split mode on v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it) instead of 32x32x16: 0 off,
+                    // 1 plain layers, 2 + the 128-column bottleneck launches, 3 (default) + the 64-column ones
     ATT_X3,         // fp32 attention through the exact bf16 split (default 1; 0 = fp32 matrix instruction)
     ATT_BF16_MFMA,  // bf16 attention on the bf16 matrix instruction (default 1)
     STEM_ROWS,      // conv1 as a 7x1 row convolution on the ring kernel where it fills the device (default 1)

@@ -5,6 +5,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DCG_STAMP=1 -I odam_amd/csrc -o tests/native/ring_stamps tests/native/ring_stamps.hip
 //   ./tests/native/ring_stamps [bf16]     (-DCG_STAMP=0: plain timing, no stamps execute)
 #include "../../odam_amd/csrc/conv_gemm.hip"
+#include "../../odam_amd/csrc/odam_common.hip"
 #include <cstdio>
 #include <cstring>
 #include <random>
@@ -16,6 +17,7 @@ static unsigned short to_bf16(float v) { unsigned u; memcpy(&u, &v, 4); return (
 
 int main(int argc, char** argv) {
     const bool bf = argc > 1 && !strcmp(argv[1], "bf16");     // bf16 operands (MODE 0) instead of fp32 through the split
+    if (argc > 1 && !strcmp(argv[1], "x16")) odam_cfg::set(odam_cfg::CG_MFMA16, 1);      // the 16x16x32 schedule (MODE 4)
     const Shape shapes[] = {{"l3.c2", 32, 50, 67, 256, 256, 3, 1}, {"l4.c2", 32, 25, 34, 512, 512, 3, 1},
                             {"l3.c1", 32, 50, 67, 1024, 256, 1, 0}, {"l4.c1", 32, 50, 67, 1024, 512, 1, 0},
                             {"l2.c2", 32, 100, 134, 128, 128, 3, 1}, {"l2.c1", 32, 100, 134, 512, 128, 1, 0},
