@@ -56,6 +56,22 @@ int odam_assoc_info(odam_assoc* m, int* persistent, int* resident_capacity, int*
  * (tests of the fallback path) */
 int odam_assoc_set_barrier_timeout_us(odam_assoc* m, long long us);
 
+/* ---- device-resident track windows: the device side of OdamProcess._preprocess_tracks (src/processor.py:133-170) ----
+ * The observations of every live track stay on the device in the world frame (14 float64 each: frame id, class, bbox px x4,
+ * dims x3, t_wo x3, az_wo, score = columns 0-13 of a track row, layout src/processor.py:98-108); _build writes the
+ * associator's track input [T][79][window] float32 for the current camera from them.
+ *   _append: n <= 32 observations of one frame; track_ids [host][n] (every id < max_tracks; a new track simply uses the next
+ *            id), rows14 [host][n][14].  Within one call every id occurs at most once (a frame adds one observation per track).
+ *   _build:  proj_px [dev][T][4] float64 (odam_sq_project_extents), cam15 [host][15] = rows 0..2 of inv(T_wc) (12), the camera's
+ *            azimuth, img_w, img_h; out [dev][T][79][window].
+ * Stream-ordered; host arrays are copied before the call returns. */
+typedef struct odam_trackwin odam_trackwin;
+int odam_trackwin_create(int max_tracks, int window, odam_trackwin** out);
+int odam_trackwin_destroy(odam_trackwin* w);
+int odam_trackwin_reset(odam_trackwin* w, void* stream);
+int odam_trackwin_append(odam_trackwin* w, int n, const int* track_ids, const double* rows14, void* stream);
+int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_px, const double* cam15, float* out, void* stream);
+
 /* diagnostics of the persistent matching kernel: enable != 0 makes the following forwards record a 100 MHz timestamp of
  * workgroup 0 at kernel start and after every stage (5 per GNN layer, final projection, score matrix, Sinkhorn loop);
  * out [host][n <= 128], if not null, receives the stamps of the last forward (synchronises the device). */

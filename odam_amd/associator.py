@@ -25,7 +25,67 @@ def hungarian_matching(scores, matching_threshold):  # associator.py:19-35
     return match
 
 
+class TrackWindows:
+    """Device-resident observations of the live tracks (include/odam_assoc.h, odam_trackwin_*): what
+    OdamProcess._preprocess_tracks (src/processor.py:133-170) rebuilds on the host every frame is built by one launch here."""
+
+    WINDOW = 100
+
+    def __init__(self, device="cuda:0", max_tracks=1024):
+        self.device = torch.device(device)
+        self.max_tracks = max_tracks
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().odam_trackwin_create(max_tracks, self.WINDOW, ctypes.byref(self._h)), "odam_trackwin_create")
+        self.lengths = []           # observations per track, as appended (the host's check against its own track list)
+
+    def _stream(self):
+        return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self):
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().odam_trackwin_reset(self._h, self._stream()), "odam_trackwin_reset")
+        self.lengths = []
+
+    def append(self, track_ids, rows82):
+        """rows82 [n, 82] float64 track rows (processor.py:98-108); track_ids [n]: existing index or len(lengths) + j for new ones"""
+        rows = np.ascontiguousarray(np.asarray(rows82, np.float64)[:, :14])
+        ids = np.ascontiguousarray(track_ids, np.int32)
+        for i0 in range(0, len(ids), 32):
+            n = min(32, len(ids) - i0)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().odam_trackwin_append(self._h, ctypes.c_int(n), ids[i0:].ctypes.data_as(ctypes.c_void_p),
+                                                           rows[i0:].ctypes.data_as(ctypes.c_void_p), self._stream()), "odam_trackwin_append")
+        for t in ids.tolist():
+            if t == len(self.lengths):
+                self.lengths.append(1)
+            else:
+                self.lengths[t] += 1
+
+    def build(self, proj_px_dev, T_cw, cam_azi, img_w, img_h):
+        T = len(self.lengths)
+        out = torch.empty(T, 79, self.WINDOW, device=self.device, dtype=torch.float32)
+        cam = np.ascontiguousarray(np.concatenate([np.asarray(T_cw, np.float64)[:3].reshape(-1), [cam_azi, img_w, img_h]]))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().odam_trackwin_build(self._h, ctypes.c_int(T), _lib.ptr(proj_px_dev), cam.ctypes.data_as(ctypes.c_void_p),
+                                                      _lib.ptr(out), self._stream()), "odam_trackwin_build")
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().odam_trackwin_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Associator:
+    native_windows = True       # OdamProcess may hand this associator a device tensor built by TrackWindows
+
     def __init__(self, config=None, max_tracks=256, device="cuda:0"):
         cfg = config or {"GNN_layers": ["self", "cross"] * 6, "self_GNN_layers": ["self"] * 4, "sinkhorn_iterations": 100}
         self.gnn_layers = list(cfg["GNN_layers"])

@@ -828,6 +828,130 @@ extern "C" int odam_assoc_set_barrier_timeout_us(odam_assoc* m, long long us) {
     return 0;
 }
 
+// ---- device-resident track windows (OdamProcess._preprocess_tracks, src/processor.py:133-170) --------------------------------
+// Every frame the reference rebuilds, on the host, the associator's track input [T, 79, 100]: the last 100 observations of every
+// live track moved into the CURRENT camera frame (centre through inv(T_wc), azimuth relative to the camera's, the box replaced
+// by the projected extent of the fitted surface).  At 40 tracks that is a 1.3 MB tensor built in numpy and uploaded per frame.
+// Here the observations stay on the device in the WORLD frame (append-only ring per track: 14 float64 per observation), and one
+// launch builds the tensor from them: the same float64 arithmetic per value, rounded to float32 once.
+struct odam_trackwin {
+    int max_tracks = 0, window = 0;
+    double* rows = nullptr;     // [max_tracks][window][14]: frame id, class, bbox px x4, dims x3, t_wo x3, az_wo, score
+    int* count = nullptr;       // [max_tracks] observations appended so far
+    double* stage = nullptr;    // pinned [8][32][14 + 1]: rows + track id of one append
+    double* d_stage = nullptr;  // device copy of one slot
+    double* d_cam = nullptr;    // [16]
+    unsigned slot = 0;
+};
+
+namespace {
+constexpr int TW_COLS = 14;
+__global__ void trackwin_append_kernel(const double* __restrict__ st, int n, double* __restrict__ rows, int* __restrict__ count, int window) {
+    const int i = blockIdx.x;
+    if (i >= n) return;
+    const int tid_ = (int)st[i * (TW_COLS + 1) + TW_COLS];
+    const int c = count[tid_];      // one block per observation; observations of one append go to different tracks
+    if (threadIdx.x < TW_COLS) rows[((size_t)tid_ * window + (c % window)) * TW_COLS + threadIdx.x] = st[i * (TW_COLS + 1) + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) count[tid_] = c + 1;
+}
+
+// out [T][79][window] float32; cam: T_cw rows 0..2 (12), cam_azi, img_w, img_h
+__global__ __launch_bounds__(128) void trackwin_build_kernel(const double* __restrict__ rows, const int* __restrict__ count, int window,
+                                                             const double* __restrict__ proj_px, const double* __restrict__ cam,
+                                                             float* __restrict__ out) {
+    const int t = blockIdx.x, l = threadIdx.x;
+    if (l >= window) return;
+    const int c = count[t], k = c < window ? c : window;
+    float* o = out + (size_t)t * 79 * window + l;
+    if (l >= k) {
+#pragma unroll 1
+        for (int ch = 0; ch < 79; ch++) o[(size_t)ch * window] = -1.0f;
+        return;
+    }
+    const double* r = rows + ((size_t)t * window + ((c - k + l) % window)) * TW_COLS;
+    const double iw = cam[13], ih = cam[14];
+    auto clip = [](double x) { return x < -1.0 ? -1.0 : (x > 2.0 ? 2.0 : x); };
+    double v[15];
+    v[0] = r[0]; v[1] = r[1];
+    v[2] = clip(proj_px[t * 4 + 0] / iw); v[3] = clip(proj_px[t * 4 + 1] / ih);
+    v[4] = clip(proj_px[t * 4 + 2] / iw); v[5] = clip(proj_px[t * 4 + 3] / ih);
+    v[6] = r[6]; v[7] = r[7]; v[8] = r[8];
+    const double x = r[9], y = r[10], z = r[11];
+    v[9] = x * cam[0] + y * cam[1] + z * cam[2] + cam[3];
+    v[10] = x * cam[4] + y * cam[5] + z * cam[6] + cam[7];
+    v[11] = x * cam[8] + y * cam[9] + z * cam[10] + cam[11];
+    const double rel = r[12] - cam[12];
+    v[12] = sin(rel); v[13] = cos(rel);
+    v[14] = r[13];
+#pragma unroll
+    for (int ch = 0; ch < 15; ch++) o[(size_t)ch * window] = (float)v[ch];
+#pragma unroll 1
+    for (int ch = 15; ch < 79; ch++) o[(size_t)ch * window] = -1.0f;
+}
+}  // namespace
+
+extern "C" int odam_trackwin_create(int max_tracks, int window, odam_trackwin** out) {
+    if (!out || max_tracks < 1 || max_tracks > 4096 || window < 1 || window > 128) return odam_fail(1, "odam_trackwin_create: bad argument");
+    odam_trackwin* w = new odam_trackwin();
+    w->max_tracks = max_tracks; w->window = window;
+    if (hipMalloc((void**)&w->rows, sizeof(double) * (size_t)max_tracks * window * TW_COLS) != hipSuccess ||
+        hipMalloc((void**)&w->count, sizeof(int) * (size_t)max_tracks) != hipSuccess ||
+        hipMalloc((void**)&w->d_stage, sizeof(double) * 32 * (TW_COLS + 1)) != hipSuccess ||
+        hipMalloc((void**)&w->d_cam, sizeof(double) * 16) != hipSuccess ||
+        hipHostMalloc((void**)&w->stage, sizeof(double) * 8 * 32 * (TW_COLS + 1), hipHostMallocDefault) != hipSuccess ||
+        hipMemset(w->count, 0, sizeof(int) * (size_t)max_tracks) != hipSuccess) {
+        if (w->rows) (void)hipFree(w->rows);
+        if (w->count) (void)hipFree(w->count);
+        if (w->d_stage) (void)hipFree(w->d_stage);
+        if (w->d_cam) (void)hipFree(w->d_cam);
+        if (w->stage) (void)hipHostFree(w->stage);
+        delete w;
+        return odam_fail(2, "odam_trackwin_create: allocation failed");
+    }
+    *out = w;
+    return 0;
+}
+
+extern "C" int odam_trackwin_destroy(odam_trackwin* w) {
+    if (!w) return 0;
+    (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->stage);
+    delete w;
+    return 0;
+}
+
+extern "C" int odam_trackwin_reset(odam_trackwin* w, void* stream) {
+    if (!w) return odam_fail(1, "odam_trackwin_reset: null handle");
+    ODAM_HIP(hipMemsetAsync(w->count, 0, sizeof(int) * (size_t)w->max_tracks, (hipStream_t)stream));
+    return 0;
+}
+
+extern "C" int odam_trackwin_append(odam_trackwin* w, int n, const int* track_ids, const double* rows14, void* stream) {
+    if (!w || n < 0 || n > 32 || (n && (!track_ids || !rows14))) return odam_fail(1, "odam_trackwin_append: bad argument (at most 32 observations per call)");
+    if (n == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    double* slot = w->stage + (size_t)(w->slot++ & 7) * 32 * (TW_COLS + 1);
+    for (int i = 0; i < n; i++) {
+        if (track_ids[i] < 0 || track_ids[i] >= w->max_tracks) return odam_fail(3, "odam_trackwin_append: track id outside the handle's capacity");
+        for (int c = 0; c < TW_COLS; c++) slot[i * (TW_COLS + 1) + c] = rows14[i * TW_COLS + c];
+        slot[i * (TW_COLS + 1) + TW_COLS] = (double)track_ids[i];
+    }
+    ODAM_HIP(hipMemcpyAsync(w->d_stage, slot, sizeof(double) * (size_t)n * (TW_COLS + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(trackwin_append_kernel, dim3(n), dim3(64), 0, st, w->d_stage, n, w->rows, w->count, w->window);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
+extern "C" int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_px, const double* cam15, float* out, void* stream) {
+    if (!w || T < 0 || T > w->max_tracks || (T && (!proj_px || !cam15 || !out))) return odam_fail(1, "odam_trackwin_build: bad argument");
+    if (T == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    ODAM_HIP(hipMemcpyAsync(w->d_cam, cam15, sizeof(double) * 15, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(trackwin_build_kernel, dim3(T), dim3(128), 0, st, w->rows, w->count, w->window, proj_px, w->d_cam, out);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}
+
 // diagnostics: run the next forwards with stage stamps (enable != 0), or read the stamps of the last one: out[0..n) =
 // 100 MHz timer of workgroup 0 at kernel start and after every stage of the persistent matching kernel
 extern "C" int odam_assoc_stage_stamps(odam_assoc* m, int enable, unsigned long long* out, int n) {

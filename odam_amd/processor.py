@@ -108,6 +108,8 @@ class OdamProcess:
         self.T_wcs = []
         self.P_cws = []
         self.usable_frames = []
+        if getattr(self, "_win", None) is not None:
+            self._win.reset()
 
     # ---- detection (processor.py:259-289) ----------------------------------------------------------
     def detect_frames(self, rgbs, frame_ids):
@@ -173,6 +175,26 @@ class OdamProcess:
         """processor.py:95-131: every detection of the first frame with detections starts a track"""
         return [r[None, :] for r in self._track_rows(detections, T_wc, with_code=False)]
 
+    # ---- device-resident track windows (odam_amd.associator.TrackWindows) ------------------------------------------------
+    def _windows(self):
+        """the device mirror of self.tracks' observations, or None where it does not apply (a caller-supplied associator
+        or fitter without the native entry points, shape codes in use, more tracks than the native store holds)"""
+        if not (getattr(self.associator, "native_windows", False) and self.no_code and hasattr(self._fitter(), "project_extents")):
+            return None
+        if getattr(self, "_win", None) is None:
+            from .associator import TrackWindows
+            self._win = TrackWindows(str(getattr(self.associator, "device", "cuda:0")))
+        w = self._win
+        if len(self.tracks) > w.max_tracks:
+            return None
+        if w.lengths != [len(t) for t in self.tracks]:        # first use, or somebody edited self.tracks: rebuild the mirror
+            w.reset()
+            longest = max((len(t) for t in self.tracks), default=0)
+            for j in range(longest):                          # observation j of every track that has one: ids stay unique per call
+                ids = [i for i, t in enumerate(self.tracks) if len(t) > j]
+                w.append(ids, np.stack([self.tracks[i][j] for i in ids]))
+        return w
+
     def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100, proj_px=None):
         """processor.py:133-170: the last `n_times` observations of every track in the CURRENT camera frame,
         [T, n_times, 79] float32 padded with -1.  All observations of all tracks go through numpy at once (the
@@ -218,6 +240,13 @@ class OdamProcess:
         params[:, 4:7] = np.sqrt(params[:, 4:7] / 2)
         params = params.astype(np.float32)
         fitter = self._fitter()
+        win = self._windows() if len(tracks) else None
+        if win is not None:
+            # everything after the per-track means on the device: surface extents (odam_sq_project_extents), then the
+            # [T, 79, n_times] window tensor in the current camera frame (odam_trackwin_build) -- nothing comes back to the host
+            T_cw = np.linalg.inv(T_wc)
+            proj_dev = fitter.project_extents(params, T_cw, self.sequence_meta.K, on_device=True)
+            return win.build(proj_dev, T_cw, cam_azi, self.sequence_meta.img_w, self.sequence_meta.img_h)
         if len(tracks) and hasattr(fitter, "project_extents"):
             # surface points, camera transform, projection and min / max on the device (odam_sq_project_extents): the same
             # float64 products per point as below; 32 bytes per track come back
@@ -260,13 +289,21 @@ class OdamProcess:
         """processor.py:212-257: a matched detection extends its track, an unmatched one (-1) starts a new one;
         matches scoring below `score_threshold` are dropped (index -1 reads the dustbin row, as in the reference)."""
         rows = self._track_rows(detections, T_wc, with_code=not self.no_code)
+        win = getattr(self, "_win", None)
+        in_step = win is not None and win.lengths == [len(t) for t in self.tracks]      # the device mirror matches the tracks as they stand
+        ids, picked = [], []
         for det_id, track_id in enumerate(pred_match):
             if score_mat[track_id, det_id] < self.score_threshold:
                 continue
             if track_id == -1:
+                ids.append(len(self.tracks))
                 self.tracks.append(rows[det_id:det_id + 1])
             else:
+                ids.append(int(track_id))
                 self.tracks[track_id] = np.concatenate([self.tracks[track_id], rows[det_id:det_id + 1]], axis=0)
+            picked.append(det_id)
+        if in_step and ids and len(set(ids)) == len(ids) and max(ids) < win.max_tracks:
+            win.append(ids, rows[picked])       # keep the mirror in step (whenever it is not, _windows() rebuilds it from self.tracks)
 
     # ---- per-frame driver (processor.py:306-345) ---------------------------------------------------
     def process_frame(self, rgb, frame_id, T_wc, detections=None):

@@ -213,7 +213,7 @@ class SqFitter:
         return out
 
 
-def _project_extents(self, params, T_cw, K):
+def _project_extents(self, params, T_cw, K, on_device=False):
     """[n,9] parameter rows -> [n,4] float64 (x_min, y_min, x_max, y_max) of each surface projected with K @ T_cw[:3]
     (OdamProcess._prepare_tracks, processor.py:181-207), computed on the device"""
     dev = self.device
@@ -231,7 +231,7 @@ def _project_extents(self, params, T_cw, K):
         ev = torch.cuda.Event()
         ev.record(cur)
         self._last = (stream, ev)
-    return out.cpu().numpy()
+    return out if on_device else out.cpu().numpy()
 
 
 SqFitter.project_extents = _project_extents
