@@ -108,6 +108,7 @@ class OdamProcess:
         self.T_wcs = []
         self.P_cws = []
         self.usable_frames = []
+        self._sum_cache = []
         if getattr(self, "_win", None) is not None:
             self._win.reset()
 
@@ -232,11 +233,33 @@ class OdamProcess:
         # parameters as sq.init_params builds them: mean centre, mean azimuth, sqrt(mean dims / 2), shapes -0
         params = np.zeros((len(tracks), 9))
         params[:, 7:] = -0.0
+        # np.mean = np.add.reduce / n.  Over axis 0 of an [n, 3] block numpy adds the rows one after the other, so a running sum
+        # per track (extended by the rows a frame appends) gives the same bits as reducing the whole track again; the 1-D
+        # azimuth column is reduced pairwise by numpy and is therefore reduced afresh.
+        cache = getattr(self, "_sum_cache", None)
+        if cache is None:
+            cache = self._sum_cache = []
+        del cache[len(tracks):]
         for i, track in enumerate(tracks):
-            n = len(track)                       # np.mean = np.add.reduce / n, without mean()'s Python overhead
-            params[i, :3] = np.add.reduce(track[:, 9:12], axis=0) / n
+            n = len(track)
+            if i < len(cache) and cache[i][0] == n:
+                _, s_t, s_d = cache[i][:3]
+            elif i < len(cache) and 0 < cache[i][0] < n and cache[i][3] == (track[0, 0], track[cache[i][0] - 1, 0]):
+                k, s_t, s_d = cache[i][:3]
+                s_t = s_t.copy(); s_d = s_d.copy()
+                for r in range(k, n):
+                    s_t += track[r, 9:12]; s_d += track[r, 6:9]
+                cache[i] = (n, s_t, s_d, (track[0, 0], track[n - 1, 0]))
+            else:
+                s_t = np.add.reduce(track[:, 9:12], axis=0); s_d = np.add.reduce(track[:, 6:9], axis=0)
+                entry = (n, s_t, s_d, (track[0, 0], track[n - 1, 0]))
+                if i < len(cache):
+                    cache[i] = entry
+                else:
+                    cache.append(entry)
+            params[i, :3] = s_t / n
             params[i, 3] = np.add.reduce(track[:, 12], axis=0) / n
-            params[i, 4:7] = np.maximum(np.add.reduce(track[:, 6:9], axis=0) / n, 0.05)    # np.clip(., 0.05, inf)
+            params[i, 4:7] = np.maximum(s_d / n, 0.05)    # np.clip(., 0.05, inf)
         params[:, 4:7] = np.sqrt(params[:, 4:7] / 2)
         params = params.astype(np.float32)
         fitter = self._fitter()
