@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (host-resident frames, shard of 8, with association)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] block (R101, bf16, 50 objects)")
+    ap.add_argument("--config4-streams", type=int, default=2, help="HIP streams of the configs[3] block")
+    ap.add_argument("--config4-batch", type=int, default=76, help="frames per forward of the configs[3] block")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo + "
                     "--one-device let several ranks share one GPU for a functional check of the N > 1 path")
     ap.add_argument("--one-device", action="store_true")
@@ -472,12 +474,16 @@ def config4_block(device, args, pmc):
     """BASELINE configs[3]: DETR-R101, 800x600 input (-> 800x1066), bf16 weights / activations on the bf16 matrix
     instruction, a 50-object scene for the fit.  A short sample of the same step as the headline line: 256 resident
     raw frames through transform + forward + post-processing + host NMS / rows, then two fit passes over 50 objects."""
-    n_frames, n_obj, B = 256, 50, 32
-    det = det_mod.Detector(backbone="resnet101", max_batch=B, device=device, n_streams=2, dtype="bf16")
+    # 76 frames per forward: the ring kernels run one 256-row tile per CU at a time, and at 76 frames layer3 / layer4 / the
+    # encoder are 3.9 / 1.98 rounds of 256 tiles (at 32: 1.64 and 0.84 -- the last round a third empty); one forward alone:
+    # 0.529 ms per frame at 76 against 0.598 at 32 (tests/native/perf_batch_sweep.py, profiles/r3_batch_sweep.txt)
+    B = args.config4_batch
+    n_frames, n_obj = 8 * B, 50
+    det = det_mod.Detector(backbone="resnet101", max_batch=B, device=device, n_streams=args.config4_streams, dtype="bf16")
     det.load_state_dict(weights.make_state_dict(backbone="resnet101", seed=0, scene=True))
     fitter = sq.SqFitter(device, 200)
     base = np.stack(list(synth.make_frames(32, h=600, w=800, seed=4)))
-    frames = torch.from_numpy(np.concatenate([base] * (n_frames // 32))).to(device)
+    frames = torch.from_numpy(np.concatenate([base] * ((n_frames + 31) // 32))[:n_frames]).to(device)
     K = np.array([[722.3, 0.0, 399.5], [0.0, 722.3, 299.5], [0.0, 0.0, 1.0]])
     H, W = transforms.target_size(800, 600)
     scene = synth.make_scene(1000, n_obj, seed=2, min_views=10, max_views=300)
@@ -508,8 +514,8 @@ def config4_block(device, args, pmc):
     det.profile(H, W, False)
     det.close(); fitter.close()
     fps_det = n_frames / (t1 - t0)
-    return {"workload": "DETR-R101, %d frames 800x600 -> 800x1066, bf16 (fp32 accumulate / softmax / LayerNorm / heads), batches of %d on 2 "
-                        "streams + 2 passes of 200-step SQ fit over %d objects (fp32)" % (n_frames, B, len(scene["tracks"])),
+    return {"workload": "DETR-R101, %d frames 800x600 -> 800x1066, bf16 (fp32 accumulate / softmax / LayerNorm / heads), batches of %d on %d "
+                        "streams + 2 passes of 200-step SQ fit over %d objects (fp32)" % (n_frames, B, args.config4_streams, len(scene["tracks"])),
             "dtype": "bf16", "frames_per_s_detect": fps_det, "fit_ms_two_passes": 1e3 * (t2 - t1),
             "frames_per_s_scene_of_1000": 1000.0 / (1000.0 / fps_det + (t2 - t1)),
             "detections_per_frame": n_det / n_frames,

@@ -1808,7 +1808,15 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
                 }
 #pragma unroll
                 for (; dpart < ((b + 1) * NDMA + NBLK - 1) / NBLK; dpart++) {
-                    const int half_ = dpart / (A_LD + B3_HI), part = dpart - half_ * (A_LD + B3_HI);
+                    // the two stages of a pair are the two 64-byte halves of the same 128-byte lines (32 consecutive channels of
+                    // a pixel): the same rows of both stages are requested back to back, so the second request meets the line
+                    // in the CU's L1 (or its miss in flight) instead of fetching it from L2 again a stage later (layer3 /
+                    // layer4 of the forward: 192.7 -> 202.2 and 211.3 -> 219.8 TFLOP/s, profiles/r3_detr_forward_B32_f32split_per_layer.txt).
+                    // (A ring of THREE pairs for the 64-column tiles, whose pair is shorter than an L2 round trip, took the
+                    // wait at the vmcnt from 1,349 to 106 cycles per 16 k and left the layer's time where it was: the wave
+                    // is paced by issuing the DMAs, ~150 cycles each, not by their latency.  Gone.)
+                    const int half_ = dpart < 2 * A_LD ? (dpart & 1) : (dpart - 2 * A_LD) / B3_HI;
+                    const int part = dpart < 2 * A_LD ? (dpart >> 1) : A_LD + (dpart - 2 * A_LD) % B3_HI;
                     dma_part16(2 * kp + 2 + half_, (s0 ^ 2) + half_, part);
                 }
                 __builtin_amdgcn_sched_barrier(0);      // (without the fence: +2 % time; static priority for waves 4-7: no change)
@@ -2154,6 +2162,35 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
             }
             s1_done = true;
         }
+    }
+    if (BF16 && NST == 4 && !s1_done) {
+        // bf16, tiles in PAIRS: k-tiles 2 kp and 2 kp + 1 are the two 64-byte halves of the same 128-byte lines, and their DMAs
+        // go out together (the same rows of both back to back), all during the first tile of the pair before; one wait and
+        // one barrier per pair.  Against one tile per barrier with three tiles in flight (same box, tests/native/
+        // perf_conv_shape.py bf16, two interleaved runs each): expand layers +2-3 % (layer2 199 -> 203, layer3 329 -> 340
+        // TFLOP/s), the 3x3 of layer3 / layer4 when run alone +2.5 %, reduce layers unchanged.
+        {
+            const TilePrep t0 = tile_prep(0), t1 = tile_prep(nk > 1 ? 1 : 0);
+#pragma unroll
+            for (int part = 0; part < LPT; part++) {
+                dma_part(t0, 0, part);
+                if (nk > 1) dma_part(t1, 1, part);
+            }
+        }
+        for (int kp = 0; 2 * kp < nk; ++kp) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int s0 = (2 * kp) & 3;
+            const bool more0 = 2 * kp + 2 < nk, more1 = 2 * kp + 3 < nk;
+            const TilePrep ta = tile_prep(more0 ? 2 * kp + 2 : 0), tb = tile_prep(more1 ? 2 * kp + 3 : 0);
+            mma_tile(s0, [&](int part) {
+                if (more0) dma_part(ta, s0 ^ 2, part);
+                if (more1) dma_part(tb, (s0 ^ 2) + 1, part);
+            });
+            if (2 * kp + 1 < nk) mma_tile(s0 + 1, [](int) {});
+        }
+        s1_done = true;
     }
     if (!s1_done) {
 #pragma unroll

@@ -1,5 +1,6 @@
-for cfg in "32 2" "48 2" "64 2" "32 3" "64 3"; do set -- $cfg
-python bench.py --batch $1 --streams $2 --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python -c "
+cd $GRAFT_REPO_ROOT
+python3 tests/native/perf_batch_sweep.py fp32 resnet50 32 38 48 64 76 77 2>&1 | grep -v amdgpu
+python3 tests/native/perf_batch_sweep.py bf16 resnet101 32 38 64 76 77 2>&1 | grep -v amdgpu
+for b in 32 38 77; do python3 bench.py --batch $b --steps 2 --warmup 1 --no-cpu-baseline --no-config4 --no-secondary 2>/dev/null | python3 -c "
 import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('B $1 streams $2: %.1f frames/s, detect %.1f ms' % (d['value'], d['roofline']['detection_phase_ms_per_step']))"
-done
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print('bench batch', d['config'].get('detector_batch'), d['value'], d['detect_only_frames_per_s_per_gpu'], d['roofline']['frac'])"; done
