@@ -5,7 +5,7 @@ scene, BASELINE.json configs[1] (1 GPU) / configs[2] (frames sharded over N GPUs
 One "step" = one pass of the hot path over one scene:
   detect all frames of this rank's shard (inputs resident in HBM as decoded uint8 [480,640,3] frames; the
   reference transform -- PIL-bilinear resize to 800x1066, /255, normalise -- runs on the device, then the forward in
-  batches of 32 on two HIP streams, per-query post-processing on device, threshold + NMS + row packing on the host)
+  batches of 32 on three HIP streams, per-query post-processing on device, threshold + NMS + row packing on the host)
   -> all-gather of detections (N > 1) -> super-quadric fit of this rank's objects, twice (run_processor.py:81-83
   runs optim -> merge -> optim; the merge itself is outside the hot path) -> all-gather of fitted parameters.
 value = frames of the WHOLE scene x steps / wall time (max over ranks).  Strong scaling: the scene is fixed.
@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary blocks (host-resident frames, shard of 8, with association)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] block (R101, bf16, 50 objects)")
-    ap.add_argument("--config4-streams", type=int, default=2, help="HIP streams of the configs[3] block")
+    ap.add_argument("--config4-streams", type=int, default=3, help="HIP streams of the configs[3] block")
     ap.add_argument("--config4-batch", type=int, default=76, help="frames per forward of the configs[3] block")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo + "
                     "--one-device let several ranks share one GPU for a functional check of the N > 1 path")
@@ -112,7 +112,10 @@ def main():
     if args.batch <= 0:
         args.batch = 32   # best at every shard size measured (125 ... 1000 frames, tests/native/sweep_shard.sh)
     if args.streams <= 0:
-        args.streams = 2 if args.batch >= 16 else 3
+        # the ring kernels hold a CU's whole LDS, so streams mix at workgroup granularity: with three, more CUs are in different
+        # phases of different layers at any moment (tests/native/sweep_streams.sh, same box: 2 / 3 / 4 streams = 1006 / 1020 /
+        # 1004 frames/s; configs[3]: 1856 / 1932 / 1935)
+        args.streams = 3
     args.chunk = args.chunk or 4 * args.batch
     detector = det_mod.Detector(max_batch=args.batch, device=device, n_streams=args.streams)
     # scene weights: calibrated batch-norm statistics + centred heads -> 10-25 detections per frame after NMS, so the
