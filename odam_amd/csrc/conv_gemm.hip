@@ -1405,8 +1405,9 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
-    const int ring = NST * (MODE >= 3 ? 256 * 64 + 96 * BN : (256 + BN) * 64);
-    const int wm = MODE >= 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
+    const int bm = MODE >= 3 ? NTH / 2 : 256;      // pre-split filters: 32 rows per wave for 64- / 128-column tiles (4 / 8 / 16 waves: 128 / 256 / 512 rows)
+    const int ring = NST * (MODE >= 3 ? bm * 64 + 96 * BN : (256 + BN) * 64);
+    const int wm = MODE >= 3 ? (BN == 256 ? 4 : NTH / 64) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
     const int wn = NTH / 64 / wm;
     const int slab = (NTH / 64) * 32 * (BN / wn) * 4;
     const int s1 = (MODE == 0 && NTH == 512) ? (BN == 256 ? 2 : (BN == 128 ? 3 : 4)) * (384 * 64 + 3 * BN * 64) : 0;   // the 3x3 stride-1 window ring (bf16)
@@ -1415,7 +1416,7 @@ constexpr int big_lds_bytes() {
 }
 
 template <int MODE, int BN, int NST, int NTH = 512, int FUSE = 0>     // FUSE: 1 = second layer on the tile (F_*), 2 = and a third (G_*)
-__global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
+__global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kernel(ConvGemmArgs a) {
     static_assert(!FUSE || (FUSE <= 4 && (MODE == 3 || MODE == 4) && NTH == 512 && ((FUSE != 3 && BN == 64) || (FUSE == 3 && BN == 128))) ||
                       (FUSE >= 5 && FUSE <= 8 && MODE == 0 && NTH == 512 && NST == 4),
                   "fused layers: pre-split filters with 64-column tiles (FUSE 1, 2, 4) or 128-column tiles (FUSE 3); bf16 (FUSE 5 + "
@@ -1430,13 +1431,14 @@ __global__ __launch_bounds__(NTH) void conv_gemm_big_kernel(ConvGemmArgs a) {
     // -- a third of the vector work of MODE 2.
     constexpr bool PRE = MODE == 3 || MODE == 4;
     constexpr bool X16 = MODE == 4;          // pre-split filters, v_mfma_f32_16x16x32_bf16: see the main loop
-    static_assert(!PRE || NTH == 512, "pre-split filters: eight-wave workgroups");
+    static_assert(!PRE || NTH == 512 || (X16 && FUSE == 0 && NTH == 1024 && BN == 64),
+                  "pre-split filters: eight-wave workgroups, or sixteen waves on 512 x 64 tiles (16x16x32 loop, plain layers)");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
-    constexpr int BM = 256, BKE = 4 * EPC;
+    constexpr int BM = PRE ? NTH / 2 : 256, BKE = 4 * EPC;
     constexpr int KU = 2 * BKE;             // channels per unit of the chunk-major K order (conv_gemm.h k_order)
     constexpr int NW = NTH / 64;
-    constexpr int WM = PRE ? (BN == 256 ? 4 : 8)
+    constexpr int WM = PRE ? (BN == 256 ? 4 : NW)
                            : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4)), WN = NW / WM;
     // NTH = 256 with BN = 256: one wave per SIMD owns 128 x 128 (256 accumulator registers of the 512 a lone wave may use)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -2266,7 +2268,8 @@ static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
-    const int tiles = ((a.M + 255) / 256) * ((a.Cout + BN - 1) / BN);
+    constexpr int bm = MODE >= 3 ? NTH / 2 : 256;
+    const int tiles = ((a.M + bm - 1) / bm) * ((a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, BN, NST, NTH>), dim3(tiles), dim3(NTH), bytes, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;
@@ -2448,6 +2451,12 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
             return bf ? launch_big<0, 128, 4>(a, stream)
                       : (pre ? (x16 ? launch_big<4, 128, 4>(a, stream) : launch_big<3, 128, 4>(a, stream)) : launch_big<2, 128, 4>(a, stream));
         } else if (x3 && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
+            // Sixteen waves on 512 x 64 tiles (cg.tiles bit 3): the 64-column loop uses ~105 registers, so FOUR waves fit a SIMD, and a
+            // wave of this loop spends more time issuing (5 DMAs of ~150 cycles, two 44-instruction splits, 28 LDS reads per 768
+            // cycles of matrix work) than the pipe needs -- with four per SIMD the pipe finds a ready wave more often, and the
+            // filter tile is fetched once per 512 rows.  conv1: 1.44 -> 1.15 ms per 32 frames (same box, A/B by config).
+            // (128-row tiles with two 4-wave workgroups per CU = the same two waves per SIMD: measured no change, not kept.)
+            if (x16 && (odam_cfg::get(odam_cfg::CG_TILES) & 8)) return launch_big<4, 64, 4, 1024>(a, stream);
             return pre ? (x16 ? launch_big<4, 64, 4>(a, stream) : launch_big<3, 64, 4>(a, stream)) : launch_big<2, 64, 4>(a, stream);
         } else if (bf && (g_big_mode >= 2 || (a.lda > 0 && a.lda < a.Cin)) && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
             return launch_big<0, 64, 4>(a, stream);     // conv1 as a row convolution (pixel stride < row length); tests: layer1's 3x3 alone
