@@ -1405,9 +1405,9 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
-    const int bm = MODE >= 3 ? NTH / 2 : 256;      // pre-split filters: 32 rows per wave for 64- / 128-column tiles (4 / 8 / 16 waves: 128 / 256 / 512 rows)
-    const int ring = NST * (MODE >= 3 ? bm * 64 + 96 * BN : (256 + BN) * 64);
-    const int wm = MODE >= 3 ? (BN == 256 ? 4 : NTH / 64) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
+    const int bm = NTH == 1024 ? 512 : 256;      // sixteen waves: 512 x 64 tiles, 32 rows per wave
+    const int ring = NST * (MODE >= 3 ? bm * 64 + 96 * BN : (bm + BN) * 64);
+    const int wm = NTH == 1024 ? 16 : MODE >= 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
     const int wn = NTH / 64 / wm;
     const int slab = (NTH / 64) * 32 * (BN / wn) * 4;
     const int s1 = (MODE == 0 && NTH == 512) ? (BN == 256 ? 2 : (BN == 128 ? 3 : 4)) * (384 * 64 + 3 * BN * 64) : 0;   // the 3x3 stride-1 window ring (bf16)
@@ -1431,14 +1431,14 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     // -- a third of the vector work of MODE 2.
     constexpr bool PRE = MODE == 3 || MODE == 4;
     constexpr bool X16 = MODE == 4;          // pre-split filters, v_mfma_f32_16x16x32_bf16: see the main loop
-    static_assert(!PRE || NTH == 512 || (X16 && FUSE == 0 && NTH == 1024 && BN == 64),
-                  "pre-split filters: eight-wave workgroups, or sixteen waves on 512 x 64 tiles (16x16x32 loop, plain layers)");
+    static_assert(!PRE || NTH == 512 || (X16 && NTH == 1024), "pre-split filters: eight-wave workgroups, or sixteen waves (16x16x32 loop)");
+    static_assert(NTH != 1024 || (FUSE == 0 && BN == 64 && (X16 || BF16)), "sixteen waves: 512 x 64 tiles of the plain layers (bf16, or the 16x16x32 split loop)");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
-    constexpr int BM = PRE ? NTH / 2 : 256, BKE = 4 * EPC;
+    constexpr int BM = NTH == 1024 ? 512 : 256, BKE = 4 * EPC;
     constexpr int KU = 2 * BKE;             // channels per unit of the chunk-major K order (conv_gemm.h k_order)
     constexpr int NW = NTH / 64;
-    constexpr int WM = PRE ? (BN == 256 ? 4 : NW)
+    constexpr int WM = NTH == 1024 ? 16 : PRE ? (BN == 256 ? 4 : 8)
                            : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4)), WN = NW / WM;
     // NTH = 256 with BN = 256: one wave per SIMD owns 128 x 128 (256 accumulator registers of the 512 a lone wave may use)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -2268,7 +2268,7 @@ static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
-    constexpr int bm = MODE >= 3 ? NTH / 2 : 256;
+    constexpr int bm = NTH == 1024 ? 512 : 256;
     const int tiles = ((a.M + bm - 1) / bm) * ((a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, BN, NST, NTH>), dim3(tiles), dim3(NTH), bytes, stream, a);
     ODAM_HIP(hipGetLastError());
@@ -2459,6 +2459,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
             if (x16 && (odam_cfg::get(odam_cfg::CG_TILES) & 8)) return launch_big<4, 64, 4, 1024>(a, stream);
             return pre ? (x16 ? launch_big<4, 64, 4>(a, stream) : launch_big<3, 64, 4>(a, stream)) : launch_big<2, 64, 4>(a, stream);
         } else if (bf && (g_big_mode >= 2 || (a.lda > 0 && a.lda < a.Cin)) && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
+            if ((odam_cfg::get(odam_cfg::CG_TILES) & 8) && !(a.KH * a.KW == 9 && a.stride == 1)) return launch_big<0, 64, 4, 1024>(a, stream);
             return launch_big<0, 64, 4>(a, stream);     // conv1 as a row convolution (pixel stride < row length); tests: layer1's 3x3 alone
         }
     }
