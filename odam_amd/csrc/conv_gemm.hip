@@ -1402,14 +1402,25 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
     }
 }
 
+// Tile rows and wave grid of the ring kernel.  Eight waves on 256 rows is the general shape; the 64-column loops need ~100
+// registers, so sixteen waves on 512 x 64 put four waves on a SIMD (conv1: 1.44 -> 1.15 ms fp32, 0.95 -> 0.74 bf16).
+// (The 256-column split loop with 32-row wave tiles was built both as twelve waves on 192 x 256 -- 140 registers, three per
+// SIMD -- and as sixteen on 256 x 256 -- 126 registers, four per SIMD: the first loses to tile rounds what it gains (layer4's
+// 3x3: 284 tiles = two rounds, 583 -> 822 us; expand layers +3-8 %), the second measured the same as eight waves (forward
+// 29.76 vs 29.83 ms): that loop is paced by the matrix pipe and its barrier, not by waves waiting to issue.  Not kept.)
+constexpr int big_bm(int BN, int NTH) { return NTH == 1024 ? 512 : 256; }
+constexpr int big_wm(int MODE, int BN, int NTH) {
+    return NTH == 1024 ? 16
+         : MODE >= 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
+}
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
-    const int bm = NTH == 1024 ? 512 : 256;      // sixteen waves: 512 x 64 tiles, 32 rows per wave
+    const int bm = big_bm(BN, NTH);
     const int ring = NST * (MODE >= 3 ? bm * 64 + 96 * BN : (bm + BN) * 64);
-    const int wm = NTH == 1024 ? 16 : MODE >= 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
+    const int wm = big_wm(MODE, BN, NTH);
     const int wn = NTH / 64 / wm;
-    const int slab = (NTH / 64) * 32 * (BN / wn) * 4;
+    const int slab = MODE == 4 ? (NTH / 64) * 16 * (BN / wn + 4) * 4 : (NTH / 64) * 32 * (BN / wn) * 4;      // the 16x16x32 loop's epilogue: 16-row slabs, rows padded by 4
     const int s1 = (MODE == 0 && NTH == 512) ? (BN == 256 ? 2 : (BN == 128 ? 3 : 4)) * (384 * 64 + 3 * BN * 64) : 0;   // the 3x3 stride-1 window ring (bf16)
     const int m = ring > slab ? ring : slab;
     return m > s1 ? m : s1;
@@ -1435,11 +1446,10 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     static_assert(NTH != 1024 || (FUSE == 0 && BN == 64 && (X16 || BF16)), "sixteen waves: 512 x 64 tiles of the plain layers (bf16, or the 16x16x32 split loop)");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
-    constexpr int BM = NTH == 1024 ? 512 : 256, BKE = 4 * EPC;
+    constexpr int BM = big_bm(BN, NTH), BKE = 4 * EPC;
     constexpr int KU = 2 * BKE;             // channels per unit of the chunk-major K order (conv_gemm.h k_order)
     constexpr int NW = NTH / 64;
-    constexpr int WM = NTH == 1024 ? 16 : PRE ? (BN == 256 ? 4 : 8)
-                           : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4)), WN = NW / WM;
+    constexpr int WM = big_wm(MODE, BN, NTH), WN = NW / WM;
     // NTH = 256 with BN = 256: one wave per SIMD owns 128 x 128 (256 accumulator registers of the 512 a lone wave may use)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPP = NTH / 4;            // 128 tile rows per DMA pass (4 chunks of 16 bytes per row)
@@ -2252,7 +2262,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         fused_bf16<BN, FUSE == 5 ? 0 : (32 << (FUSE - 5))>(a, acc, smem, lds_base, m0, wm, wn, wave, lane);
         return;
     }
-    static_assert(WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>(),
+    static_assert(X16 || (WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>()),
                   "ring and epilogue staging fit the dynamic LDS");
     epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
 }
@@ -2268,7 +2278,7 @@ static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
-    constexpr int bm = NTH == 1024 ? 512 : 256;
+    constexpr int bm = big_bm(BN, NTH);
     const int tiles = ((a.M + bm - 1) / bm) * ((a.Cout + BN - 1) / BN);
     hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, BN, NST, NTH>), dim3(tiles), dim3(NTH), bytes, stream, a);
     ODAM_HIP(hipGetLastError());
@@ -2441,7 +2451,8 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         if (a.Cout % 256 == 0 || a.Cout >= 384) {
             if (big_eligible(a, 256))
                 return bf ? launch_big<0, 256, 4>(a, stream)
-                          : (pre ? (x16 ? launch_big<4, 256, 4>(a, stream) : launch_big<3, 256, 4>(a, stream)) : launch_big<2, 256, 4>(a, stream));
+                          : (pre ? (x16 ? launch_big<4, 256, 4>(a, stream)
+                                        : launch_big<3, 256, 4>(a, stream)) : launch_big<2, 256, 4>(a, stream));
 #ifndef CG_NO_BN128_FALLBACK
             // too few 256-wide tiles to fill the device (the encoder's N = 256 layers at M = 27,200: 107) but enough 128-wide
             // ones: the ring kernel on 256 x 128 tiles instead of the 128 x 128 tiles of the fp32 matrix instruction
