@@ -1408,9 +1408,9 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
 // SIMD -- and as sixteen on 256 x 256 -- 126 registers, four per SIMD: the first loses to tile rounds what it gains (layer4's
 // 3x3: 284 tiles = two rounds, 583 -> 822 us; expand layers +3-8 %), the second measured the same as eight waves (forward
 // 29.76 vs 29.83 ms): that loop is paced by the matrix pipe and its barrier, not by waves waiting to issue.  Not kept.)
-constexpr int big_bm(int BN, int NTH) { return NTH == 1024 ? 512 : 256; }
+constexpr int big_bm(int BN, int NTH) { return (NTH == 1024 && BN == 64) ? 512 : 256; }
 constexpr int big_wm(int MODE, int BN, int NTH) {
-    return NTH == 1024 ? 16
+    return NTH == 1024 ? (BN == 64 ? 16 : 4)      // bf16, 256 columns: sixteen waves of 64 x 64
          : MODE >= 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
 }
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     constexpr bool PRE = MODE == 3 || MODE == 4;
     constexpr bool X16 = MODE == 4;          // pre-split filters, v_mfma_f32_16x16x32_bf16: see the main loop
     static_assert(!PRE || NTH == 512 || (X16 && NTH == 1024), "pre-split filters: eight-wave workgroups, or sixteen waves (16x16x32 loop)");
-    static_assert(NTH != 1024 || (FUSE == 0 && BN == 64 && (X16 || BF16)), "sixteen waves: 512 x 64 tiles of the plain layers (bf16, or the 16x16x32 split loop)");
+    static_assert(NTH != 1024 || (FUSE == 0 && ((BN == 64 && (X16 || BF16)) || (BN == 256 && BF16))), "sixteen waves: plain layers (512 x 64: bf16 or the 16x16x32 split loop; 256 x 256: bf16)");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;       // elements per 16-byte chunk
     constexpr int BM = big_bm(BN, NTH), BKE = 4 * EPC;
@@ -2062,9 +2062,9 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         // The k order differs from the generic loop's (ky outside the two 32-channel halves of a chunk): same products, a
         // different but fixed summation order.
         const long tensor_bytes = (long)a.B * a.H * a.W * lda * 2;
-        const bool s1 = a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.k_order == 1 && a.Ho == a.H && a.Wo == a.W &&
+        const bool s1 = NTH == 512 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.k_order == 1 && a.Ho == a.H && a.Wo == a.W &&
                         tensor_bytes < 0x7fffffffL && a.s1_window != 0;
-        if (s1) {
+        if constexpr (NTH == 512) if (s1) {
             constexpr int NSS = BN == 256 ? 2 : (BN == 128 ? 3 : 4);
             constexpr int AW_BYTES = 384 * ROWB;                  // window region: 3 passes of 128 rows
             constexpr int STG = AW_BYTES + 3 * BN * ROWB;
@@ -2450,7 +2450,7 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
         const bool x16 = pre && odam_cfg::get(odam_cfg::CG_MFMA16) != 0 && (a.Cout & 3) == 0 && (a.ldc & 3) == 0 && a.Kpad % 32 == 0;   // 16x16x32 schedule
         if (a.Cout % 256 == 0 || a.Cout >= 384) {
             if (big_eligible(a, 256))
-                return bf ? launch_big<0, 256, 4>(a, stream)
+                return bf ? ((odam_cfg::get(odam_cfg::CG_TILES) & 16) && !(a.KH * a.KW == 9 && a.stride == 1) ? launch_big<0, 256, 4, 1024>(a, stream) : launch_big<0, 256, 4>(a, stream))
                           : (pre ? (x16 ? launch_big<4, 256, 4>(a, stream)
                                         : launch_big<3, 256, 4>(a, stream)) : launch_big<2, 256, 4>(a, stream));
 #ifndef CG_NO_BN128_FALLBACK
