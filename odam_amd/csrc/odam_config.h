@@ -13,7 +13,7 @@ enum Key {
     CG_S1,          // bf16 3x3 stride 1: one LDS window per (channel slice, ky) serves the three horizontal taps (default 1)
     CG_UT,          // uniform-tap LDS-DMA gather of the 128x128 / 128x64 / 64x64 tiles (default 1; 0 = register-staged gather)
     CG_TILES,       // bit 0: 8-wave 128x128 tiles, bit 1: 8-wave 128x64, bit 2: four-stage 64x64, bit 3: 16-wave 512x64 ring tiles for
-                    // fp32 layers of <= 64 output channels (default 15)
+                    // layers of <= 64 output channels, bit 4: 16 waves of 64x64 on the 256x256 tiles of the plain bf16 layers (default 31)
     CG_FORCE,       // tests: pin one small tile shape (1: 128x64, 2: 64x64, 3: 4-wave 128x128; default 0)
     CG_PRESPLIT,    // fp32 split mode takes pre-split filters where the caller supplies them (default 1)
     CG_MFMA16,      // fp32 split mode on v_mfma_f32_16x16x32_bf16 (the chip holds a higher clock on it) instead of 32x32x16: 0 off,

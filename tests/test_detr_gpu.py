@@ -611,7 +611,7 @@ def test_bf16_r101_full_size_vs_bf16_faithful_oracle(measured):
     det.close()
 
 
-@pytest.mark.parametrize("cfg", ["cg.ut=0", "cg.tiles=0", "cg.tiles=7", "cg.force=2", "cg.ring=2", "cg.ring=0", "cg.ring=2,cg.presplit=0", "cg.f32=0",
+@pytest.mark.parametrize("cfg", ["cg.ut=0", "cg.tiles=0", "cg.tiles=7", "cg.tiles=15", "cg.force=2", "cg.ring=2", "cg.ring=0", "cg.ring=2,cg.presplit=0", "cg.f32=0",
                                  "att.x3=0,cg.fuse=1", "stem.rows=0,cg.fuse=0", "cg.s1=0", "cg.fuse_bf16=0", "cg.fuse_bf16=1,att.bf16_mfma=0", "cg.mfma16=0"])
 def test_conv_gemm_alternative_paths(cfg):
     """Every surviving switch of the library's config table (include/odam_config.h): the register-staged gather (what layers too
