@@ -37,6 +37,9 @@ typedef struct {
     int img_h, img_w;      /* network input size, e.g. 800 x 1066 for a 640x480 frame (transforms.py:78-96) */
     int dtype;             /* 0: fp32 everywhere (parity mode).  1: bf16 weights + activations in memory, bf16 MFMA
                               with fp32 accumulation, fp32 softmax / LayerNorm / head outputs (BASELINE config 4) */
+    int pre_norm;          /* 0: post-norm layers (the shipped configuration).  1: `normalize_before` -- every encoder / decoder
+                              sub-block normalises its input and adds its output to the stream, the encoder ends in its own
+                              LayerNorm "transformer.encoder.norm.*" (src/models/transformer.py:169-188, 240-262, 26-28) */
 } odam_detr_cfg;
 
 int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out);

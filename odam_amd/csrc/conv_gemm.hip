@@ -2469,10 +2469,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
             // cycles of matrix work) than the pipe needs -- with four per SIMD the pipe finds a ready wave more often, and the
             // filter tile is fetched once per 512 rows.  conv1: 1.44 -> 1.15 ms per 32 frames (same box, A/B by config).
             // (128-row tiles with two 4-wave workgroups per CU = the same two waves per SIMD: measured no change, not kept.)
-            if (x16 && (odam_cfg::get(odam_cfg::CG_TILES) & 8)) return launch_big<4, 64, 4, 1024>(a, stream);
+            if (x16 && (odam_cfg::get(odam_cfg::CG_TILES) & 8) && (a.M + 511) / 512 >= 256) return launch_big<4, 64, 4, 1024>(a, stream);      // (fewer 512-row tiles than CUs: the 256-row ones)
             return pre ? (x16 ? launch_big<4, 64, 4>(a, stream) : launch_big<3, 64, 4>(a, stream)) : launch_big<2, 64, 4>(a, stream);
         } else if (bf && (g_big_mode >= 2 || (a.lda > 0 && a.lda < a.Cin)) && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
-            if ((odam_cfg::get(odam_cfg::CG_TILES) & 8) && !(a.KH * a.KW == 9 && a.stride == 1)) return launch_big<0, 64, 4, 1024>(a, stream);
+            if ((odam_cfg::get(odam_cfg::CG_TILES) & 8) && !(a.KH * a.KW == 9 && a.stride == 1) && (a.M + 511) / 512 >= 256) return launch_big<0, 64, 4, 1024>(a, stream);
             return launch_big<0, 64, 4>(a, stream);     // conv1 as a row convolution (pixel stride < row length); tests: layer1's 3x3 alone
         }
     }

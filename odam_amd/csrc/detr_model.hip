@@ -68,6 +68,8 @@ struct odam_detr {
     std::vector<DecLayer> dec;
     Conv cross_k_all, cross_v_all;
     LN dec_norm;
+    LN enc_norm;                 // pre_norm only: the encoder's final LayerNorm (transformer.py:27-28)
+    const void* memory_out = nullptr;      // where the last forward left the encoder's output (odam_detr_debug_read)
     Conv class_embed;
     Conv mlp[5][3];  // bbox, offset, angle, size, depth
     Conv stem_rows;              // fp32: conv1 as a 7x1 convolution over 32-float rows of the framed NHWC4 image (see forward_impl)
@@ -518,6 +520,7 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
     RC(pack_linear(m, m->cross_k_all, kall, &kball, 0, c.dec_layers * E));
     RC(pack_linear(m, m->cross_v_all, vall, &vball, 0, c.dec_layers * E));
     RC(pack_ln(m, m->dec_norm, "transformer.decoder.norm"));
+    if (c.pre_norm) RC(pack_ln(m, m->enc_norm, "transformer.encoder.norm"));
     {
         NEED(w, "class_embed.weight"); NEED(b, "class_embed.bias");
         RC(pack_linear(m, m->class_embed, *w, b, 0, (int)w->shape[0]));
@@ -634,8 +637,22 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
     const float* pos = pos_b ? pos_b : m->pos;     // row r of the batch reads pos[r % Lp]
     const int Lp = pos_b ? M : L;
     RC(odam_dk::launch_add_pos(m->src, pos, Lp, m->srcpos, M, dt, st));
+    const void* memory_p = m->src;      // the encoder's output (pre_norm: after its final LayerNorm, in tmp)
     for (size_t i = 0; i < m->enc.size(); i++) {
         const EncLayer& e = m->enc[i];
+        if (c.pre_norm) {
+            // forward_pre (transformer.py:169-183): src2 = norm1(src); q = k = src2 + pos; src += attn(q, k, src2);
+            //                                       src2 = norm2(src); src += linear2(relu(linear1(src2)))
+            RC(odam_dk::launch_add_layernorm(m->src, nullptr, e.n1.g, e.n1.b, m->tmp, pos, Lp, m->srcpos, M, dt, st));
+            RC(lin_t(m, e.qk, m->srcpos, M, nullptr, false, m->qk, st));
+            RC(lin_t(m, e.v, m->tmp, M, nullptr, false, m->v, st));
+            RC(att_t(m, m->qk, 2 * E, off(m->qk, E), 2 * E, m->v, E, m->att, E, B, Hh, L, L, st, key_mask));
+            RC(lin_t(m, e.out, m->att, M, m->src, false, m->src, st));                  // residual added in place
+            RC(odam_dk::launch_add_layernorm(m->src, nullptr, e.n2.g, e.n2.b, m->tmp, nullptr, L, nullptr, M, dt, st));
+            RC(lin_t(m, e.l1, m->tmp, M, nullptr, true, m->ffn, st));
+            RC(lin_t(m, e.l2, m->ffn, M, m->src, false, m->src, st));
+            continue;
+        }
         RC(lin_t(m, e.qk, m->srcpos, M, nullptr, false, m->qk, st));
         RC(lin_t(m, e.v, m->src, M, nullptr, false, m->v, st));
         RC(att_t(m, m->qk, 2 * E, off(m->qk, E), 2 * E, m->v, E, m->att, E, B, Hh, L, L, st, key_mask));
@@ -645,9 +662,14 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
         RC(lin_t(m, e.l2, m->ffn, M, m->src, false, m->tmp, st));
         RC(odam_dk::launch_add_layernorm(m->tmp, nullptr, e.n2.g, e.n2.b, m->src, pos, Lp, m->srcpos, M, dt, st));
     }
+    if (c.pre_norm) {      // memory = encoder.norm(src) (transformer.py:82-83), memory + pos for the cross-attention keys
+        RC(odam_dk::launch_add_layernorm(m->src, nullptr, m->enc_norm.g, m->enc_norm.b, m->tmp, pos, Lp, m->srcpos, M, dt, st));
+        memory_p = m->tmp;
+    }
+    m->memory_out = memory_p;
     // memory = src, memory + pos = srcpos
     RC(lin_t(m, m->cross_k_all, m->srcpos, M, nullptr, false, m->kc, st));
-    RC(lin_t(m, m->cross_v_all, m->src, M, nullptr, false, m->vc, st));
+    RC(lin_t(m, m->cross_v_all, memory_p, M, nullptr, false, m->vc, st));
 
     // ---- decoder (transformer.py:217-238) --------------------------------------------------------
     ODAM_HIP(hipMemsetAsync(m->tgt, 0, es * (size_t)Mq * E, st));
@@ -655,6 +677,22 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
     const int ldkv = c.dec_layers * E;
     for (size_t i = 0; i < m->dec.size(); i++) {
         const DecLayer& d = m->dec[i];
+        if (c.pre_norm) {
+            // forward_pre (transformer.py:240-262): every sub-block normalises its INPUT and adds its output to tgt
+            RC(odam_dk::launch_add_layernorm(m->tgt, nullptr, d.n1.g, d.n1.b, m->dtmp, m->query_pos, Q, m->tgtpos, Mq, dt, st));
+            RC(lin_t(m, d.qk, m->tgtpos, Mq, nullptr, false, m->dqk, st));
+            RC(lin_t(m, d.v, m->dtmp, Mq, nullptr, false, m->dv, st));
+            RC(att_t(m, m->dqk, 2 * E, off(m->dqk, E), 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
+            RC(lin_t(m, d.out, m->datt, Mq, m->tgt, false, m->tgt, st));
+            RC(odam_dk::launch_add_layernorm(m->tgt, nullptr, d.n2.g, d.n2.b, m->dtmp, m->query_pos, Q, m->tgtpos, Mq, dt, st));
+            RC(lin_t(m, d.cq, m->tgtpos, Mq, nullptr, false, m->dq, st));
+            RC(att_t(m, m->dq, E, off(m->kc, i * E), ldkv, off(m->vc, i * E), ldkv, m->datt, E, B, Hh, Q, L, st, key_mask));
+            RC(lin_t(m, d.cout, m->datt, Mq, m->tgt, false, m->tgt, st));
+            RC(odam_dk::launch_add_layernorm(m->tgt, nullptr, d.n3.g, d.n3.b, m->dtmp, nullptr, Q, nullptr, Mq, dt, st));
+            RC(lin_t(m, d.l1, m->dtmp, Mq, nullptr, true, m->dffn, st));
+            RC(lin_t(m, d.l2, m->dffn, Mq, m->tgt, false, m->tgt, st));
+            continue;
+        }
         RC(lin_t(m, d.qk, m->tgtpos, Mq, nullptr, false, m->dqk, st));
         RC(lin_t(m, d.v, m->tgt, Mq, nullptr, false, m->dv, st));
         RC(att_t(m, m->dqk, 2 * E, off(m->dqk, E), 2 * E, m->dv, E, m->datt, E, B, Hh, Q, Q, st));
@@ -701,7 +739,7 @@ extern "C" int odam_detr_debug_read(odam_detr* m, int B, float* layer4_nchw, flo
     if (!m || !m->finalized || !m->layer4) return odam_fail(1, "odam_detr_debug_read: no forward has run");
     hipStream_t st = (hipStream_t)stream;
     if (layer4_nchw) RC(odam_dk::launch_nhwc_to_nchw(m->layer4, layer4_nchw, B, m->fh, m->fw, 2048, m->dt, st));
-    if (memory) RC(odam_dk::launch_to_f32(m->src, memory, (size_t)B * m->L * m->cfg.hidden_dim, m->dt, st));
+    if (memory) RC(odam_dk::launch_to_f32(m->memory_out ? m->memory_out : m->src, memory, (size_t)B * m->L * m->cfg.hidden_dim, m->dt, st));
     return 0;
 }
 

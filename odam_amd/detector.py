@@ -19,7 +19,8 @@ class _Cfg(ctypes.Structure):
     _fields_ = [("resnet_blocks", ctypes.c_int * 4), ("hidden_dim", ctypes.c_int), ("nheads", ctypes.c_int),
                 ("dim_feedforward", ctypes.c_int), ("enc_layers", ctypes.c_int), ("dec_layers", ctypes.c_int),
                 ("num_queries", ctypes.c_int), ("num_classes1", ctypes.c_int), ("angle_bins", ctypes.c_int),
-                ("max_batch", ctypes.c_int), ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("dtype", ctypes.c_int)]
+                ("max_batch", ctypes.c_int), ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("dtype", ctypes.c_int),
+                ("pre_norm", ctypes.c_int)]
 
 
 def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000, mask=None):
@@ -42,14 +43,28 @@ def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000, mask=Non
     return pos.reshape(h * w, 2 * num_pos_feats).contiguous()
 
 
+def learned_position_embedding(row_embed, col_embed, h, w):
+    """PositionEmbeddingLearned for an h x w grid -> [h*w, 256] float32 (position_encoding.py:49-74): token (y, x) carries
+    cat(col_embed[x], row_embed[y]); the tables hold 50 rows (h, w <= 50), and the padding mask plays no part."""
+    if h > row_embed.shape[0] or w > col_embed.shape[0]:
+        raise _lib.OdamError("learned position embedding: the token grid exceeds the embedding tables (50 x 50)")
+    x_emb, y_emb = col_embed[:w], row_embed[:h]
+    pos = torch.cat([x_emb.unsqueeze(0).repeat(h, 1, 1), y_emb.unsqueeze(1).repeat(1, w, 1)], dim=-1)
+    return pos.reshape(h * w, -1).to(torch.float32).contiguous()
+
+
 class Detector:
     """DETR forward on the GPU library.  One native handle per input size (the workspace and the
     position table depend on it), created lazily at the first call with that size."""
 
     def __init__(self, backbone="resnet50", hidden_dim=256, nheads=8, dim_feedforward=2048, enc_layers=6,
                  dec_layers=6, num_queries=100, num_classes=18, angle_bins=30, max_batch=8, device="cuda:0",
-                 n_streams=2, dtype="fp32"):
+                 n_streams=2, dtype="fp32", pre_norm=False, position_embedding="sine"):
         self.n_streams = max(1, int(n_streams))
+        if position_embedding not in ("sine", "v2", "learned", "v3"):      # build_position_encoding (position_encoding.py:77-87)
+            raise ValueError(f"not supported {position_embedding}")
+        self.learned_pos = position_embedding in ("learned", "v3")
+        self.pre_norm = bool(pre_norm)
         self.resize = (800, 1333)   # get_transforms(): shortest side, longest-side cap (transforms.py:281-290)
         if dtype not in ("fp32", "bf16"):
             raise ValueError("dtype must be 'fp32' (parity mode) or 'bf16' (BASELINE config 4)")
@@ -114,6 +129,7 @@ class Detector:
             setattr(cfg, k, a[k])
         cfg.max_batch, cfg.img_h, cfg.img_w = self.max_batch, H, W
         cfg.dtype = 1 if self.dtype == "bf16" else 0
+        cfg.pre_norm = 1 if self.pre_norm else 0
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.odam_detr_create(ctypes.byref(cfg), ctypes.byref(h)), "odam_detr_create")
@@ -132,12 +148,17 @@ class Detector:
         fh, fw = ctypes.c_int(), ctypes.c_int()
         _lib.check(L.odam_detr_feature_hw(h, ctypes.byref(fh), ctypes.byref(fw)), "odam_detr_feature_hw")
         tensors = dict(self._sd)
-        tensors["pos_embed"] = sine_position_embedding(fh.value, fw.value, a["hidden_dim"] // 2)
+        tensors["pos_embed"] = self._position_table(fh.value, fw.value)
         for name, t in tensors.items():
             shape = (ctypes.c_longlong * max(t.dim(), 1))(*t.shape)
             _lib.check(L.odam_detr_set_weight(h, name.encode(), ctypes.c_void_p(t.data_ptr()), shape, t.dim()),
                        f"odam_detr_set_weight({name})")
         _lib.check(L.odam_detr_finalize(h), "odam_detr_finalize")
+
+    def _position_table(self, h, w, mask=None):
+        if self.learned_pos:
+            return learned_position_embedding(self._sd["backbone.1.row_embed.weight"], self._sd["backbone.1.col_embed.weight"], h, w)
+        return sine_position_embedding(h, w, self.arch["hidden_dim"] // 2, mask=mask)
 
     # ---- DETR.forward over images of different sizes (detr.py:64-65 -> misc.py:303-320) ----------------------
     def forward_nested(self, images):
@@ -163,7 +184,7 @@ class Detector:
         fh, fw = fh.value, fw.value
         m = F.interpolate(mask[None].float(), size=(fh, fw)).to(torch.bool)[0]            # backbone.py:79
         a = self.arch
-        pos = torch.stack([sine_position_embedding(fh, fw, a["hidden_dim"] // 2, mask=m[i]) for i in range(B)])
+        pos = torch.stack([self._position_table(fh, fw, mask=m[i]) for i in range(B)])
         dev = self.device
         d_x, d_m, d_pos = x.to(dev), m.reshape(B, fh * fw).to(torch.uint8).to(dev).contiguous(), pos.to(dev).contiguous()
         Q = a["num_queries"]
@@ -425,9 +446,10 @@ def build(args):
     g = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
     ds = g("dataset_file", "scan_net")
     num_classes = 18 if ds == "scan_net" else (91 if ds == "coco" else 20)
-    if g("pre_norm", False) or g("dilation", False) or g("masks", False):
-        raise _lib.OdamError("pre_norm / dilation / masks configurations are not built")
-    det = Detector(backbone=g("backbone", "resnet50"), hidden_dim=g("hidden_dim", 256), nheads=g("nheads", 8),
+    if g("dilation", False) or g("masks", False):
+        raise _lib.OdamError("dilation / masks configurations are not built")
+    det = Detector(pre_norm=g("pre_norm", False), position_embedding=g("position_embedding", "sine"),
+                   backbone=g("backbone", "resnet50"), hidden_dim=g("hidden_dim", 256), nheads=g("nheads", 8),
                    dim_feedforward=g("dim_feedforward", 2048), enc_layers=g("enc_layers", 6),
                    dec_layers=g("dec_layers", 6), num_queries=g("num_queries", 100), num_classes=num_classes)
     return det, None, None

@@ -46,6 +46,18 @@ def make_state_dict(backbone="resnet50", hidden=256, ffn=2048, enc_layers=6, dec
     return sd
 
 
+def add_variant_weights(sd, hidden=256, seed=0):
+    """The tensors only the configuration VARIANTS read, under the reference's key names, drawn from their own generator so that
+    the entries of `sd` stay what they are: the encoder's final LayerNorm of `pre_norm` models (transformer.py:26-28) and the
+    two 50-row tables of the learned position embedding (position_encoding.py:53-60, uniform in [0, 1) as reset_parameters)."""
+    g = torch.Generator().manual_seed(7000 + seed)
+    sd["transformer.encoder.norm.weight"] = 1.0 + 0.1 * _u(g, (hidden,), 1.0)
+    sd["transformer.encoder.norm.bias"] = 0.05 * _u(g, (hidden,), 1.0)
+    sd["backbone.1.row_embed.weight"] = torch.rand((50, hidden // 2), generator=g, dtype=torch.float32)
+    sd["backbone.1.col_embed.weight"] = torch.rand((50, hidden // 2), generator=g, dtype=torch.float32)
+    return sd
+
+
 def scene_backbone_gains(sd):
     """residual branches of the backbone damped further (bn3 gain 0.4 -> 0.1): with calibrated (centring) batch-norm
     statistics a random 50-layer network amplifies a last-bit perturbation of its input about 30x by layer4; damped it

@@ -84,8 +84,50 @@ def _ln(x, sd, p):
     return F.layer_norm(x, (x.shape[-1],), sd[p + ".weight"], sd[p + ".bias"], 1e-5)
 
 
-def transformer(src, pos, query_embed, sd, nheads=8, enc_layers=6, dec_layers=6, prefix="transformer."):
+def position_embedding_learned(sd, h, w, batch=1, prefix="backbone.1."):
+    """PositionEmbeddingLearned.forward (src/models/position_encoding.py:49-74) -> [B, C, h, w]"""
+    x_emb = sd[prefix + "col_embed.weight"][torch.arange(w)]
+    y_emb = sd[prefix + "row_embed.weight"][torch.arange(h)]
+    pos = torch.cat([x_emb.unsqueeze(0).repeat(h, 1, 1), y_emb.unsqueeze(1).repeat(1, w, 1)], dim=-1)
+    return pos.permute(2, 0, 1).unsqueeze(0).repeat(batch, 1, 1, 1)
+
+
+def _ffn(x, sd, p):
+    return F.linear(F.relu(F.linear(x, sd[p + "linear1.weight"], sd[p + "linear1.bias"])), sd[p + "linear2.weight"], sd[p + "linear2.bias"])
+
+
+def transformer_pre(src, pos, query_embed, sd, nheads=8, enc_layers=6, dec_layers=6, prefix="transformer."):
+    """`normalize_before` variant (src/models/transformer.py: encoder layer forward_pre :169-183, final encoder norm :26-28 /
+    :82-83, decoder layer forward_pre :240-262, per-layer decoder norm :117-127): same shapes as `transformer`."""
+    bs = src.shape[0]
+    x = src.flatten(2).permute(2, 0, 1)
+    pe = pos.flatten(2).permute(2, 0, 1)
+    qe = query_embed.unsqueeze(1).repeat(1, bs, 1)
+    for i in range(enc_layers):
+        p = f"{prefix}encoder.layers.{i}."
+        x2 = _ln(x, sd, p + "norm1")
+        q = k = x2 + pe
+        x = x + _mha(sd, p + "self_attn.", q, k, x2, nheads)
+        x = x + _ffn(_ln(x, sd, p + "norm2"), sd, p)
+    memory = _ln(x, sd, prefix + "encoder.norm")
+    tgt = torch.zeros_like(qe)
+    inter = []
+    for i in range(dec_layers):
+        p = f"{prefix}decoder.layers.{i}."
+        t2 = _ln(tgt, sd, p + "norm1")
+        q = k = t2 + qe
+        tgt = tgt + _mha(sd, p + "self_attn.", q, k, t2, nheads)
+        t2 = _ln(tgt, sd, p + "norm2")
+        tgt = tgt + _mha(sd, p + "multihead_attn.", t2 + qe, memory + pe, memory, nheads)
+        tgt = tgt + _ffn(_ln(tgt, sd, p + "norm3"), sd, p)
+        inter.append(_ln(tgt, sd, prefix + "decoder.norm"))
+    return torch.stack(inter).transpose(1, 2), memory
+
+
+def transformer(src, pos, query_embed, sd, nheads=8, enc_layers=6, dec_layers=6, prefix="transformer.", pre_norm=False):
     """src [B,C,h,w], pos [B,C,h,w], query_embed [Q,C] -> hs [dec_layers,B,Q,C], memory [HW,B,C]"""
+    if pre_norm:
+        return transformer_pre(src, pos, query_embed, sd, nheads, enc_layers, dec_layers, prefix)
     bs = src.shape[0]
     x = src.flatten(2).permute(2, 0, 1)
     pe = pos.flatten(2).permute(2, 0, 1)
@@ -133,13 +175,13 @@ def heads(hs, sd):
 
 
 @torch.no_grad()
-def detr_forward(sd, img, blocks=(3, 4, 6, 3), nheads=8, enc_layers=6, dec_layers=6, return_taps=False):
+def detr_forward(sd, img, blocks=(3, 4, 6, 3), nheads=8, enc_layers=6, dec_layers=6, return_taps=False, pre_norm=False, learned_pos=False):
     """img [B,3,H,W] float32 CPU -> the reference's output dict for the last decoder layer."""
     feat = resnet_body(img, sd, blocks)
     B, _, h, w = feat.shape
-    pos = position_embedding(h, w, batch=B)
+    pos = position_embedding_learned(sd, h, w, batch=B) if learned_pos else position_embedding(h, w, batch=B)
     src = F.conv2d(feat, sd["input_proj.weight"], sd["input_proj.bias"])
-    hs, memory = transformer(src, pos, sd["query_embed.weight"], sd, nheads, enc_layers, dec_layers)
+    hs, memory = transformer(src, pos, sd["query_embed.weight"], sd, nheads, enc_layers, dec_layers, pre_norm=pre_norm)
     out = heads(hs[-1], sd)
     if return_taps:
         out["_layer4"] = feat

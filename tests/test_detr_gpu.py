@@ -138,6 +138,23 @@ def test_forward_vs_reference_golden(model, golden):
             assert np.allclose(post[k][b], z[f"post{b}_{k}"], rtol=1e-4, atol=1e-3), (b, k)
 
 
+@pytest.mark.parametrize("variant", ["pre", "learned", "pre_learned"])
+def test_config_variants_vs_reference_golden(golden, variant):
+    """pre_norm / learned position embedding (the two config variants besides the shipped one that the transformer has):
+    the GPU forward against the reference's own DETR built with those keys (detr_variants.npz), and build(cfg) accepts them"""
+    from odam_amd import detector, weights
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_golden_detr_variants import image
+    z = golden("detr_variants.npz")
+    det, _, _ = detector.build({"pre_norm": variant.startswith("pre"), "position_embedding": "learned" if variant.endswith("learned") else "sine"})
+    det.load_state_dict(weights.add_variant_weights(weights.make_state_dict(seed=0)))
+    out = det(image().to(DEV))
+    for k in KEYS:
+        assert np.abs(out[k].cpu().numpy() - z[f"{variant}_{k}"]).max() <= 1e-4 * max(1.0, float(np.abs(z[f"{variant}_{k}"]).max())), k
+    assert np.array_equal(out["pred_logits"].argmax(-1).cpu().numpy(), z[f"{variant}_pred_logits"].argmax(-1))
+    det.close()
+
+
 def test_full_size_forward_vs_reference_golden(model, golden):
     """the reference's own DETR output on one 3x800x1066 frame (850 encoder tokens): BASELINE's full size"""
     det, _ = model
