@@ -40,6 +40,8 @@ typedef struct {
     int pre_norm;          /* 0: post-norm layers (the shipped configuration).  1: `normalize_before` -- every encoder / decoder
                               sub-block normalises its input and adds its output to the stream, the encoder ends in its own
                               LayerNorm "transformer.encoder.norm.*" (src/models/transformer.py:169-188, 240-262, 26-28) */
+    int dilation;          /* 1: the DC5 backbone (src/models/backbone.py:89-91): layer4 keeps layer3's resolution -- stride 1, its
+                              3x3 filters dilated by 2 from the second block on -- so the token grid is ceil(H/16) x ceil(W/16) */
 } odam_detr_cfg;
 
 int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out);

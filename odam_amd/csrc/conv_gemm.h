@@ -70,6 +70,8 @@ struct ConvGemmArgs {
     // layer's Cout = 64 / 128 / 256), G_Wt [G_N][F_ldc] (the next reduce).  F_res / F_C / G_C then point to bf16 tensors.
     const void* F_Wt = nullptr;
     const void* G_Wt = nullptr;
+    int dil = 1;                    // dilation of the taps (both axes): tap (ky, kx) reads input pixel (oy stride - pad + ky dil, ox stride - pad + kx dil);
+                                    // the window loop and the bottleneck-on-the-tile launches take dil = 1 only
     int s1_window = 0;              // set by launch_conv_gemm (bf16 ring kernel, 3x3 stride 1): one LDS window per (channel slice, ky)
                                     //    serves the three horizontal taps (odam_config.h cg.s1)
 };

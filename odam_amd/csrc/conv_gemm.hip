@@ -352,7 +352,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             unsigned mk = plain ? 1u : 0u;
             for (int t = 0; t < (plain ? 0 : ntaps); t++) {
                 const int ky = (t * kw_inv) >> 16, kx = t - ky * a.KW;
-                if ((unsigned)(a_iy0[i] + ky) < (unsigned)a.H && (unsigned)(a_ix0[i] + kx) < (unsigned)a.W) mk |= 1u << t;
+                if ((unsigned)(a_iy0[i] + ky * a.dil) < (unsigned)a.H && (unsigned)(a_ix0[i] + kx * a.dil) < (unsigned)a.W) mk |= 1u << t;
             }
             a_mask[i] = a_ok[i] ? mk : 0u;
         }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
             }
             const int ky = (tap * kw_inv) >> 16;
             const int kx = tap - ky * a.KW;
-            const int soff = ((ky * a.W + kx) * lda + cbase) * (int)sizeof(T);
+            const int soff = ((ky * a.W + kx) * a.dil * lda + cbase) * (int)sizeof(T);
 #pragma unroll
             for (int i = 0; i < A_LD; i++) {
                 const unsigned vo = ((a_mask[i] >> tap) & 1u) ? a_voff[i] : OOB_VOFF;
@@ -409,10 +409,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
         const int ky = (tap * kw_inv) >> 16;
         const int kx = tap - ky * a.KW;
         const bool tap_ok = tap < ntaps;
-        const int koff = (ky * a.W + kx) * lda + ci;
+        const int koff = (ky * a.W + kx) * a.dil * lda + ci;
 #pragma unroll
         for (int i = 0; i < A_LD; i++) {
-            const int iy = a_iy0[i] + ky, ix = a_ix0[i] + kx;
+            const int iy = a_iy0[i] + ky * a.dil, ix = a_ix0[i] + kx * a.dil;
             const bool ok = a_ok[i] && tap_ok && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
             ra[i] = ok ? *reinterpret_cast<const float4*>(Ag + (size_t)(a_base[i] + koff)) : float4{0.f, 0.f, 0.f, 0.f};
         }
@@ -1508,7 +1508,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         unsigned mk = plain ? 1u : 0u;
         for (int t = 0; t < (plain ? 0 : ntaps); t++) {
             const int ky = (t * kw_inv) >> 16, kx = t - ky * a.KW;
-            if ((unsigned)(iy0 + ky) < (unsigned)a.H && (unsigned)(ix0 + kx) < (unsigned)a.W) mk |= 1u << t;
+            if ((unsigned)(iy0 + ky * a.dil) < (unsigned)a.H && (unsigned)(ix0 + kx * a.dil) < (unsigned)a.W) mk |= 1u << t;
         }
         a_mask[i] = ok ? mk : 0u;
     }
@@ -1556,7 +1556,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             cbase = kb & (a.Cin - 1);
         }
         const int ky = (tap * kw_inv) >> 16, kx = tap - ky * a.KW;
-        return TilePrep{tap, ((ky * a.W + kx) * lda + cbase) * (int)sizeof(T), PRE ? kt * 96 : kt * BKE * (int)sizeof(T)};
+        return TilePrep{tap, ((ky * a.W + kx) * a.dil * lda + cbase) * (int)sizeof(T), PRE ? kt * 96 : kt * BKE * (int)sizeof(T)};
     };
     auto dma_part = [&](const TilePrep& tp, int st, int part) {      // part is a compile-time constant at every call site
         const unsigned sb = lds_base + (unsigned)(st * STAGE + wave_u * 16 * ROWB);
@@ -2062,7 +2062,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         // The k order differs from the generic loop's (ky outside the two 32-channel halves of a chunk): same products, a
         // different but fixed summation order.
         const long tensor_bytes = (long)a.B * a.H * a.W * lda * 2;
-        const bool s1 = NTH == 512 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.k_order == 1 && a.Ho == a.H && a.Wo == a.W &&
+        const bool s1 = NTH == 512 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.k_order == 1 && a.Ho == a.H && a.Wo == a.W &&
                         tensor_bytes < 0x7fffffffL && a.s1_window != 0;
         if constexpr (NTH == 512) if (s1) {
             constexpr int NSS = BN == 256 ? 2 : (BN == 128 ? 3 : 4);
@@ -2406,7 +2406,7 @@ bool fused_second_ok(const ConvGemmArgs& a) {
     if (!fuse || !g_big_mode || g_big_f32 != 2 || a.dtype != ODAM_CG_F32) return false;
     if (!a.F_Wt3 || !a.F_C || !a.Wt3 || a.Kpad % 16 != 0) return false;
     const bool l1 = a.Cout == 64 && a.F_ldc == 256, l2 = a.Cout == 128 && a.F_ldc == 512 && !a.G_Wt3;     // the two shapes built
-    if (!l1 && !l2) return false;
+    if ((!l1 && !l2) || a.dil != 1) return false;
     if ((long)a.Cout * a.Kpad * 6 >= 0x7fffffffL || (long)a.M * a.F_ldc * 4 >= 0x7fffffffL) return false;      // buffer descriptors over the output / residual
     if (a.G_Wt3 && (fuse < 2 || !a.G_C || (a.G_N != 64 && a.G_N != 128))) return false;      // fuse 1: second layer only
     return big_eligible(a, a.Cout);
@@ -2418,7 +2418,7 @@ bool fused_second_ok(const ConvGemmArgs& a) {
 bool fused_bf16_ok(const ConvGemmArgs& a) {
     if (!g_fuse_bf16 || !g_big_mode || a.dtype != ODAM_CG_BF16 || !a.F_Wt || !a.F_C) return false;
     if (a.Cout != 64 && a.Cout != 128 && a.Cout != 256) return false;
-    if (a.F_ldc != 4 * a.Cout || a.KH * a.KW != 9 || a.Cin != a.Cout || !a.k_order) return false;
+    if (a.F_ldc != 4 * a.Cout || a.KH * a.KW != 9 || a.Cin != a.Cout || !a.k_order || a.dil != 1) return false;
     if ((long)a.M * a.F_ldc * 2 >= 0x7fffffffL) return false;
     if (a.G_Wt) {
         if (g_fuse_bf16 < 2 || !a.G_C) return false;

@@ -35,7 +35,7 @@ struct Conv {          // packed convolution / linear layer on device
     void* w3 = nullptr;      // fp32 models: the same filters split into three bf16 planes (conv_gemm.h Wt3), or null
     float* scale = nullptr;  // [Cout] or null
     float* bias = nullptr;   // [Cout] or null
-    int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0;
+    int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, Kpad = 0, dil = 1;
     int k_order = 0;         // conv_gemm.h: 1 = channel-chunk-major K (multi-tap filters with Cin % k-tile == 0)
 };
 
@@ -160,7 +160,7 @@ const HostTensor* find(odam_detr* m, const std::string& name) {
     }
 
 // [Cout, Cin, KH, KW] (PyTorch) -> [Cout][Kpad], k = (ky*KW + kx)*CinP + ci, CinP = Cin rounded up to 4
-int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad) {
+int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad, int dil = 1) {
     const int Cout = (int)w.shape[0], Cin = (int)w.shape[1];
     const int KH = w.shape.size() > 2 ? (int)w.shape[2] : 1, KW = w.shape.size() > 3 ? (int)w.shape[3] : 1;
     const int epc = m->dt ? 8 : 4;             // elements per 16-byte chunk
@@ -179,7 +179,7 @@ int pack_conv(odam_detr* m, Conv& c, const HostTensor& w, int stride, int pad) {
                     p[(size_t)o * Kpad + k] = w.data[(((size_t)o * Cin + ci) * KH + ky) * KW + kx];
                 }
     c.k_order = k_order;
-    c.Cin = CinP; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
+    c.Cin = CinP; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad; c.dil = dil;
     if (int rc = m->upload_w3(&c.w3, p, Cout, Kpad)) return rc;
     return m->upload_w(&c.w, p);
 }
@@ -225,8 +225,8 @@ int run_conv(const Conv& c, const void* x, int B, int H, int W, const void* res,
     a.dtype = dtype; a.out_f32 = out_f32;
     a.A = x; a.Wt = c.w; a.Wt3 = c.w3; a.scale = c.scale; a.bias = c.bias; a.res = res; a.C = y;
     a.B = B; a.H = H; a.W = W; a.Cin = c.Cin; a.log2Cin = ilog2(c.Cin);
-    a.Ho = conv_out(H, c.KH, c.stride, c.pad); a.Wo = conv_out(W, c.KW, c.stride, c.pad);
-    a.Cout = c.Cout; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad; a.Kpad = c.Kpad;
+    a.Ho = conv_out(H, (c.KH - 1) * c.dil + 1, c.stride, c.pad); a.Wo = conv_out(W, (c.KW - 1) * c.dil + 1, c.stride, c.pad);
+    a.Cout = c.Cout; a.KH = c.KH; a.KW = c.KW; a.stride = c.stride; a.pad = c.pad; a.Kpad = c.Kpad; a.dil = c.dil;
     a.relu = relu ? 1 : 0; a.M = B * a.Ho * a.Wo; a.ldc = ldc > 0 ? ldc : c.Cout;
     a.k_order = c.k_order;
     return odam_cg::launch_conv_gemm(a, st);
@@ -244,7 +244,7 @@ int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, cons
         }
         m->ev_flops.resize(m->ev.size() / 2);
     }
-    const int Ho = conv_out(H, c.KH, c.stride, c.pad), Wo = conv_out(W, c.KW, c.stride, c.pad);
+    const int Ho = conv_out(H, (c.KH - 1) * c.dil + 1, c.stride, c.pad), Wo = conv_out(W, (c.KW - 1) * c.dil + 1, c.stride, c.pad);
     const int Cin_true = (c.KH == 7) ? 3 : c.Cin;  // the stem's 4th input channel is zero padding
     m->ev_flops[m->ev_used / 2] = 2.0 * B * Ho * Wo * (double)c.Cout * c.KH * c.KW * Cin_true;
     ODAM_HIP(hipEventRecord(m->ev[m->ev_used], st));
@@ -260,6 +260,7 @@ int conv_t(odam_detr* m, const Conv& c, const void* x, int B, int H, int W, cons
 int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, int B, int H, int W, const void* res, void* y,
                  hipStream_t st, const Conv* next_c1 = nullptr, void* t_next = nullptr, bool* chained = nullptr) {
     if (chained) *chained = false;
+    if (c2.dil != 1) return -1;      // dilated 3x3 (the DC5 backbone's layer4): the separate launches
     if (c3.KH != 1 || c3.stride != 1 || c3.Kpad != c2.Cout) return -1;
     if (!m->dt && (!c2.w3 || !c3.w3)) return -1;
     ConvGemmArgs a{};
@@ -388,7 +389,7 @@ extern "C" int odam_detr_create(const odam_detr_cfg* cfg, odam_detr** out) {
     m->H1 = conv_out(cfg->img_h, 7, 2, 3); m->W1 = conv_out(cfg->img_w, 7, 2, 3);
     m->H2 = conv_out(m->H1, 3, 2, 1); m->W2 = conv_out(m->W1, 3, 2, 1);
     int h = m->H2, w = m->W2;
-    for (int l = 1; l < 4; l++) { h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1); }
+    for (int l = 1; l < (cfg->dilation ? 3 : 4); l++) { h = conv_out(h, 3, 2, 1); w = conv_out(w, 3, 2, 1); }      // dilation: layer4 keeps layer3's resolution
     m->fh = h; m->fw = w; m->L = h * w;
     *out = m;
     return 0;
@@ -453,11 +454,16 @@ extern "C" int odam_detr_finalize(odam_detr* m) {
     for (int l = 0; l < 4; l++) {
         for (int i = 0; i < c.resnet_blocks[l]; i++) {
             const std::string p = bb + "layer" + std::to_string(l + 1) + "." + std::to_string(i) + ".";
-            const int stride = (i == 0 && l > 0) ? 2 : 1;
+            // `dilation` (backbone.py:89-91 -> torchvision replace_stride_with_dilation = [False, False, True]): layer4's stride
+            // becomes a dilation -- its first block runs with stride 1 and the PREVIOUS dilation (1), the others with dilation 2
+            // and padding 2 (torchvision ResNet._make_layer: previous_dilation for block 0, self.dilation *= stride after it)
+            const bool dc5 = c.dilation && l == 3;
+            const int stride = (i == 0 && l > 0 && !dc5) ? 2 : 1;
+            const int dil = (dc5 && i > 0) ? 2 : 1;
             Bottleneck b;
             NEED(w1, p + "conv1.weight"); NEED(w2, p + "conv2.weight"); NEED(w3, p + "conv3.weight");
             RC(pack_conv(m, b.c1, *w1, 1, 0)); RC(fold_bn(m, b.c1, p + "bn1"));
-            RC(pack_conv(m, b.c2, *w2, stride, 1)); RC(fold_bn(m, b.c2, p + "bn2"));   // v1.5: stride on the 3x3
+            RC(pack_conv(m, b.c2, *w2, stride, dil, dil)); RC(fold_bn(m, b.c2, p + "bn2"));   // v1.5: stride on the 3x3
             RC(pack_conv(m, b.c3, *w3, 1, 0)); RC(fold_bn(m, b.c3, p + "bn3"));
             if (i == 0) {
                 NEED(wd, p + "downsample.0.weight");

@@ -20,7 +20,7 @@ class _Cfg(ctypes.Structure):
                 ("dim_feedforward", ctypes.c_int), ("enc_layers", ctypes.c_int), ("dec_layers", ctypes.c_int),
                 ("num_queries", ctypes.c_int), ("num_classes1", ctypes.c_int), ("angle_bins", ctypes.c_int),
                 ("max_batch", ctypes.c_int), ("img_h", ctypes.c_int), ("img_w", ctypes.c_int), ("dtype", ctypes.c_int),
-                ("pre_norm", ctypes.c_int)]
+                ("pre_norm", ctypes.c_int), ("dilation", ctypes.c_int)]
 
 
 def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000, mask=None):
@@ -59,12 +59,13 @@ class Detector:
 
     def __init__(self, backbone="resnet50", hidden_dim=256, nheads=8, dim_feedforward=2048, enc_layers=6,
                  dec_layers=6, num_queries=100, num_classes=18, angle_bins=30, max_batch=8, device="cuda:0",
-                 n_streams=2, dtype="fp32", pre_norm=False, position_embedding="sine"):
+                 n_streams=2, dtype="fp32", pre_norm=False, position_embedding="sine", dilation=False):
         self.n_streams = max(1, int(n_streams))
         if position_embedding not in ("sine", "v2", "learned", "v3"):      # build_position_encoding (position_encoding.py:77-87)
             raise ValueError(f"not supported {position_embedding}")
         self.learned_pos = position_embedding in ("learned", "v3")
         self.pre_norm = bool(pre_norm)
+        self.dilation = bool(dilation)
         self.resize = (800, 1333)   # get_transforms(): shortest side, longest-side cap (transforms.py:281-290)
         if dtype not in ("fp32", "bf16"):
             raise ValueError("dtype must be 'fp32' (parity mode) or 'bf16' (BASELINE config 4)")
@@ -130,6 +131,7 @@ class Detector:
         cfg.max_batch, cfg.img_h, cfg.img_w = self.max_batch, H, W
         cfg.dtype = 1 if self.dtype == "bf16" else 0
         cfg.pre_norm = 1 if self.pre_norm else 0
+        cfg.dilation = 1 if self.dilation else 0
         h = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _lib.check(L.odam_detr_create(ctypes.byref(cfg), ctypes.byref(h)), "odam_detr_create")
@@ -446,9 +448,9 @@ def build(args):
     g = (lambda k, d: args.get(k, d)) if isinstance(args, dict) else (lambda k, d: getattr(args, k, d))
     ds = g("dataset_file", "scan_net")
     num_classes = 18 if ds == "scan_net" else (91 if ds == "coco" else 20)
-    if g("dilation", False) or g("masks", False):
-        raise _lib.OdamError("dilation / masks configurations are not built")
-    det = Detector(pre_norm=g("pre_norm", False), position_embedding=g("position_embedding", "sine"),
+    if g("masks", False):
+        raise _lib.OdamError("the segmentation head (masks) is not part of this path")
+    det = Detector(pre_norm=g("pre_norm", False), position_embedding=g("position_embedding", "sine"), dilation=g("dilation", False),
                    backbone=g("backbone", "resnet50"), hidden_dim=g("hidden_dim", 256), nheads=g("nheads", 8),
                    dim_feedforward=g("dim_feedforward", 2048), enc_layers=g("enc_layers", 6),
                    dec_layers=g("dec_layers", 6), num_queries=g("num_queries", 100), num_classes=num_classes)

@@ -37,17 +37,22 @@ def frozen_bn(x, sd, p):
     return x * scale + bias
 
 
-def resnet_body(x, sd, blocks=(3, 4, 6, 3), prefix="backbone.0.body."):
+def resnet_body(x, sd, blocks=(3, 4, 6, 3), prefix="backbone.0.body.", dilation=False):
+    """torchvision ResNet-50/101 v1.5 body (absent from the reference tree; restated from its published definition).  `dilation`:
+    replace_stride_with_dilation = [False, False, True] (src/models/backbone.py:89-91) -- layer4 with stride 1, its 3x3 filters
+    dilated by 2 (padding 2) from the second block on, the first block at the previous dilation (ResNet._make_layer)."""
     x = F.conv2d(x, sd[prefix + "conv1.weight"], None, stride=2, padding=3)
     x = F.relu(frozen_bn(x, sd, prefix + "bn1"))
     x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
     for l in range(4):
         for i in range(blocks[l]):
             p = f"{prefix}layer{l + 1}.{i}."
-            stride = 2 if (i == 0 and l > 0) else 1
+            dc5 = dilation and l == 3
+            stride = 2 if (i == 0 and l > 0 and not dc5) else 1
+            dil = 2 if (dc5 and i > 0) else 1
             idt = x
             out = F.relu(frozen_bn(F.conv2d(x, sd[p + "conv1.weight"]), sd, p + "bn1"))
-            out = F.relu(frozen_bn(F.conv2d(out, sd[p + "conv2.weight"], None, stride=stride, padding=1), sd, p + "bn2"))
+            out = F.relu(frozen_bn(F.conv2d(out, sd[p + "conv2.weight"], None, stride=stride, padding=dil, dilation=dil), sd, p + "bn2"))
             out = frozen_bn(F.conv2d(out, sd[p + "conv3.weight"]), sd, p + "bn3")
             if i == 0:
                 idt = frozen_bn(F.conv2d(x, sd[p + "downsample.0.weight"], None, stride=stride), sd, p + "downsample.1")
@@ -175,9 +180,10 @@ def heads(hs, sd):
 
 
 @torch.no_grad()
-def detr_forward(sd, img, blocks=(3, 4, 6, 3), nheads=8, enc_layers=6, dec_layers=6, return_taps=False, pre_norm=False, learned_pos=False):
+def detr_forward(sd, img, blocks=(3, 4, 6, 3), nheads=8, enc_layers=6, dec_layers=6, return_taps=False, pre_norm=False, learned_pos=False,
+                 dilation=False):
     """img [B,3,H,W] float32 CPU -> the reference's output dict for the last decoder layer."""
-    feat = resnet_body(img, sd, blocks)
+    feat = resnet_body(img, sd, blocks, dilation=dilation)
     B, _, h, w = feat.shape
     pos = position_embedding_learned(sd, h, w, batch=B) if learned_pos else position_embedding(h, w, batch=B)
     src = F.conv2d(feat, sd["input_proj.weight"], sd["input_proj.bias"])

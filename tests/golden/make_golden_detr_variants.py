@@ -1,5 +1,6 @@
 """Golden for the configuration variants the shipped yaml does not use: `pre_norm: True` (src/models/transformer.py:169-188,
-240-262, 26-28) and `position_embedding: 'learned'` (src/models/position_encoding.py:49-74, 83-84).  The reference's DETR is
+240-262, 26-28) `position_embedding: 'learned'` (src/models/position_encoding.py:49-74, 83-84) and `dilation: True` (src/models/backbone.py:89-91;
+the dilated layer4 itself is torchvision's, restated in make_golden_detr._ResNet -- the body stays "parity unpinned").  The reference's DETR is
 built from its own config with those two keys changed and run AS IT IS on the CPU (ResNet body: the stand-in of
 make_golden_detr.py, torchvision not installed), round-1 weights seed 0 + odam_amd.weights.add_variant_weights.
 Writes tests/golden/detr_variants.npz (2 frames of 3x256x320 regenerated from the seed; three model variants).
@@ -16,7 +17,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 VARIANTS = {"pre": dict(pre_norm=True, position_embedding="sine"), "learned": dict(pre_norm=False, position_embedding="learned"),
-            "pre_learned": dict(pre_norm=True, position_embedding="learned")}
+            "pre_learned": dict(pre_norm=True, position_embedding="learned"), "dc5": dict(dilation=True)}
 KEYS = ("pred_logits", "pred_boxes", "pred_angle", "pred_offset", "pred_size", "pred_depth")
 
 
@@ -30,7 +31,7 @@ def main():
     refenv.setup()
     import torchvision
     from make_golden_detr import _ResNet
-    torchvision.models.resnet50 = lambda replace_stride_with_dilation=None, pretrained=False, norm_layer=None: _ResNet((3, 4, 6, 3), norm_layer)
+    torchvision.models.resnet50 = lambda replace_stride_with_dilation=None, pretrained=False, norm_layer=None: _ResNet((3, 4, 6, 3), norm_layer, replace_stride_with_dilation)
     from src.config.configs import ConfigLoader
     from src.models.detr import build as build_detector
     from odam_amd import weights

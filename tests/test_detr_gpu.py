@@ -138,15 +138,16 @@ def test_forward_vs_reference_golden(model, golden):
             assert np.allclose(post[k][b], z[f"post{b}_{k}"], rtol=1e-4, atol=1e-3), (b, k)
 
 
-@pytest.mark.parametrize("variant", ["pre", "learned", "pre_learned"])
+@pytest.mark.parametrize("variant", ["pre", "learned", "pre_learned", "dc5"])
 def test_config_variants_vs_reference_golden(golden, variant):
-    """pre_norm / learned position embedding (the two config variants besides the shipped one that the transformer has):
+    """pre_norm / learned position embedding / dilated layer4 (the config variants besides the shipped one):
     the GPU forward against the reference's own DETR built with those keys (detr_variants.npz), and build(cfg) accepts them"""
     from odam_amd import detector, weights
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_golden_detr_variants import image
     z = golden("detr_variants.npz")
-    det, _, _ = detector.build({"pre_norm": variant.startswith("pre"), "position_embedding": "learned" if variant.endswith("learned") else "sine"})
+    det, _, _ = detector.build({"pre_norm": variant.startswith("pre"), "position_embedding": "learned" if variant.endswith("learned") else "sine",
+                                "dilation": variant == "dc5"})
     det.load_state_dict(weights.add_variant_weights(weights.make_state_dict(seed=0)))
     out = det(image().to(DEV))
     for k in KEYS:
@@ -188,6 +189,33 @@ def test_full_size_forward_vs_oracle(model):
     for b in range(2):
         assert np.array_equal(pp["classes"][b], pref["classes"][b])
         assert np.allclose(pp["translates"][b], pref["translates"][b], rtol=1e-4, atol=1e-4)
+
+
+def test_full_size_all_variants_vs_oracle():
+    """pre_norm + learned positions at the full size (25 x 34 tokens), and the dilated layer4 at a size where its 3x3 launches
+    run on the 256-row ring kernel (dilation in the tap offsets of the LDS-DMA gather) with 40 x 50 = 2,000 tokens"""
+    import detr_oracle as O
+    from odam_amd import detector, weights
+    sd = weights.add_variant_weights(weights.make_state_dict(seed=0))
+    rel = lambda a, b: ((a - b).abs().max() / b.abs().max()).item()
+    from odam_amd import _lib
+    ring = _lib.config()["cg.ring"]
+    for kw, okw, (B, H, W) in ((dict(pre_norm=True, position_embedding="learned"), dict(pre_norm=True, learned_pos=True), (1, 800, 1066)),
+                               (dict(dilation=True), dict(dilation=True), (2, 640, 800))):
+        _lib.set_config("cg.ring", 2 if "dilation" in kw else ring)      # the ring kernel on every eligible layer: two frames are too few tiles for the default rule
+        det = detector.Detector(max_batch=B, device=DEV, n_streams=1, **kw); det.load_state_dict(sd)
+        torch.manual_seed(11)
+        img = torch.randn(B, 3, H, W)
+        ref = O.detr_forward(sd, img, return_taps=True, **okw)
+        out = det(img.to(DEV))
+        l4, mem = det.debug_taps(B, H, W)
+        assert rel(l4.cpu(), ref["_layer4"]) <= 2e-5, kw
+        assert rel(mem.cpu(), ref["_memory"]) <= 3e-5, kw
+        for k in KEYS:
+            assert (out[k].cpu() - ref[k]).abs().max().item() <= 2e-4 * max(1.0, ref[k].abs().max().item()), (kw, k)
+        assert torch.equal(out["pred_logits"].cpu().argmax(-1), ref["pred_logits"].argmax(-1)), kw
+        det.close()
+    _lib.set_config("cg.ring", ring)
 
 
 def test_batch_size_does_not_change_results(model):

@@ -49,16 +49,17 @@ def test_forward_matches_reference_detr(sd, golden):
             assert np.allclose(post[k][b], z[f"post{b}_{k}"], rtol=1e-5, atol=1e-4), (b, k)
 
 
-@pytest.mark.parametrize("variant", ["pre", "learned", "pre_learned"])
+@pytest.mark.parametrize("variant", ["pre", "learned", "pre_learned", "dc5"])
 def test_config_variants_match_reference_detr(sd, golden, variant):
-    """`pre_norm: True` (transformer.py:169-188, 240-262, 26-28) and `position_embedding: 'learned'` (position_encoding.py:49-74):
+    """`pre_norm: True` (transformer.py:169-188, 240-262, 26-28), `position_embedding: 'learned'` (position_encoding.py:49-74) and
+    `dilation: True` (backbone.py:89-91; 16 x 20 tokens instead of 8 x 10):
     the oracle against the reference's DETR built with those config keys (tests/golden/make_golden_detr_variants.py)."""
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
     from make_golden_detr_variants import image
     from odam_amd import weights
     z = golden("detr_variants.npz")
     sdv = weights.add_variant_weights(dict(sd))
-    out = O.detr_forward(sdv, image(), pre_norm=variant.startswith("pre"), learned_pos=variant.endswith("learned"))
+    out = O.detr_forward(sdv, image(), pre_norm=variant.startswith("pre"), learned_pos=variant.endswith("learned"), dilation=variant == "dc5")
     for k in KEYS:
         assert np.abs(out[k].numpy() - z[f"{variant}_{k}"]).max() <= 2e-5 * max(1.0, float(np.abs(z[f"{variant}_{k}"]).max())), k
     assert np.array_equal(out["pred_logits"].argmax(-1).numpy(), z[f"{variant}_pred_logits"].argmax(-1))
