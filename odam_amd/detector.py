@@ -159,6 +159,9 @@ class Detector:
 
     def _position_table(self, h, w, mask=None):
         if self.learned_pos:
+            for k in ("backbone.1.row_embed.weight", "backbone.1.col_embed.weight"):
+                if k not in self._sd:
+                    raise _lib.OdamError(f"position_embedding='learned': the state dict has no {k}")
             return learned_position_embedding(self._sd["backbone.1.row_embed.weight"], self._sd["backbone.1.col_embed.weight"], h, w)
         return sine_position_embedding(h, w, self.arch["hidden_dim"] // 2, mask=mask)
 
