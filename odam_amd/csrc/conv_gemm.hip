@@ -30,6 +30,13 @@ __device__ unsigned long long g_stamps[8];
 #else
 #define CG_STAMP_AT(i) do { } while (0)
 #endif
+#if CG_STAMP      // phase stamps of the layer1 bottleneck tail (fused_chain), read by tests/native/tail_stamps.py through odam_cg_tail_stamps
+__device__ unsigned long long g_tail_stamps[8];
+#define CG_TSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                          ts_acc[i] += t_ - ts_prev; ts_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CG_TSTAMP(i) do { } while (0)
+#endif
 #ifndef CG_ABLATE
 #define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores, 16 no first-tile load
 #endif
@@ -760,6 +767,9 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
         for (int it = 0; it < 8; it++)
             rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0));
     };
+#if CG_STAMP
+    unsigned long long ts_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ts_prev = __builtin_readcyclecounter();      // (not fenced: slot 6 also holds the main loop)
+#endif
     load_res(0);
     dma_group(0);
     float* slab = smem + wave * (32 * 64);
@@ -785,6 +795,7 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
     wave_sync();
     uint4 ah[4], am[4], al[4];
     frags(ah, am, al);
+    CG_TSTAMP(6);
     floatx16 acc3[2];
 #pragma unroll
     for (int jc = 0; jc < 2; jc++)
@@ -800,6 +811,7 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
         if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __syncthreads();                                        // ... and everybody's; everybody is done with group g - 1's buffers
+        CG_TSTAMP(0);
         if (g + 1 < 4) dma_group(g + 1);
         const char* wf = lds_c + SLABS + (g & 1) * GB;
         const char* wg = lds_c + SLABS + 2 * GB + (g & 1) * GB;
@@ -825,6 +837,7 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
             for (int r = 0; r < 16; r++)
                 slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
         wave_sync();
+        CG_TSTAMP(1);
         const int n = g * 64 + c4 * 4;
         float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
         if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
@@ -843,8 +856,10 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
         }
         if (g + 1 < 4) load_res(g + 1);
         wave_sync();
+        CG_TSTAMP(2);
         uint4 xh[4], xm[4], xl[4];
         frags(xh, xm, xl);
+        CG_TSTAMP(3);
 #pragma unroll
         for (int jc = 0; jc < 2; jc++)
 #pragma unroll
@@ -857,6 +872,7 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
                 ODAM_MM2(acc3[jc], xh[s_], bh);
             }
         __builtin_amdgcn_wave_barrier();
+        CG_TSTAMP(4);
     }
 #undef ODAM_MM2
     // the reduce's own epilogue: scale / bias / ReLU, [32 rows][64 channels] out through the slab
@@ -879,6 +895,13 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
         const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
         if (m < a.M) *reinterpret_cast<float4*>(a.G_C + (size_t)m * 64 + c4 * 4) = v;
     }
+#if CG_STAMP
+    CG_TSTAMP(7);
+    if (lane == 0) {
+        for (int i = 0; i < 8; i++) if (i != 5) atomicAdd(&g_tail_stamps[i], ts_acc[i]);
+        atomicAdd(&g_tail_stamps[5], 1ull);
+    }
+#endif
 }
 
 // ---- the chain into the NEXT STAGE: layer1's last block + layer2's first reduce (256 -> 128 channels) ---------------------
@@ -2489,3 +2512,14 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
 }
 
 }  // namespace odam_cg
+
+#if CG_STAMP
+extern "C" int odam_cg_tail_stamps(unsigned long long* out8, int reset) {      // diagnostic builds only (-DCG_STAMP=1)
+    if (out8 && hipMemcpyFromSymbol(out8, HIP_SYMBOL(odam_cg::g_tail_stamps), 8 * sizeof(unsigned long long)) != hipSuccess) return 2;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(odam_cg::g_tail_stamps), z, sizeof(z)) != hipSuccess) return 2;
+    }
+    return 0;
+}
+#endif

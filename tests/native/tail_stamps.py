@@ -1,5 +1,6 @@
 """Phase timeline of the layer1 bottleneck launch's tail (fused_chain), diagnostic build only:
-   hipcc ... -DCG_STAMP=1 (every s_memtime stamp executes) -> odam_cg_tail_stamps"""
+   build the library with -DCG_STAMP=1 first (hipcc ... -DCG_STAMP=1 -o odam_amd/libodam_amd.so odam_amd/csrc/*.hip): every stamp
+   executes and the library exports odam_cg_tail_stamps; the product build has neither"""
 import os, sys, ctypes
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 import torch
