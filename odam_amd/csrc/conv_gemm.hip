@@ -558,9 +558,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
 //   fp32 matrix instruction's own k-ordered chain 1.1-1.9e-7 -- the same accuracy class, at 6 x 32 instead of 8 x 64
 //   matrix-pipe cycles per 16 k.  Results differ from MODE 1 in the last bits (different summation tree), so this mode
 //   is a switch (set_f32_mode), validated by the same tests as MODE 1.
-// NTH = 512: one workgroup per CU (two waves per SIMD run the same tile in lock step).  NTH = 256 (BN <= 128): a four-wave
-// workgroup with the same 128x64 / 64x64 wave tile, TWO per CU with independent barriers -- one workgroup's k-tile boundary
-// (barrier, fragment latency, DMA issue) falls under the other's MFMAs.
+// NTH = 512: one workgroup per CU (two waves per SIMD run the same tile in lock step); NTH = 1024: sixteen waves where a wave's
+// loop fits ~128 registers (big_bm / big_wm).  (Four-wave workgroups, two per CU with independent barriers, were measured
+// slower on every layer shape in round 2 and again in round 3, and are gone.)
 // ---- fused second layer of the 64-column ring kernel (ConvGemmArgs F_*) ---------------------------------------------------
 // After the K loop a wave holds 32 rows x 64 channels of this layer's output in two accumulators.  It applies scale / bias
 // / ReLU, turns the tile through a private 8 KB LDS slab (row-major, 16-byte chunk c of row r at c ^ (r & 15): conflict-
@@ -1434,7 +1434,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
 constexpr int big_bm(int BN, int NTH) { return (NTH == 1024 && BN == 64) ? 512 : 256; }
 constexpr int big_wm(int MODE, int BN, int NTH) {
     return NTH == 1024 ? (BN == 64 ? 16 : 4)      // bf16, 256 columns: sixteen waves of 64 x 64
-         : MODE >= 3 ? (BN == 256 ? 4 : 8) : (NTH == 512 ? (BN == 256 ? 2 : (BN == 128 ? 4 : 8)) : (BN >= 128 ? 2 : 4));
+         : MODE >= 3 ? (BN == 256 ? 4 : 8) : (BN == 256 ? 2 : (BN == 128 ? 4 : 8));
 }
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
@@ -1473,7 +1473,6 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     constexpr int KU = 2 * BKE;             // channels per unit of the chunk-major K order (conv_gemm.h k_order)
     constexpr int NW = NTH / 64;
     constexpr int WM = big_wm(MODE, BN, NTH), WN = NW / WM;
-    // NTH = 256 with BN = 256: one wave per SIMD owns 128 x 128 (256 accumulator registers of the 512 a lone wave may use)
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RPP = NTH / 4;            // 128 tile rows per DMA pass (4 chunks of 16 bytes per row)
     constexpr int A_LD = BM / RPP, B_LD = (BN + RPP - 1) / RPP;   // BN < RPP: only the first waves carry filter rows
