@@ -40,6 +40,12 @@ def projection(pts, intr_mat):  # geometry_utils.py:276-316, unbatched, keep_z=F
     return pts
 
 
+def _track_mark(track, k):
+    """what identifies the first k rows of a track for the running sums of _prepare_tracks: frame id and centre of its first
+    and its k-th observation (a slot of the track list that now holds another track, or an edited prefix, does not match)"""
+    return (track[0, 0], track[0, 9], track[0, 10], track[k - 1, 0], track[k - 1, 9], track[k - 1, 10])
+
+
 def get_cam_azi(T_wc):  # scannet_utils.py:213-222
     o = np.array([[0, 0, 1], [0, 0, 0]])
     o = (get_homogeneous(o) @ T_wc.T)[:, :3]
@@ -244,15 +250,15 @@ class OdamProcess:
             n = len(track)
             if i < len(cache) and cache[i][0] == n:
                 _, s_t, s_d = cache[i][:3]
-            elif i < len(cache) and 0 < cache[i][0] < n and cache[i][3] == (track[0, 0], track[cache[i][0] - 1, 0]):
+            elif i < len(cache) and 0 < cache[i][0] < n and cache[i][3] == _track_mark(track, cache[i][0]):
                 k, s_t, s_d = cache[i][:3]
                 s_t = s_t.copy(); s_d = s_d.copy()
                 for r in range(k, n):
                     s_t += track[r, 9:12]; s_d += track[r, 6:9]
-                cache[i] = (n, s_t, s_d, (track[0, 0], track[n - 1, 0]))
+                cache[i] = (n, s_t, s_d, _track_mark(track, n))
             else:
                 s_t = np.add.reduce(track[:, 9:12], axis=0); s_d = np.add.reduce(track[:, 6:9], axis=0)
-                entry = (n, s_t, s_d, (track[0, 0], track[n - 1, 0]))
+                entry = (n, s_t, s_d, _track_mark(track, n))
                 if i < len(cache):
                     cache[i] = entry
                 else:
