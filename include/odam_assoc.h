@@ -31,8 +31,9 @@ int odam_assoc_finalize(odam_assoc* m);
  * matching GNN layers and the final projection run as ONE persistent launch (256 workgroups, device-wide barriers between
  * the stages, exchanged buffers coherent through sc1 accesses), then the score matrix and the Sinkhorn kernel.
  * The persistent launch is used only when the runtime says all its workgroups can be resident at once on this device
- * (odam_assoc_info; never under a CU mask); ODAM_ASSOC_PERSIST=0 / odam_assoc_set_persistent(m, 0) issue the matching
- * layers as separate launches instead (and ODAM_ASSOC_GRAPH=1 replays that sequence from a hipGraph per track count).
+ * (odam_assoc_info; never under a CU mask); the odam_config key assoc.persist = 0 (read when a handle is finalised) or
+ * odam_assoc_set_persistent(m, 0) per handle issue the matching layers as separate launches instead.  The library reads no
+ * environment variable.
  * One handle serves one stream at a time.
  * Residency can still be lost to a foreign kernel that holds CUs: every barrier wait is bounded (20 ms by default); a launch
  * that hits the bound is abandoned, Z_out is filled with NaN and the handle's lost-launch counter moves.  The caller checks
@@ -64,12 +65,17 @@ int odam_assoc_set_barrier_timeout_us(odam_assoc* m, long long us);
  *            id), rows14 [host][n][14].  Within one call every id occurs at most once (a frame adds one observation per track).
  *   _build:  proj_px [dev][T][4] float64 (odam_sq_project_extents), cam15 [host][15] = rows 0..2 of inv(T_wc) (12), the camera's
  *            azimuth, img_w, img_h; out [dev][T][79][window].
- * Stream-ordered; host arrays are copied before the call returns. */
+ *   _load:   bulk (re)build -- lengths [host][T] observations per track, rows14 [host][sum_t min(lengths[t], window)][14] = the
+ *            last min(length, window) observations of track 0, then of track 1, ...; leaves the store exactly as lengths[t]
+ *            appends per track would.  One upload, one launch; synchronises the stream.
+ * Stream-ordered; host arrays are copied before the call returns (_append stages them in a pinned ring of eight slots whose
+ * reuse waits for the upload issued from that slot, however far behind the stream is). */
 typedef struct odam_trackwin odam_trackwin;
 int odam_trackwin_create(int max_tracks, int window, odam_trackwin** out);
 int odam_trackwin_destroy(odam_trackwin* w);
 int odam_trackwin_reset(odam_trackwin* w, void* stream);
 int odam_trackwin_append(odam_trackwin* w, int n, const int* track_ids, const double* rows14, void* stream);
+int odam_trackwin_load(odam_trackwin* w, int T, const int* lengths, const double* rows14, void* stream);
 int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_px, const double* cam15, float* out, void* stream);
 
 /* diagnostics of the persistent matching kernel: enable != 0 makes the following forwards record a 100 MHz timestamp of

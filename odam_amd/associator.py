@@ -38,6 +38,7 @@ class TrackWindows:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().odam_trackwin_create(max_tracks, self.WINDOW, ctypes.byref(self._h)), "odam_trackwin_create")
         self.lengths = []           # observations per track, as appended (the host's check against its own track list)
+        self.marks = []             # per track: (frame id and centre of its first observation, ... of its last) -- see in_step()
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -46,6 +47,36 @@ class TrackWindows:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().odam_trackwin_reset(self._h, self._stream()), "odam_trackwin_reset")
         self.lengths = []
+        self.marks = []
+
+    @staticmethod
+    def _mark(row):
+        return (float(row[0]), float(row[9]), float(row[10]), float(row[11]))
+
+    def in_step(self, tracks):
+        """True when the mirror holds exactly `tracks` as far as the host can tell without reading rows back: the same number of
+        observations per track AND the same first / last observation (frame id, world centre) -- a track list that was
+        replaced or edited at equal lengths (a restore, a test) is caught as well."""
+        if len(tracks) != len(self.lengths):
+            return False
+        for t, n, m in zip(tracks, self.lengths, self.marks):
+            if len(t) != n or (n and (self._mark(t[0]), self._mark(t[-1])) != m):
+                return False
+        return True
+
+    def load(self, tracks):
+        """(re)build the mirror from a host track list in one upload (include/odam_assoc.h, odam_trackwin_load)"""
+        T = len(tracks)
+        if T > self.max_tracks:
+            raise _lib.OdamError(f"TrackWindows: {T} tracks exceed the store's {self.max_tracks}")
+        lens = np.ascontiguousarray([len(t) for t in tracks], np.int32)
+        tails = [np.asarray(t, np.float64)[-self.WINDOW:, :14] for t in tracks if len(t)]
+        rows = np.ascontiguousarray(np.concatenate(tails, axis=0)) if tails else np.zeros((0, 14))
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().odam_trackwin_load(self._h, ctypes.c_int(T), lens.ctypes.data_as(ctypes.c_void_p),
+                                                     rows.ctypes.data_as(ctypes.c_void_p), self._stream()), "odam_trackwin_load")
+        self.lengths = lens.tolist()
+        self.marks = [(self._mark(t[0]), self._mark(t[-1])) if len(t) else None for t in tracks]
 
     def append(self, track_ids, rows82):
         """rows82 [n, 82] float64 track rows (processor.py:98-108); track_ids [n]: existing index or len(lengths) + j for new ones"""
@@ -56,11 +87,14 @@ class TrackWindows:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.lib().odam_trackwin_append(self._h, ctypes.c_int(n), ids[i0:].ctypes.data_as(ctypes.c_void_p),
                                                            rows[i0:].ctypes.data_as(ctypes.c_void_p), self._stream()), "odam_trackwin_append")
-        for t in ids.tolist():
+        for t, row in zip(ids.tolist(), np.asarray(rows82, np.float64)):
+            m = self._mark(row)
             if t == len(self.lengths):
                 self.lengths.append(1)
+                self.marks.append((m, m))
             else:
                 self.lengths[t] += 1
+                self.marks[t] = (self.marks[t][0] if self.marks[t] else m, m)
 
     def build(self, proj_px_dev, T_cw, cam_azi, img_w, img_h):
         T = len(self.lengths)
@@ -175,7 +209,11 @@ class Associator:
 
     def assignment(self, tracks, detections, n_tracks, n_det, sequence=False):
         """tracks [T,79,100], detections [1,79,30] or [79,30] (any device) -> Z [(T+1),(n_det+1)] device tensor.
-        Stream-ordered; sequence=True takes the launch-sequence path (no device-wide barrier)."""
+        Stream-ordered; sequence=True takes the launch-sequence path (no device-wide barrier).
+
+        This is the RAW entry: an abandoned persistent launch (include/odam_assoc.h) leaves Z all NaN and is reported only
+        through odam_assoc_lost_launches -- use assignment_checked() (what __call__ does) unless the caller synchronises and
+        checks that counter itself, as the timing scripts do.  A loss taken here is attributed to the next checked call."""
         dev = self.device
         if n_tracks > self.max_tracks:
             self._grow(n_tracks)

@@ -842,6 +842,8 @@ struct odam_trackwin {
     double* d_stage = nullptr;  // device copy of one slot
     double* d_cam = nullptr;    // [16]
     unsigned slot = 0;
+    hipEvent_t copied[8] = {};  // recorded behind the upload from pinned slot i: the host rewrites a slot only after its copy has run
+    bool copied_armed[8] = {};
 };
 
 namespace {
@@ -854,6 +856,20 @@ __global__ void trackwin_append_kernel(const double* __restrict__ st, int n, dou
     if (threadIdx.x < TW_COLS) rows[((size_t)tid_ * window + (c % window)) * TW_COLS + threadIdx.x] = st[i * (TW_COLS + 1) + threadIdx.x];
     __syncthreads();
     if (threadIdx.x == 0) count[tid_] = c + 1;
+}
+
+// track t: its last k = min(c, window) observations to the ring positions an append sequence of c rows would have left them in
+__global__ __launch_bounds__(128) void trackwin_load_kernel(const double* __restrict__ src, const int* __restrict__ meta, int T,
+                                                            double* __restrict__ rows, int* __restrict__ count, int window) {
+    const int t = blockIdx.x, l = threadIdx.x;
+    const int first = meta[t], c = meta[T + t], k = c < window ? c : window;
+    if (l < k) {
+        const double* r = src + (size_t)(first + l) * TW_COLS;
+        double* o = rows + ((size_t)t * window + ((c - k + l) % window)) * TW_COLS;
+#pragma unroll
+        for (int j = 0; j < TW_COLS; j++) o[j] = r[j];
+    }
+    if (l == 0) count[t] = c;
 }
 
 // out [T][79][window] float32; cam: T_cw rows 0..2 (12), cam_azi, img_w, img_h
@@ -909,12 +925,23 @@ extern "C" int odam_trackwin_create(int max_tracks, int window, odam_trackwin** 
         delete w;
         return odam_fail(2, "odam_trackwin_create: allocation failed");
     }
+    for (int i = 0; i < 8; i++)
+        if (hipEventCreateWithFlags(&w->copied[i], hipEventDisableTiming) != hipSuccess) {
+            for (int j = 0; j < i; j++) (void)hipEventDestroy(w->copied[j]);
+            (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->stage);
+            delete w;
+            return odam_fail(2, "odam_trackwin_create: event creation failed");
+        }
     *out = w;
     return 0;
 }
 
 extern "C" int odam_trackwin_destroy(odam_trackwin* w) {
     if (!w) return 0;
+    for (int i = 0; i < 8; i++) {
+        if (w->copied_armed[i]) (void)hipEventSynchronize(w->copied[i]);      // no upload may still be reading the pinned ring
+        (void)hipEventDestroy(w->copied[i]);
+    }
     (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->stage);
     delete w;
     return 0;
@@ -930,16 +957,57 @@ extern "C" int odam_trackwin_append(odam_trackwin* w, int n, const int* track_id
     if (!w || n < 0 || n > 32 || (n && (!track_ids || !rows14))) return odam_fail(1, "odam_trackwin_append: bad argument (at most 32 observations per call)");
     if (n == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    double* slot = w->stage + (size_t)(w->slot++ & 7) * 32 * (TW_COLS + 1);
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; i++)
         if (track_ids[i] < 0 || track_ids[i] >= w->max_tracks) return odam_fail(3, "odam_trackwin_append: track id outside the handle's capacity");
+    // The upload below is truly asynchronous (pinned source): the ring slot may be rewritten only once the copy that was issued
+    // from it eight appends ago has run -- appends can queue behind long kernels on the stream (a detector forward, a rebuild).
+    const int si = (int)(w->slot++ & 7);
+    if (w->copied_armed[si]) ODAM_HIP(hipEventSynchronize(w->copied[si]));
+    double* slot = w->stage + (size_t)si * 32 * (TW_COLS + 1);
+    for (int i = 0; i < n; i++) {
         for (int c = 0; c < TW_COLS; c++) slot[i * (TW_COLS + 1) + c] = rows14[i * TW_COLS + c];
         slot[i * (TW_COLS + 1) + TW_COLS] = (double)track_ids[i];
     }
     ODAM_HIP(hipMemcpyAsync(w->d_stage, slot, sizeof(double) * (size_t)n * (TW_COLS + 1), hipMemcpyHostToDevice, st));
+    ODAM_HIP(hipEventRecord(w->copied[si], st));
+    w->copied_armed[si] = true;
     hipLaunchKernelGGL(trackwin_append_kernel, dim3(n), dim3(64), 0, st, w->d_stage, n, w->rows, w->count, w->window);
     ODAM_HIP(hipGetLastError());
     return 0;
+}
+
+// Bulk (re)build of the mirror: track t gets the last min(lengths[t], window) of its observations -- rows14 holds exactly those,
+// track after track -- and the count lengths[t].  One upload and one launch; synchronises the stream (a rebuild is rare: first
+// use, or the host edited its track list).
+extern "C" int odam_trackwin_load(odam_trackwin* w, int T, const int* lengths, const double* rows14, void* stream) {
+    if (!w || T < 0 || T > w->max_tracks || (T && (!lengths || !rows14))) return odam_fail(1, "odam_trackwin_load: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    ODAM_HIP(hipMemsetAsync(w->count, 0, sizeof(int) * (size_t)w->max_tracks, st));
+    if (T == 0) return 0;
+    std::vector<int> meta(2 * (size_t)T);      // [t] = first row of track t in rows14, [T + t] = its length
+    long total = 0;
+    for (int t = 0; t < T; t++) {
+        if (lengths[t] < 0) return odam_fail(1, "odam_trackwin_load: negative track length");
+        meta[t] = (int)total; meta[T + t] = lengths[t];
+        total += lengths[t] < w->window ? lengths[t] : w->window;
+    }
+    double* d_rows = nullptr; int* d_meta = nullptr;
+    if (hipMalloc((void**)&d_rows, sizeof(double) * (size_t)(total ? total : 1) * TW_COLS) != hipSuccess ||
+        hipMalloc((void**)&d_meta, sizeof(int) * 2 * (size_t)T) != hipSuccess) {
+        if (d_rows) (void)hipFree(d_rows);
+        return odam_fail(2, "odam_trackwin_load: allocation failed");
+    }
+    int rc = 0;
+    if (hipMemcpyAsync(d_rows, rows14, sizeof(double) * (size_t)total * TW_COLS, hipMemcpyHostToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * 2 * (size_t)T, hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = odam_fail(2, "odam_trackwin_load: upload failed");
+    if (!rc) {
+        hipLaunchKernelGGL(trackwin_load_kernel, dim3(T), dim3(128), 0, st, d_rows, d_meta, T, w->rows, w->count, w->window);
+        if (hipGetLastError() != hipSuccess) rc = odam_fail(2, "odam_trackwin_load: launch failed");
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = odam_fail(2, "odam_trackwin_load: stream synchronisation failed");
+    (void)hipFree(d_rows); (void)hipFree(d_meta);
+    return rc;
 }
 
 extern "C" int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_px, const double* cam15, float* out, void* stream) {

@@ -1,0 +1,298 @@
+// cg_common.hpp -- what every translation unit of the contraction kernels shares: vector types, the hand-written LDS-DMA
+// instruction, the scale / bias / residual / ReLU epilogue, the exact three-way bf16 split of a fragment.  See conv_gemm.h.
+#pragma once
+#include "conv_gemm.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+#include "odam_config.h"
+#include "odam_err.h"
+
+namespace odam_cg {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// One k-tile is 8 chunks of 16 bytes per row in both precisions: 32 fp32 or 64 bf16 values; LDS rows are
+// padded by one chunk (144-byte rows: 16-byte aligned, conflict-free for ds_read_b128).
+constexpr int LDS_STRIDE = 36;  // floats per LDS row
+// CG_STAMP=1 (diagnostic build only, tests/native/ring_stamps.hip): the ring kernel accumulates s_memtime deltas of its
+// loop phases per wave (1 s_waitcnt vmcnt, 0 s_barrier, 2 first half of the matrix instructions, 3 the rest; the
+// unpipelined loops: 0 wait + barrier, 1 fragment reads + DMA issue) into g_stamps[0..3], k-tiles into [4], waves into [5].  No stamp executes in the product build.
+#ifndef CG_STAMP
+#define CG_STAMP 0
+#endif
+#if CG_STAMP
+static __device__ unsigned long long g_stamps[8];
+#define CG_STAMP_AT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                            st_acc[i] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CG_STAMP_AT(i) do { } while (0)
+#endif
+#if CG_STAMP      // phase stamps of the layer1 bottleneck tail (fused_chain), read by tests/native/tail_stamps.py through odam_cg_tail_stamps
+static __device__ unsigned long long g_tail_stamps[8];
+#define CG_TSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                          ts_acc[i] += t_ - ts_prev; ts_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define CG_TSTAMP(i) do { } while (0)
+#endif
+#ifndef CG_ABLATE
+#define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores, 16 no first-tile load
+#endif
+
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_VOFF = 0x80000000u;   // >= num_records of every buffer descriptor below: the load returns zeros
+
+// UT ("uniform tap"): Cin is a multiple of the k-tile, so a whole k-tile lies inside one filter tap and the tap,
+// its input offset and the channel offset are wave-uniform (SGPRs).  The gather then costs three VALU
+// instructions per 16-byte load: per-row tap-validity bit -> select the row's byte offset or an out-of-range one ->
+// buffer_load_dwordx4 (hardware returns zeros for the padding halo and the ragged last tile; no branches).
+// One LDS-DMA instruction written by hand: the compiler does not know it, so it neither counts it in its own
+// s_waitcnt bookkeeping nor drains vmcnt before every ds_read that might alias the DMA's destination (which it does
+// for the builtin) -- the deep pipeline below retires these loads itself with counted waits.  M0 (the LDS
+// destination base) is compiler-reserved: saved, set and restored inside the statement.
+__device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, unsigned voff, int soff) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(rsrc), "s"(lds_byte), "s"(soff)
+                 : "memory");
+}
+
+// ---- epilogue shared by the kernels below: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------
+// acc[i][j] is the wave's (i, j)-th 32x32 accumulator tile of its (BM / WM) x (BN / WN) sub-tile; `smem` (at least
+// WM * WN * 32 * (BN / WN) floats, free after the K loop) is used to turn the sub-tile for wide stores.
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool BF16>
+__device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[TM][TN], float* smem, int smem_floats,
+                                         int m0, int n0, int wm, int wn, int wave, int lane) {
+    // ---- epilogue: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------------
+    // bf16 mode: residual and output are bf16 unless out_f32 asks for an fp32 result (the prediction heads).
+    const int half = lane >> 5;
+    const bool res_f32 = !BF16;
+    const bool out_f32 = !BF16 || a.out_f32;
+    auto load_res1 = [&](size_t idx) -> float {
+        return res_f32 ? reinterpret_cast<const float*>(a.res)[idx]
+                       : bf2f(reinterpret_cast<const unsigned short*>(a.res)[idx]);
+    };
+    auto store1 = [&](size_t idx, float v) {
+        if (out_f32) reinterpret_cast<float*>(a.C)[idx] = v;
+        else reinterpret_cast<unsigned short*>(a.C)[idx] = f2bf(v);
+    };
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;   // this wave's sub-tile
+    if constexpr (BF16) {
+        if (!a.out_f32 && (a.Cout & 7) == 0 && (a.ldc & 7) == 0) {
+            // bf16 output: 8 channels per lane, so that residual loads and stores are 16 bytes per lane (the 8-byte form
+            // of the path below moves bytes at 0.55-0.7 of the rate: the wide expand + residual layers are HBM-bound)
+            float* Ep = smem + wave * (32 * WCOLS);
+            constexpr int LPR = WCOLS / 8, RPI = 64 / LPR, NIT = 32 / RPI;
+            const int c8e = (lane % LPR) * 8;
+            const int n = n0 + wn * WCOLS + c8e;
+            const bool n_ok = n < a.Cout;
+            float sc[8], bi[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) { sc[c] = (n_ok && a.scale) ? a.scale[n + c] : 1.f; bi[c] = (n_ok && a.bias) ? a.bias[n + c] : 0.f; }
+            const unsigned short* resp = reinterpret_cast<const unsigned short*>(a.res);
+            unsigned short* outp = reinterpret_cast<unsigned short*>(a.C);
+            // The residual rows of ALL the wave's row tiles are requested before the first one is used: the expand + residual
+            // layers are bound by how many bytes a CU keeps in flight (one workgroup per CU: nothing else covers the epilogue's
+            // HBM latency), and one row tile at a time was 32 KB per CU -- 13 GB/s per CU, 3.1 TB/s over the chip
+            // (layer3's expand).  TM * NIT 16-byte registers per lane (64 at most) are free here: the K loop's fragments are dead.
+            uint4 rv[TM][NIT];
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
+                    rv[i][it] = uint4{0u, 0u, 0u, 0u};
+                    if (a.res && n_ok && m < a.M) rv[i][it] = *reinterpret_cast<const uint4*>(resp + (size_t)m * a.ldc + n);
+                }
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < TN; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * WCOLS + j * 32 + (lane & 31)] = acc[i][j][r];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int it = 0; it < NIT; it++) {
+                    const int row = it * RPI + lane / LPR;
+                    const int m = m0 + wm * WROWS + i * 32 + row;
+                    const float4 v0 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c8e]);
+                    const float4 v1 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c8e + 4]);
+                    const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    const unsigned rw[4] = {rv[i][it].x, rv[i][it].y, rv[i][it].z, rv[i][it].w};
+                    unsigned ow[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        float lo = v[2 * c] * sc[2 * c] + bi[2 * c], hi = v[2 * c + 1] * sc[2 * c + 1] + bi[2 * c + 1];
+                        lo += __builtin_bit_cast(float, rw[c] << 16);
+                        hi += __builtin_bit_cast(float, rw[c] & 0xffff0000u);
+                        if (a.relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+                        ow[c] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                    }
+                    if (n_ok && m < a.M) *reinterpret_cast<uint4*>(outp + (size_t)m * a.ldc + n) = uint4{ow[0], ow[1], ow[2], ow[3]};
+                }
+            }
+            return;
+        }
+    }
+    if ((a.Cout & 3) == 0 && (a.ldc & 3) == 0) {
+        // Wide path: the accumulator layout (one column per lane) would give 4-byte accesses; the sub-tile is
+        // turned through LDS (free after the K loop) so that every lane owns 4 consecutive channels of a row:
+        // 16-byte (fp32) / 8-byte (bf16) residual loads and stores, 256 / 128 contiguous bytes per 16 lanes.
+        // Unpadded rows: a wave writes 32 consecutive floats of one row per half (ds_write_b32: conflict-free), and
+        // the 16-lane groups of ds_read_b128 ({0-3,12-15,20-27}, ...) land on 16 distinct 16-byte slots for both
+        // 128-byte and 256-byte rows.
+        constexpr int EP_LD = WCOLS;
+        (void)smem_floats;
+        float* Ep = smem + wave * (32 * EP_LD);     // one 32-row slab per wave, reused for each of its TM row tiles
+        constexpr int LPR = WCOLS / 4;              // lanes per row
+        constexpr int RPI = 64 / LPR;               // rows per wave-instruction
+        constexpr int NIT = 32 / RPI;
+        const int c4e = (lane % LPR) * 4;
+        const int n = n0 + wn * WCOLS + c4e;
+        const bool n_ok = n < a.Cout;               // Cout % 4 == 0: the four channels are in or out together
+        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+        if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
+        if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
+        // residual rows: row tile i + 1's are requested as soon as row tile i's accumulators have gone to LDS (their registers
+        // are free then), i.e. before tile i is read back, combined and stored -- two row tiles of loads in flight per wave
+        // instead of one (the expand + residual layers are bound by the bytes a CU keeps in flight)
+        float4 rv[2][NIT];
+        auto load_res = [&](int i, float4 (&dst)[NIT]) {
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int m = m0 + wm * WROWS + i * 32 + it * RPI + lane / LPR;
+                dst[it] = float4{0.f, 0.f, 0.f, 0.f};
+                if (a.res && n_ok && m < a.M) {
+                    const size_t idx = (size_t)m * a.ldc + n;
+                    if (res_f32) {
+                        dst[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.res) + idx);
+                    } else {
+                        const ushort4 u = *reinterpret_cast<const ushort4*>(reinterpret_cast<const unsigned short*>(a.res) + idx);
+                        dst[it] = float4{bf2f(u.x), bf2f(u.y), bf2f(u.z), bf2f(u.w)};
+                    }
+                }
+            }
+        };
+        load_res(0, rv[0]);
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            // The slab is private to this wavefront and a wavefront's LDS operations execute in order, so the
+            // transposition needs no workgroup barrier (the K loop ended with one): waves store as soon as they are done.
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < TN; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++)
+                    Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * EP_LD + j * 32 + (lane & 31)] = acc[i][j][r];
+            if (i + 1 < TM) load_res(i + 1, rv[(i + 1) & 1]);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int row = it * RPI + lane / LPR;
+                const int m = m0 + wm * WROWS + i * 32 + row;
+                const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
+                const float4 rr = rv[i & 1][it];
+                float4 o;
+                o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                if (a.relu) {
+                    o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
+                    o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
+                }
+                if (n_ok && m < a.M && (!(CG_ABLATE & 8) || o.x == 12345.678f)) {   // 8: (almost) never store
+                    const size_t idx = (size_t)m * a.ldc + n;
+                    if (out_f32) {
+                        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + idx) = o;
+                    } else {
+                        ushort4 u = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
+                        *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + idx) = u;
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // Narrow path (channel counts that are not a multiple of 4: the prediction heads): residual values of a
+    // whole 32x32 tile are fetched first, then combined and stored.
+#pragma unroll
+    for (int j = 0; j < TN; j++) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        const bool n_ok = n < a.Cout;
+        const float sc = (a.scale && n_ok) ? a.scale[n] : 1.0f;
+        const float bi = (a.bias && n_ok) ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+            const int mb = m0 + wm * (BM / WM) + i * 32 + 4 * half;
+            float rv[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                rv[r] = (a.res && n_ok && m < a.M) ? load_res1((size_t)m * a.ldc + n) : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int m = mb + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] * sc + bi;
+                v += rv[r];
+                if (a.relu) v = v > 0.0f ? v : 0.0f;
+                if (n_ok && m < a.M) store1((size_t)m * a.ldc + n, v);
+            }
+        }
+    }
+}
+
+// The wave's 32-row accumulator tile as (row, column, value) triples, 64 columns at a time, for either matrix-instruction
+// shape: 32x32 blocks (lane: column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)) or 16x16 blocks (lane: column l & 15,
+// rows 4 (l >> 4) + r).  f(row 0..31, column 0..63 inside the group, channel = 64 h2 + column, value).
+template <int TN, class F>
+__device__ __forceinline__ void acc_cols64(floatx16 (&acc)[1][TN], int h2, int lane, F&& f) {
+    const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) f((r & 3) + 8 * (r >> 2) + 4 * half, j * 32 + l32, h2 * 64 + j * 32 + l32, acc[0][2 * h2 + j][r]);
+}
+template <int NJ, class F>
+__device__ __forceinline__ void acc_cols64(floatx4 (&acc)[2][NJ], int h2, int lane, F&& f) {
+    const int kq = lane >> 4, r16 = lane & 15;
+#pragma unroll
+    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) f(mi * 16 + 4 * kq + r, j * 16 + r16, h2 * 64 + j * 16 + r16, acc[mi][4 * h2 + j][r]);
+}
+
+__device__ __forceinline__ void cg_split8(const float4& c0, const float4& c1, uint4& hi, uint4& mid, uint4& lo) {
+    const float v[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+    unsigned uh[8], um[8], ul[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        uh[e] = __builtin_bit_cast(unsigned, v[e]);
+        const float r1 = v[e] - __builtin_bit_cast(float, uh[e] & 0xffff0000u);
+        um[e] = __builtin_bit_cast(unsigned, r1);
+        ul[e] = __builtin_bit_cast(unsigned, r1 - __builtin_bit_cast(float, um[e] & 0xffff0000u));
+    }
+    auto pk = [](unsigned lo_, unsigned hi_) { return __builtin_amdgcn_perm(hi_, lo_, 0x07060302u); };
+    hi = uint4{pk(uh[0], uh[1]), pk(uh[2], uh[3]), pk(uh[4], uh[5]), pk(uh[6], uh[7])};
+    mid = uint4{pk(um[0], um[1]), pk(um[2], um[3]), pk(um[4], um[5]), pk(um[6], um[7])};
+    lo = uint4{pk(ul[0], ul[1]), pk(ul[2], ul[3]), pk(ul[4], ul[5]), pk(ul[6], ul[7])};
+}
+
+constexpr int FUSE_W3_BYTES = 4 * 3 * 256 * 32, FUSE_LDS_BYTES = FUSE_W3_BYTES + 8 * 32 * 64 * 4;    // 96 KB + 64 KB = all of it
+
+}  // namespace odam_cg

@@ -23,24 +23,42 @@ class _Cfg(ctypes.Structure):
                 ("pre_norm", ctypes.c_int), ("dilation", ctypes.c_int)]
 
 
+def _axis_phase_table(counts, channels, temperature):
+    """[..., channels] float32: normalised running token count along one image axis times 2 pi, divided by the channel's
+    wavelength; even channels carry the sine and odd channels the cosine of the SAME wavelength (pairs share an exponent).
+    `counts` float32 [...], already divided by the axis total.  Every operation is the float32 torch CPU op the reference
+    applies at this point (position_encoding.py:31-43), so the table can be compared bit for bit."""
+    pair = torch.arange(channels, dtype=torch.float32).div(2, rounding_mode="floor")
+    wavelength = torch.pow(float(temperature), pair * 2 / channels)
+    phase = counts.unsqueeze(-1) / wavelength
+    table = torch.empty_like(phase)
+    table[..., 0::2] = torch.sin(phase[..., 0::2])
+    table[..., 1::2] = torch.cos(phase[..., 1::2])
+    return table
+
+
 def sine_position_embedding(h, w, num_pos_feats=128, temperature=10000, mask=None):
-    """PositionEmbeddingSine(128, normalize=True) for an h x w grid -> [h*w, 256] float32
-    (position_encoding.py:26-46; torch CPU ops, so the table equals the reference's bit for bit).  `mask` [h,w] bool
-    (True = padding) for an image padded inside a mixed-size batch; None = no padding."""
-    not_mask = torch.ones(1, h, w, dtype=torch.bool) if mask is None else ~mask.reshape(1, h, w)
-    y_embed = not_mask.cumsum(1, dtype=torch.float32)
-    x_embed = not_mask.cumsum(2, dtype=torch.float32)
-    eps, scale = 1e-6, 2 * math.pi
-    y_embed = y_embed / (y_embed[:, -1:, :] + eps) * scale
-    x_embed = x_embed / (x_embed[:, :, -1:] + eps) * scale
-    dim_t = torch.arange(num_pos_feats, dtype=torch.float32)
-    dim_t = temperature ** (2 * (dim_t // 2) / num_pos_feats)
-    pos_x = x_embed[:, :, :, None] / dim_t
-    pos_y = y_embed[:, :, :, None] / dim_t
-    pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
-    pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
-    pos = torch.cat((pos_y, pos_x), dim=3)  # [1, h, w, 256]
-    return pos.reshape(h * w, 2 * num_pos_feats).contiguous()
+    """Sine position table of an h x w token grid -> [h*w, 2*num_pos_feats] float32, row-major tokens, the vertical half of
+    the channels first (what PositionEmbeddingSine(128, normalize=True) returns, position_encoding.py:26-46; checked bit for
+    bit against the reference-run table tests/golden/detr_small.npz["pos_25x34"]).  `mask` [h,w] bool (True = padding)
+    for an image padded inside a mixed-size batch; None = no padding.
+
+    A token's coordinate is the count of unpadded tokens up to and including it along the axis, over the count of the
+    whole row / column (+1e-6), times 2 pi.  Without padding the two coordinates depend on the row resp. the column only, so
+    two 1-D tables are built and broadcast; with padding the counts are 2-D."""
+    two_pi = 2 * math.pi
+    out = torch.empty(h, w, 2 * num_pos_feats, dtype=torch.float32)
+    if mask is None:
+        rows = torch.arange(1, h + 1, dtype=torch.float32)
+        cols = torch.arange(1, w + 1, dtype=torch.float32)
+        out[:, :, :num_pos_feats] = _axis_phase_table(rows / (rows[-1] + 1e-6) * two_pi, num_pos_feats, temperature)[:, None, :]
+        out[:, :, num_pos_feats:] = _axis_phase_table(cols / (cols[-1] + 1e-6) * two_pi, num_pos_feats, temperature)[None, :, :]
+    else:
+        live = (~mask.reshape(h, w)).to(torch.float32)
+        down, across = live.cumsum(0), live.cumsum(1)
+        out[:, :, :num_pos_feats] = _axis_phase_table(down / (down[-1:, :] + 1e-6) * two_pi, num_pos_feats, temperature)
+        out[:, :, num_pos_feats:] = _axis_phase_table(across / (across[:, -1:] + 1e-6) * two_pi, num_pos_feats, temperature)
+    return out.reshape(h * w, 2 * num_pos_feats)
 
 
 def learned_position_embedding(row_embed, col_embed, h, w):

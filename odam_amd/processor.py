@@ -194,12 +194,13 @@ class OdamProcess:
         w = self._win
         if len(self.tracks) > w.max_tracks:
             return None
-        if w.lengths != [len(t) for t in self.tracks]:        # first use, or somebody edited self.tracks: rebuild the mirror
-            w.reset()
-            longest = max((len(t) for t in self.tracks), default=0)
-            for j in range(longest):                          # observation j of every track that has one: ids stay unique per call
-                ids = [i for i, t in enumerate(self.tracks) if len(t) > j]
-                w.append(ids, np.stack([self.tracks[i][j] for i in ids]))
+        # the window kernel reads the fitter's projected extents through a raw pointer on the window store's stream: both must
+        # live on one device (a detector + fitter on cuda:0 with the associator on cuda:1 takes the host path)
+        fdev = getattr(self._fitter(), "device", None)
+        if fdev is not None and torch.device(fdev) != w.device:
+            return None
+        if not w.in_step(self.tracks):                        # first use, or somebody edited self.tracks: rebuild the mirror
+            w.load(self.tracks)
         return w
 
     def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100, proj_px=None):
@@ -248,7 +249,7 @@ class OdamProcess:
         del cache[len(tracks):]
         for i, track in enumerate(tracks):
             n = len(track)
-            if i < len(cache) and cache[i][0] == n:
+            if i < len(cache) and cache[i][0] == n and cache[i][3] == _track_mark(track, n):
                 _, s_t, s_d = cache[i][:3]
             elif i < len(cache) and 0 < cache[i][0] < n and cache[i][3] == _track_mark(track, cache[i][0]):
                 k, s_t, s_d = cache[i][:3]
@@ -269,7 +270,7 @@ class OdamProcess:
         params[:, 4:7] = np.sqrt(params[:, 4:7] / 2)
         params = params.astype(np.float32)
         fitter = self._fitter()
-        win = self._windows() if len(tracks) else None
+        win = self._windows() if len(tracks) and n_times == getattr(getattr(self, "_win", None), "WINDOW", 100) else None
         if win is not None:
             # everything after the per-track means on the device: surface extents (odam_sq_project_extents), then the
             # [T, 79, n_times] window tensor in the current camera frame (odam_trackwin_build) -- nothing comes back to the host
@@ -319,7 +320,7 @@ class OdamProcess:
         matches scoring below `score_threshold` are dropped (index -1 reads the dustbin row, as in the reference)."""
         rows = self._track_rows(detections, T_wc, with_code=not self.no_code)
         win = getattr(self, "_win", None)
-        in_step = win is not None and win.lengths == [len(t) for t in self.tracks]      # the device mirror matches the tracks as they stand
+        in_step = win is not None and win.in_step(self.tracks)      # the device mirror matches the tracks as they stand
         ids, picked = [], []
         for det_id, track_id in enumerate(pred_match):
             if score_mat[track_id, det_id] < self.score_threshold:

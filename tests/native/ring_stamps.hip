@@ -5,6 +5,10 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DCG_STAMP=1 -I odam_amd/csrc -o tests/native/ring_stamps tests/native/ring_stamps.hip
 //   ./tests/native/ring_stamps [bf16]     (-DCG_STAMP=0: plain timing, no stamps execute)
 #include "../../odam_amd/csrc/conv_gemm.hip"
+#include "../../odam_amd/csrc/cg_big_f32.hip"
+#include "../../odam_amd/csrc/cg_big_bf16.hip"
+#include "../../odam_amd/csrc/cg_fused_f32.hip"
+#include "../../odam_amd/csrc/cg_fused_bf16.hip"
 #include "../../odam_amd/csrc/odam_common.hip"
 #include <cstdio>
 #include <cstring>

@@ -200,3 +200,66 @@ def test_process_sequence_with_network(golden):
         assert np.array_equal(t[:, :2], r[:, :2])
         assert np.allclose(t, r, rtol=1e-6, atol=1e-6)
     net.close()
+
+
+def _random_tracks(rs, lengths):
+    tracks = []
+    for n in lengths:
+        t = rs.normal(0, 1, (n, 82)); t[:, 14:78] = -1
+        t[:, 0] = np.arange(n) + rs.randint(0, 50)         # frame ids ascend inside a track
+        tracks.append(t)
+    return tracks
+
+
+@pytest.mark.gpu
+def test_track_windows_rebuild_and_queued_appends_equal_the_host_path():
+    """The device mirror of the track list (odam_trackwin_*) against OdamProcess._preprocess_tracks on the host:
+    (a) a bulk rebuild (odam_trackwin_load) from 40 tracks of 1..260 observations (ring wrap past the window of 100, more than
+    32 tracks); (b) the append path, 300 back-to-back appends queued behind a long kernel on the same stream -- the pinned
+    staging ring has eight slots and every upload from it is asynchronous, so a slot must not be rewritten before its copy has
+    run; (c) a track list edited at equal lengths is noticed (marks) and rebuilt."""
+    import torch
+    from odam_amd.associator import TrackWindows
+    from odam_amd.processor import OdamProcess, get_cam_azi
+    rs = np.random.RandomState(11)
+    proc = OdamProcess(None, None, None, None)
+    proc.init_sequence(np.array([[577.87, 0, 319.5], [0, 577.87, 239.5], [0, 0, 1.0]]), 480, 640)
+    Q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+    T_wc = np.eye(4); T_wc[:3, :3] = Q; T_wc[:3, 3] = rs.normal(size=3)
+    cam_azi = get_cam_azi(T_wc)
+    lengths = [1, 2, 99, 100, 101, 260, 37] + list(rs.randint(1, 230, 33))
+    tracks = _random_tracks(rs, lengths)
+    proj = rs.uniform(-200, 900, (len(tracks), 4))
+
+    def host(tr):
+        return np.ascontiguousarray(proc._preprocess_tracks(tr, T_wc, cam_azi, proj_px=proj).transpose(0, 2, 1))
+
+    def device(win):
+        out = win.build(torch.from_numpy(proj).to("cuda:0"), np.linalg.inv(T_wc), cam_azi, 640, 480)
+        return out.cpu().numpy()
+
+    win = TrackWindows("cuda:0")
+    win.load(tracks)                                                    # (a)
+    assert win.in_step(tracks)
+    assert np.array_equal(device(win), host(tracks))
+
+    # (b) observation j of every track that has one, one append call each (ids unique per call), all queued behind ~50 ms of
+    # device work so that far more than eight uploads are pending when the host refills the ring
+    win.reset()
+    busy = torch.randn(4096, 4096, device="cuda:0")
+    for _ in range(40):
+        busy = busy @ busy * 1e-3
+    for j in range(max(lengths)):
+        ids = [i for i, t in enumerate(tracks) if len(t) > j]
+        win.append(ids, np.stack([tracks[i][j] for i in ids]))
+    assert win.in_step(tracks)
+    assert np.array_equal(device(win), host(tracks))
+    del busy
+
+    # (c) same lengths, one track replaced: the marks differ, OdamProcess._windows() would rebuild
+    edited = [t.copy() for t in tracks]
+    edited[5] = _random_tracks(rs, [len(tracks[5])])[0]
+    assert not win.in_step(edited)
+    win.load(edited)
+    assert np.array_equal(device(win), host(edited))
+    win.close()
