@@ -42,6 +42,28 @@ PEAK_F32_SPLIT = PEAK_BF16_MFMA / 6
 PMC_SUMMARY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_summary.json")
 
 
+def parity_block():
+    """What the committed parity evidence says about the numbers on this line (north star: bit-exact IDs / class labels,
+    super-quadric parameters within 1e-4 relative) -- quoted from files the test suite writes and checks, not re-measured here."""
+    out = {"ids_and_class_labels": "bit-exact: detections per frame (count, class, NMS order), every association decision, track "
+                                   "membership and merge clusters equal the reference run of the whole chain (tests/test_e2e.py on "
+                                   "tests/golden/e2e.npz); class arg-max, keep sets and NMS order equal on every detector golden",
+           "sq_per_step": "kernel == CPU oracle bit for bit (1 ... 3000 views); oracle vs reference teacher-forced over 200 steps: points "
+                          "<= 4e-7, gradient <= 1e-5 of its max, Adam <= 1 ulp (tests/test_sq_oracle.py)"}
+    try:
+        with open(os.path.join(REPO, "tests", "golden", "sq_survey_table.txt")) as f:
+            tail = [l[1:].strip() for l in f.read().splitlines() if l.startswith("#")][1:]
+        out["sq_end_state_survey"] = tail
+        out["sq_end_state_note"] = ("free-running 200-step fits of 46 problems against the reference's own fits: NOT all within 1e-4 -- the fit "
+                                    "is a chain of arg-extreme decisions and the reference itself moves by more than 1e-4 under 1-2 ulp nudges "
+                                    "of its input (s) and across ATen's own CPU dispatch levels; the gate is e <= max(1e-4, 3 s) per problem "
+                                    "(tests/sq_survey_lib.py), whole-chain fits are pinned object by object (tests/e2e_lib.py: 25 of 33 "
+                                    "within 5e-5, 6 inside the reference's spread, 1 bistable)")
+    except OSError:
+        out["sq_end_state_survey"] = None
+    return out
+
+
 def pmc_summary():
     try:
         with open(PMC_SUMMARY) as f:
@@ -77,12 +99,20 @@ def main():
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[3] block (R101, bf16, 50 objects)")
     ap.add_argument("--config4-streams", type=int, default=3, help="HIP streams of the configs[3] block")
     ap.add_argument("--config4-batch", type=int, default=76, help="frames per forward of the configs[3] block")
+    ap.add_argument("--config4-frames", type=int, default=1000, help="frames of the configs[3] scene")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL); gloo + "
                     "--one-device let several ranks share one GPU for a functional check of the N > 1 path")
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--force-collectives", action="store_true", help="initialise the process group and run both "
                     "all-gathers even in a world of one (RCCL call path on a single GPU)")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered detections and fitted rows of the last step here (.npz)")
+    ap.add_argument("--full-chain", action="store_true", help="secondary block: the whole driver chain of run_processor.py:70-83 on the "
+                    "ranks of this job (detect shard -> all-gather -> association replayed on every rank -> fit of the RESULTING tracks "
+                    "-> merge -> fit; odam_amd/pipeline.py)")
+    ap.add_argument("--chain-frames", type=int, default=0, help="frames of the --full-chain block (0 = --frames)")
+    ap.add_argument("--chain-chunk", type=int, default=0, help="frames per all-gather of the --full-chain block (0 = the whole scene)")
+    ap.add_argument("--dump-chain", default="", help="every rank r writes tracks, fits and merge result of the --full-chain block to <path>.r<r>.npz")
+    ap.add_argument("--only-chain", action="store_true", help="run nothing but the --full-chain block (tests)")
     args = ap.parse_args()
 
     ws = int(os.environ.get("WORLD_SIZE", "1"))
@@ -131,6 +161,14 @@ def main():
     owners = [parallel.object_shard([len(t) for t in tracks], r, ws) for r in range(ws)]
     mine_all = mine = owners[rank]
     frame_ids = scene["img_names"]
+
+    if args.only_chain:
+        blk = full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, ws)
+        if rank == 0:
+            print(json.dumps({"full_chain": blk}))
+        if ws > 1 or args.force_collectives:
+            torch.distributed.destroy_process_group()
+        return
 
     det_ms = []
     last = {}
@@ -251,6 +289,7 @@ def main():
         "detect_only_frames_per_s_per_gpu": (f1 - f0) / t_det,
     }
     result.update(secondary)
+    result["parity"] = parity_block()
     pmc = pmc_summary()
     if conv_ms > 0 and det_phase_ms > 0:
         # Batches run on several HIP streams at once, so a launch's own duration includes the kernels it shares
@@ -335,6 +374,8 @@ def main():
                                   "measured": "streaming-formulation bytes (12000 + 80 F + 40 per object-step) x 200 steps / launch "
                                               "duration (HIP events): what an HBM-streaming formulation would move; this kernel "
                                               "sees each view's 80 bytes through L2 only"}}
+    if args.full_chain:
+        result["full_chain"] = full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, ws)
     if rank == 0 and ws == 1 and not args.no_config4:
         del frames
         detector.close()
@@ -388,7 +429,60 @@ def secondary_blocks(step, detector, chunk, frames, tracks, N, per_frame, scene,
     return out
 
 
-def _new_process(device, tracks_cap=128):
+def full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, ws):
+    """The chain a user of the reference runs (run_processor.py:70-83) on this job's ranks, through odam_amd.pipeline.run_scene:
+    every rank detects its frames, the detections are all-gathered, the sequential association loop (processor.py:306-345) is
+    replayed on every rank with the hand-written scene association weights (tests/scene_weights.py), the tracks THAT COME OUT are
+    dealt over the ranks and fitted, gathered, merged (run_merge.py:79-130) and fitted again.  Timed once after one untimed pass
+    over the first frames (handles, first tracks).  Not the headline metric: it contains the replicated association loop."""
+    from odam_amd import pipeline
+    n = args.chain_frames or args.frames
+    ids, T = scene["img_names"], scene["T_wcs"]
+    img_size = (synth.IMG_W, synth.IMG_H)
+    if args.chain_chunk or n != args.frames:      # a rank's frames are then spread over the scene: keep all of them resident
+        frames, f0 = build_frames(0, n, device), 0
+
+    def detect(a, b):
+        rows = []
+        for c0, rows16 in detector.detect_resident_chunks(frames[a - f0:b - f0], img_size, synth.K_SCANNET, chunk=args.chunk):
+            for i in range(rows16.shape[0]):
+                sel = detector.select(rows16[i], 0.6, True, 30)
+                rows.append(detection_array({k: [v] for k, v in sel.items()}, 0, ids[a + c0 + i], synth.IMG_W, synth.IMG_H))
+        return rows
+    proc, net = _new_process(device, fit_iters=200)
+    warm = min(n, 2 * args.batch * max(ws, 1))
+    pipeline.run_scene(proc, warm, ids, T, detect=detect, device=coll_dev, force=args.force_collectives)
+    proc.init_sequence(synth.K_SCANNET, synth.IMG_H, synth.IMG_W)
+    stages = {}
+    torch.cuda.synchronize()
+    if ws > 1:
+        torch.distributed.barrier()
+    s0 = time.perf_counter()
+    out = pipeline.run_scene(proc, n, ids, T, detect=detect, chunk=args.chain_chunk, device=coll_dev, force=args.force_collectives,
+                             stages=stages)
+    torch.cuda.synchronize()
+    if ws > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - s0
+    first = stages.pop("first_pass")
+    if args.dump_chain:
+        cat = lambda ts: np.concatenate([np.asarray(t).reshape(-1, 82) for t in ts]) if len(ts) else np.zeros((0, 82))
+        np.savez(f"{args.dump_chain}.r{rank}.npz", tracks=cat(proc.tracks), track_len=[len(t) for t in proc.tracks],
+                 params1=first["params"], fitted1=first["fitted"], qc1=np.asarray(first["bboxes_qc"]), dl1=np.asarray(first["bboxes_dl"]),
+                 merged=cat(out["tracks"]), merged_len=[len(t) for t in out["tracks"]],
+                 params2=out["params"], fitted2=out["fitted"], qc2=np.asarray(out["bboxes_qc"]), dl2=np.asarray(out["bboxes_dl"]))
+    res = {"frames": n, "ranks": ws, "value": n / dt, "unit": "frames/s", "ms": 1e3 * dt,
+           "stages_ms": {k: 1e3 * v for k, v in stages.items()},
+           "tracks": len(proc.tracks), "objects_after_merge": len(out["tracks"]),
+           "fitted_pass1": int(np.sum(first["fitted"])), "fitted_pass2": int(np.sum(out["fitted"])),
+           "chunk_frames": args.chain_chunk or n, "lost_persistent_launches": net.lost_launches,
+           "note": "odam_amd.pipeline.run_scene: detect (sharded) -> all-gather -> association replayed on every rank -> fit of the "
+                   "resulting tracks (sharded) -> all-gather -> merge -> fit (sharded) -> all-gather; wall clock of rank 0 between barriers"}
+    net.close()
+    return res
+
+
+def _new_process(device, tracks_cap=128, fit_iters=1):
     sys.path.insert(0, os.path.join(REPO, "tests"))
     import scene_weights
     from odam_amd import associator
@@ -400,7 +494,7 @@ def _new_process(device, tracks_cap=128):
     class _Det:
         pass
     d = _Det(); d.device = device
-    proc = OdamProcess(d, net, None, None, fitter=sq.SqFitter(device, 1))
+    proc = OdamProcess(d, net, None, None, fitter=sq.SqFitter(device, fit_iters))
     proc.init_sequence(synth.K_SCANNET, synth.IMG_H, synth.IMG_W)
     return proc, net
 
@@ -475,21 +569,22 @@ def association_overlapped(detector, frames, chunk, scene, device, N, fit_ms):
 
 def config4_block(device, args, pmc):
     """BASELINE configs[3]: DETR-R101, 800x600 input (-> 800x1066), bf16 weights / activations on the bf16 matrix
-    instruction, a 50-object scene for the fit.  A short sample of the same step as the headline line: 256 resident
-    raw frames through transform + forward + post-processing + host NMS / rows, then two fit passes over 50 objects."""
+    instruction, a 50-object scene for the fit.  The same step as the headline line on a scene of its own: 1000 resident raw
+    800x600 frames through transform + forward + post-processing + host NMS / rows, then two fit passes over 50 objects whose
+    tracks were projected with the 800x600 intrinsics (one untimed pass, one timed; nothing extrapolated)."""
     # 76 frames per forward: the ring kernels run one 256-row tile per CU at a time, and at 76 frames layer3 / layer4 / the
     # encoder are 3.9 / 1.98 rounds of 256 tiles (at 32: 1.64 and 0.84 -- the last round a third empty); one forward alone:
     # 0.529 ms per frame at 76 against 0.598 at 32 (tests/native/perf_batch_sweep.py, profiles/r3_batch_sweep.txt)
     B = args.config4_batch
-    n_frames, n_obj = 8 * B, 50
+    n_frames, n_obj = args.config4_frames, 50
     det = det_mod.Detector(backbone="resnet101", max_batch=B, device=device, n_streams=args.config4_streams, dtype="bf16")
     det.load_state_dict(weights.make_state_dict(backbone="resnet101", seed=0, scene=True))
     fitter = sq.SqFitter(device, 200)
     base = np.stack(list(synth.make_frames(32, h=600, w=800, seed=4)))
     frames = torch.from_numpy(np.concatenate([base] * ((n_frames + 31) // 32))[:n_frames]).to(device)
-    K = np.array([[722.3, 0.0, 399.5], [0.0, 722.3, 299.5], [0.0, 0.0, 1.0]])
+    K = np.array([[722.3, 0.0, 399.5], [0.0, 722.3, 299.5], [0.0, 0.0, 1.0]])      # the ScanNet intrinsics scaled to 800x600
     H, W = transforms.target_size(800, 600)
-    scene = synth.make_scene(1000, n_obj, seed=2, min_views=10, max_views=300)
+    scene = synth.make_scene(n_frames, n_obj, seed=2, K=K, img_w=800, img_h=600, min_views=10, max_views=min(300, n_frames))
     ids = scene["img_names"]
 
     def step():
@@ -501,8 +596,8 @@ def config4_block(device, args, pmc):
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(2):
-            multi_view.optim_process(scene["tracks"], ids, scene["T_wcs"], scene["P_cws"], synth.IMG_H, synth.IMG_W,
-                                     synth.K_SCANNET, "super_quadric", True, 200, 10, fitter=fitter)
+            multi_view.optim_process(scene["tracks"], ids, scene["T_wcs"], scene["P_cws"], 600, 800, K, "super_quadric", True, 200, 10,
+                                     fitter=fitter)
         torch.cuda.synchronize()
         return n, t1
     step()
@@ -520,7 +615,8 @@ def config4_block(device, args, pmc):
     return {"workload": "DETR-R101, %d frames 800x600 -> 800x1066, bf16 (fp32 accumulate / softmax / LayerNorm / heads), batches of %d on %d "
                         "streams + 2 passes of 200-step SQ fit over %d objects (fp32)" % (n_frames, B, args.config4_streams, len(scene["tracks"])),
             "dtype": "bf16", "frames_per_s_detect": fps_det, "fit_ms_two_passes": 1e3 * (t2 - t1),
-            "frames_per_s_scene_of_1000": 1000.0 / (1000.0 / fps_det + (t2 - t1)),
+            "frames": n_frames, "extrapolated": False,
+            "frames_per_s_scene": n_frames / (t2 - t0),
             "detections_per_frame": n_det / n_frames,
             "roofline": {"bound": "mfma", "achieved": conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None,
                          "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
@@ -556,13 +652,21 @@ def cpu_baseline(scene, tracks, N):
             out = detr_oracle.detr_forward(sd, x)
             detr_oracle.postprocess(out, (synth.IMG_W, synth.IMG_H), 0.6, synth.K_SCANNET)
         return len(xs) / (time.perf_counter() - s_)
+    def rates(xs):
+        """per-frame rates: a CPU box shared with the driver jitters by 2x between consecutive frames, so every thread count is
+        judged by the MEDIAN of >= 5 single-frame timings and the spread is reported"""
+        r = []
+        for x in xs:
+            r.append(run([x]))
+        return r
+    per = {}
     for nt in sorted({n for n in (8, 16, 32, min(64, ncpu)) if n <= ncpu}):   # beyond 64 threads the box only gets slower (256: 0.01 frames/s)
         torch.set_num_threads(nt)
         detr_oracle.detr_forward(sd, imgs[0])          # warm-up at this thread count
-        sweep[nt] = run(imgs[1:3])
+        per[nt] = rates(imgs[1:6])
+        sweep[nt] = float(np.median(per[nt]))
     best = max(sweep, key=sweep.get)
-    torch.set_num_threads(best)
-    det_fps = run(imgs[1:6])                           # >= 5 frames at the thread count that is reported
+    det_fps = sweep[best]                              # BASELINE.md section 4: >= 5 frames at the thread count that is reported
     torch.set_num_threads(keep)
     o = Oracle()
     sample = sorted(range(len(tracks)), key=lambda i: len(tracks[i]))[len(tracks) // 2 - 1: len(tracks) // 2 + 2]
@@ -575,12 +679,14 @@ def cpu_baseline(scene, tracks, N):
     sq_ops = len(sample) / (time.perf_counter() - s)
     e2e = N / (N / det_fps + 2 * len(tracks) / sq_ops)
     return {"value": e2e, "unit": "frames/s", "cores": ncpu, "threads_used": best, "kind": "port",
-            "sample": f"detector oracle (torch CPU fp32, host transform + forward + post-processing): 2 frames per thread count over "
-                      f"{sorted(sweep)} threads, then 5 frames at the best ({best} threads: {det_fps:.3f} frames/s) on a host with "
+            "sample": f"detector oracle (torch CPU fp32, host transform + forward + post-processing): 5 frames at each of "
+                      f"{sorted(sweep)} threads, median of the single-frame rates per thread count, the best reported ({best} threads: "
+                      f"{det_fps:.3f} frames/s, min {min(per[best]):.3f} max {max(per[best]):.3f}) on a host with "
                       f"{ncpu} logical cores; SQ oracle (analytic-gradient C "
                       f"port, 1 thread -- faster than the reference's autograd loop): {len(sample)} median-size objects at "
                       f"{sq_ops:.2f} objects/s; composed as N/(N/det + 2*O/sq) for the {N}-frame, {len(tracks)}-object scene",
             "detector_frames_per_s": det_fps, "detector_frames_per_s_by_threads": {str(k): v for k, v in sweep.items()},
+            "detector_frames_per_s_spread_by_threads": {str(k): [min(v), max(v)] for k, v in per.items()},
             "sq_objects_per_s": sq_ops}
 
 

@@ -593,7 +593,7 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
         const long Mst = (long)B * m->H1 * m->W1;
         const bool rows_mode = dt ? (m->stem_rows.w != nullptr && odam_cfg::get(odam_cfg::CG_RING) != 0)
                                   : (m->stem_rows.w3 != nullptr && odam_cg::f32_mode() == 2);
-        if (rows_ok && rows_mode && Mst >= 192L * 256) {
+        if (rows_ok && rows_mode && (Mst >= 192L * 256 || odam_cfg::get(odam_cfg::CG_PIN))) {
             RC(odam_dk::launch_nchw_to_nhwc4_framed(img, m->x4, B, c.img_h, c.img_w, dt, st));
             RC(stem_rows_t(m, B, st));
         } else {

@@ -369,8 +369,13 @@ class OdamProcess:
         self.logger.info("Merging tracks")
         return merge.merge_process(data, self.usable_frames)
 
-    def optim_process(self, tracks):
+    def optim_process(self, tracks, return_params=False):
         m = self.sequence_meta
         return multi_view.optim_process(tracks, self.usable_frames, self.T_wcs, self.P_cws, m.img_h, m.img_w, m.K,
                                         self.representation, prior=True, n_iters=200, n_views=10,
-                                        fitter=self._fitter())
+                                        fitter=self._fitter(), return_params=return_params)
+
+    def optim_process_params(self, tracks):
+        """optim_process + the fitted parameter rows and the fitted / not-fitted flags (what a rank sends to the others:
+        odam_amd/pipeline.py)"""
+        return self.optim_process(tracks, return_params=True)

@@ -36,3 +36,31 @@ def test_two_ranks_on_one_device_equal_one_rank(tmp_path):
         assert np.array_equal(za["cnt"], z["cnt"])
         assert np.array_equal(za["blk"].view(np.uint32), z["blk"].view(np.uint32))          # detections: bit for bit
         assert np.array_equal(za["fitted"].view(np.uint32), z["fitted"].view(np.uint32))    # fitted parameters + boxes
+
+
+def test_whole_chain_two_ranks_equal_one_rank(tmp_path):
+    """The chain a user runs (run_processor.py:70-83: detect -> associate -> fit -> merge -> fit) through
+    odam_amd.pipeline.run_scene on two ranks sharing the device (gloo) against one rank: 104 frames in batches of 16, so the
+    ranks' shards end in a ragged batch of 4 and the one-rank run in one of 8; the association is replayed on both ranks,
+    the tracks THAT COME OUT are dealt over the ranks for both fit passes.  With the kernel choice pinned independent of the
+    row count (odam_config cg.pin = 1) everything is equal bit for bit: every track row (IDs = positions in the list), both
+    passes' parameters and boxes, the merged tracks; both ranks of the pair hold the same result.  A chunked gather (two
+    all-gathers per scene) gives the same again."""
+    bench = os.path.join(REPO, "bench.py")
+    chain = ["--only-chain", "--full-chain", "--frames", "104", "--objects", "4", "--batch", "16", "--streams", "2"]
+    env = {"ODAM_CONFIG": "cg.pin=1"}
+    a, b, c = (str(tmp_path / n) for n in "abc")
+    _run([sys.executable, bench, "--gpus", "1", "--dump-chain", a] + chain, env=env)
+    port = str(29300 + os.getpid() % 300)
+    two = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1"]
+    _run(two + ["--master-port", port, bench, "--gpus", "2", "--backend", "gloo", "--one-device", "--dump-chain", b] + chain, env=env)
+    _run(two + ["--master-port", str(int(port) + 1), bench, "--gpus", "2", "--backend", "gloo", "--one-device", "--chain-chunk", "64",
+                "--dump-chain", c] + chain, env=env)
+    za = np.load(a + ".r0.npz")
+    assert len(za["track_len"]) >= 10 and za["fitted1"].sum() >= 3 and za["fitted2"].sum() >= 3      # the chain did real work
+    assert len(za["merged_len"]) <= len(za["track_len"])
+    for path in (b + ".r0.npz", b + ".r1.npz", c + ".r0.npz", c + ".r1.npz"):
+        z = np.load(path)
+        for k in za.files:
+            assert za[k].shape == z[k].shape, (path, k)
+            assert np.array_equal(za[k].view(np.uint8), z[k].view(np.uint8)), (path, k)

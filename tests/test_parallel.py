@@ -120,3 +120,78 @@ def test_allgather_gloo_world_of_8():
     for p in procs:
         p.join(timeout=60)
     assert len(res) == 8 and all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
+
+
+def _chain(z, oracle, chunk):
+    """odam_amd.pipeline.run_scene over the canned-detection sequence of tests/golden/process_tracks.npz with the oracle-backed
+    test doubles (tests only): returns everything a rank ends up holding"""
+    import sys
+    from conftest import GOLDEN
+    sys.path.insert(0, GOLDEN)
+    from make_golden_process import FakeAssociator
+    from test_multi_view_host import OracleFitter
+    from odam_amd import pipeline
+    from odam_amd.processor import OdamProcess
+
+    class _Det:
+        device = "cpu"
+    proc = OdamProcess(_Det(), FakeAssociator(), None, None, fitter=OracleFitter(oracle))
+    proc.init_sequence(z["K"], 480, 640)
+    ids = [int(f) for f in z["img_names"]]
+    calls = []
+
+    def detect(f0, f1):
+        calls.append((f0, f1))
+        return [np.asarray(z[f"det{ids[f]}"], np.float64).reshape(-1, 79) for f in range(f0, f1)]
+    stages = {}
+    out = pipeline.run_scene(proc, len(ids), ids, z["scene_T_wcs"], detect=detect, chunk=chunk, device="cpu", stages=stages)
+    first = stages["first_pass"]
+    cat = lambda ts: np.concatenate([np.asarray(t).reshape(-1, 82) for t in ts])
+    return {"tracks": cat(proc.tracks), "lens": np.array([len(t) for t in proc.tracks]), "calls": np.array(calls),
+            "p1": first["params"], "f1": first["fitted"], "qc1": np.asarray(first["bboxes_qc"]), "dl1": np.asarray(first["bboxes_dl"]),
+            "merged": cat(out["tracks"]), "mlens": np.array([len(t) for t in out["tracks"]]),
+            "p2": out["params"], "f2": out["fitted"], "qc2": np.asarray(out["bboxes_qc"]),
+            "pts": np.stack([q.compute_ellipsoid_points()[0] for q in out["quadrics"]])}
+
+
+def _worker_chain(rank, ws, port, chunk, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    from conftest import GOLDEN, Oracle
+    res = _chain(np.load(os.path.join(GOLDEN, "process_tracks.npz")), Oracle(), chunk)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunk", [0, 16])
+def test_run_scene_world_of_2_equals_world_of_1(chunk, oracle, golden):
+    """The whole driver chain (run_processor.py:70-83) through odam_amd.pipeline.run_scene: two gloo ranks -- each detects its
+    share of every chunk, association replayed on both, the RESULTING tracks dealt over the ranks for both fit passes, merge in
+    between -- end with what one rank computes alone, bit for bit, on both ranks: track rows and IDs, parameters, fitted flags,
+    float64 boxes (they travel as 32-bit word pairs), merged tracks, surface points of the final quadrics (re-sampled from the
+    parameters where another rank did the fit)."""
+    z = golden("process_tracks.npz")
+    one = _chain(z, oracle, chunk)
+    assert len(one["lens"]) == int(z["n_tracks"]) and one["f1"].sum() >= 2
+    for i in range(int(z["n_tracks"])):      # and the one-rank chain is the reference's track list (float32 detection transport)
+        assert np.array_equal(one["tracks"][one["lens"][:i].sum():one["lens"][:i + 1].sum(), :2], z[f"track{i}"][:, :2])
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() + 131 + chunk) % 2000
+    procs = [ctx.Process(target=_worker_chain, args=(r, 2, port, chunk, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+    n = len(z["img_names"])
+    spans = [(0, n)] if not chunk else [(c, min(n, c + chunk)) for c in range(0, n, chunk)]
+    for r in range(2):
+        want_calls = [(c0 + s, c0 + e) for c0, c1 in spans for s, e in [__import__("odam_amd.parallel", fromlist=["x"]).frame_shard(c1 - c0, r, 2)]]
+        assert res[r]["calls"].tolist() == [list(c) for c in want_calls]      # a rank detects only its share of every chunk
+        for k in one:
+            if k == "calls":
+                continue
+            assert one[k].shape == res[r][k].shape, (r, k)
+            assert np.array_equal(np.ascontiguousarray(one[k]).view(np.uint8), np.ascontiguousarray(res[r][k]).view(np.uint8)), (r, k)

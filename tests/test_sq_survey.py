@@ -16,8 +16,12 @@ def _oracle_finals(z, oracle):
 
 def test_oracle_vs_reference_spread(oracle, golden):
     z = golden("sq_survey.npz")
-    rows = S.survey_rows(z, _oracle_finals(z, oracle), oracle)
+    rows = S.survey_rows(z, _oracle_finals(z, oracle), oracle, dispatch=golden("sq_survey_dispatch.npz"))
     S.check(rows)
+    # the reference's own answer depends on the instruction set ATen dispatches its CPU kernels to at least as much as ours
+    # differs from it: the stored (AVX-512) run and the scalar-kernel run agree to 1e-4 on no more than about half of the problems
+    assert sum(r["d"]["avx512"] == 0 for r in rows) == len(rows)
+    assert sum(r["d"]["default"] <= 1e-4 for r in rows) <= 0.6 * len(rows)
     # the committed table is this very measurement
     path = os.path.join(GOLDEN, "sq_survey_table.txt")
     if os.environ.get("ODAM_WRITE_SURVEY_TABLE"):
