@@ -90,6 +90,16 @@ void sample_on_batch(float* shapes, float* epsilons, float* etas, float* omegas,
  * library's return-code convention:  a[3], e[2] -> etas[1000], omegas[1000]  (all [host]). */
 int odam_sq_sample(const float* a, const float* e, float* etas, float* omegas);
 
+/* Result extraction of a fit pass (run_multi_view.py:66-67): the reference's compute_oriented_bbox (src/utils/box_utils.py:319-410)
+ * for n_obj surfaces -- qhull's 2-D hull of the xy projection walked as an OPEN polygon from qhull's own start vertex, the
+ * smallest rectangle over the edge directions, the z extent.  points [host][n_obj][n_pts][3] float32 (the fit's out_points,
+ * downloaded) -> corners [host][n_obj][8][3] float64, status [host][n_obj]: 0 = done; 1 = this object sits inside qhull's
+ * round-off tolerance band (or two candidate rectangles tie to 1e-9) and must be recomputed with scipy / qhull itself, which is
+ * what the reference calls -- odam_amd/multi_view.py does.  Host code, multi-threaded, no device call. */
+int odam_sq_oriented_bbox(const float* points, int n_obj, int n_pts, double* corners, int* status);
+/* the hull alone (tests): hull [host][n_pts] <- point indices in the order of scipy's ConvexHull(points[:, :2]).vertices */
+int odam_sq_hull2d(const float* points, int n_pts, int* hull, int* n_hull, int* status);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,6 +85,30 @@ def compute_oriented_bbox(pts):
     return np.concatenate([upper, lower], axis=0)
 
 
+def compute_oriented_bboxes(points):
+    """compute_oriented_bbox for a batch: points [n, N, 3] float32 -> list of n [8, 3] float64 boxes.
+
+    The library's host routine (include/odam_sq.h, odam_sq_oriented_bbox; csrc/hull2d.h) follows qhull's 2-D construction so that
+    the hull's vertex ORDER -- which decides the edge the reference's open polygon leaves out -- is qhull's; an object that sits
+    inside qhull's round-off tolerance band (status 1: exact coincidences, cube-like surfaces) is recomputed here with
+    scipy's qhull, the library the reference itself calls.  Returns (boxes, n_recomputed)."""
+    import ctypes
+    from . import _lib
+    pts = np.ascontiguousarray(points, np.float32)
+    n = len(pts)
+    if n == 0:
+        return [], 0
+    corners = np.empty((n, 8, 3), np.float64)
+    status = np.ones(n, np.int32)
+    _lib.check(_lib.lib().odam_sq_oriented_bbox(pts.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(n), ctypes.c_int(pts.shape[1]),
+                                                corners.ctypes.data_as(ctypes.c_void_p), status.ctypes.data_as(ctypes.c_void_p)),
+               "odam_sq_oriented_bbox")
+    redo = np.flatnonzero(status)
+    for i in redo:
+        corners[i] = compute_oriented_bbox(pts[i])
+    return [corners[i] for i in range(n)], len(redo)
+
+
 def _edge_lines(bbox, img_h, img_w, thr=EDGE_THRESHOLD):
     """bbox [[x_min,y_min],[x_max,y_max]] -> {name: [a, b, -value]} for edges farther than `thr`
     pixels from the image border (quadric_helper.py:69-109)."""
@@ -227,10 +251,14 @@ def optim_process(tracks, img_names, T_wcs, P_cws, img_h, img_w, K, representati
             points[i] = fpts[j]
 
     quadrics, bboxes_qc = [], []
+    boxes = {}
+    if fit_ids:       # oriented boxes of all fitted surfaces in one native call (run_multi_view.py:66-67)
+        bl, _ = compute_oriented_bboxes(np.stack([points[i] for i in fit_ids]))
+        boxes = dict(zip(fit_ids, bl))
     for obj_id in range(n_objs):
         if obj_id in points:  # run_multi_view.py:64-69
             quadrics.append(SuperQuadric(params[obj_id], classes[obj_id], points[obj_id], fitter))
-            bboxes_qc.append(compute_oriented_bbox(points[obj_id]))
+            bboxes_qc.append(boxes[obj_id])
         else:                 # fewer than n_views constrained frames: keep the detector box (:59-62)
             quadrics.append(SuperQuadric(params[obj_id], classes[obj_id], None, fitter))
             bboxes_qc.append(bboxes_dl[obj_id])
