@@ -146,6 +146,9 @@ int odam_op_conv_bf16_mode(int mode);
  * v_mfma_f32_32x32x16_bf16 (fp32-class accuracy -- 0.8-1.4e-7 of sum |a b| against float64, the fp32 instruction
  * 1.1-1.9e-7 -- at 2.7x the matrix rate; last bits differ from mode 0).  Process-wide; also ODAM_CG_BIG_F32. */
 int odam_op_conv_f32_mode(int mode);
+/* diagnostics: launches of conv1 with the max-pool on its tile (odam_config stem.pool) since the library was loaded -- lets a
+ * test see that the fused path, not the conv1 + max-pool pair, produced what it compares */
+long long odam_op_pooled_stem_launches(void);
 int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                       int B, int H, int Lq, int Lk, void* stream);
 int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y, int M,

@@ -109,6 +109,53 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     }
     const int tile_m = bid / tiles_n, tile_n = bid - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
+    // stem with the max-pool on the tile (ConvGemmArgs::pool): tile = a 2-D patch of conv outputs, (b, first row, first column)
+    constexpr bool POOLABLE = NTH == 1024 && BN == 64 && FUSE == 0 && (MODE == 4 || MODE == 0);
+    constexpr int pl_tw = 2 * POOL_PW + 1, pl_rows = (2 * POOL_PH + 1) * pl_tw;      // patch: 17 x 29 conv outputs
+    static_assert(pl_rows <= 512, "a patch fits a 512-row tile");
+    int pl_b = 0, pl_y0 = 0, pl_x0 = 0;
+    if constexpr (POOLABLE) {
+        if (a.pool) {
+            const int txs = (a.Wp + POOL_PW - 1) / POOL_PW, tys = (a.Hp + POOL_PH - 1) / POOL_PH;
+            pl_b = bid / (tys * txs);
+            const int rem = bid - pl_b * tys * txs, ty = rem / txs, tx = rem - ty * txs;
+            pl_y0 = 2 * ty * POOL_PH - 1; pl_x0 = 2 * tx * POOL_PW - 1;
+        }
+    }
+    // second half of the pooled epilogue: S = the patch after scale / bias / ReLU, [512 rows][BN + 4] fp32 in LDS (0 where the conv
+    // output does not exist: behind a ReLU, zero padding pools like max_pool2d's -inf padding); every thread takes (pooled pixel, 4
+    // channels) items: nine 16-byte reads, one store
+    auto pool_store = [&](const float* S) {
+        constexpr int SLD = BN + 4;
+        const int py0 = (pl_y0 + 1) >> 1, px0 = (pl_x0 + 1) >> 1;
+        constexpr int items = POOL_PH * POOL_PW * (BN / 4);
+        for (int it = tid; it < items; it += NTH) {
+            const int c4p = it & (BN / 4 - 1), pp = it / (BN / 4), ppy = pp / POOL_PW, ppx = pp - ppy * POOL_PW;
+            const int py = py0 + ppy, px = px0 + ppx;
+            if (py >= a.Hp || px >= a.Wp) continue;
+            const float* w0 = S + ((2 * ppy) * pl_tw + 2 * ppx) * SLD + c4p * 4;
+            float4 m4 = *reinterpret_cast<const float4*>(w0);
+#pragma unroll
+            for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+                for (int dx = 0; dx < 3; dx++) {
+                    if (dy == 0 && dx == 0) continue;
+                    const float4 v = *reinterpret_cast<const float4*>(w0 + (dy * pl_tw + dx) * SLD);
+                    m4.x = fmaxf(m4.x, v.x); m4.y = fmaxf(m4.y, v.y); m4.z = fmaxf(m4.z, v.z); m4.w = fmaxf(m4.w, v.w);
+                }
+            const size_t o = (((size_t)pl_b * a.Hp + py) * a.Wp + px) * a.ldc + c4p * 4;
+            if constexpr (BF16) {
+                const unsigned lo = (unsigned)f2bf(m4.x) | ((unsigned)f2bf(m4.y) << 16), hi = (unsigned)f2bf(m4.z) | ((unsigned)f2bf(m4.w) << 16);
+                *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.C) + o) = uint2{lo, hi};
+            } else {
+                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + o) = m4;
+            }
+        }
+    };
+    auto pool_row_ok = [&](int R) {      // does row R of the patch exist as a conv output?
+        const int dy = R / pl_tw, oy = pl_y0 + dy, ox = pl_x0 + R - dy * pl_tw;
+        return R < pl_rows && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+    };
 
     // ---- gather bookkeeping (uniform-tap path of the kernel above) -------------------------------------------------
     const int c4 = tid & 3, r0 = tid >> 2;
@@ -118,7 +165,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     const int ntaps = a.KH * a.KW;
     const int kw_inv = (65536 + a.KW - 1) / a.KW;
     const int nt_inv = (65536 + ntaps - 1) / ntaps;
-    const int b0 = m0 / hw;
+    const int b0 = (POOLABLE && a.pool) ? pl_b : m0 / hw;
     const int csrc = X16 ? (c4 ^ ((lane >> 4) & 1)) : (c4 ^ ((lane >> 4) & 3));     // 16-row fragments: rows r, r + 4 differ in the key (see X16)
     const int margin = (a.pad * a.W + a.pad) * lda;
     const unsigned long long pa = (unsigned long long)(Ag + (size_t)b0 * a.H * a.W * lda - margin), pw = (unsigned long long)Wg;
@@ -128,10 +175,15 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
 #pragma unroll
     for (int i = 0; i < A_LD; i++) {
         const int m = m0 + r0 + RPP * i;
-        const bool ok = m < a.M;
+        bool ok = m < a.M;
         const int mm = ok ? m : 0;
         int base, iy0 = 0, ix0 = 0;
-        if (plain) {
+        if (POOLABLE && a.pool) {      // row r of the patch = conv output (y0 + r / tw, x0 + r % tw) of image pl_b, where that exists
+            const int r = r0 + RPP * i, dy = r / pl_tw, oy = pl_y0 + dy, ox = pl_x0 + r - dy * pl_tw;
+            ok = r < pl_rows && (unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo;
+            iy0 = (ok ? oy : 0) * a.stride - a.pad; ix0 = (ok ? ox : 0) * a.stride - a.pad;
+            base = ((pl_b * a.H + iy0) * a.W + ix0) * lda;
+        } else if (plain) {
             base = mm * lda;
         } else {
             const int b = mm / hw, rem = mm - b * hw, oy = rem / a.Wo, ox = rem - oy * a.Wo;
@@ -483,6 +535,34 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         if constexpr (FUSE == 2) { fused_chain(a, c16, smem, lds_base, m0, wave, lane); return; }
         if constexpr (FUSE == 3) { fused_second128(a, c16, smem, lds_base, m0, wave, lane); return; }
         if constexpr (FUSE == 4) { fused_chain128(a, c16, smem, lds_base, m0, wave, lane); return; }
+        if constexpr (POOLABLE) {
+            if (a.pool) {
+                constexpr int SLD = BN + 4;
+                static_assert(BM * SLD * 4 <= NST * STAGE, "the pooling slab fits the ring");
+                float* S = smem;
+                float scv[NJ], biv[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    const int n = j * 16 + r16;
+                    scv[j] = a.scale ? a.scale[n] : 1.0f; biv[j] = a.bias ? a.bias[n] : 0.0f;
+                }
+#pragma unroll
+                for (int mi = 0; mi < MI; mi++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int R = wm * (BM / WM) + mi * 16 + 4 * kq + r;
+                        const bool ok = pool_row_ok(R);
+#pragma unroll
+                        for (int j = 0; j < NJ; j++) {
+                            const float v = c16[mi][j][r] * scv[j] + biv[j];
+                            S[R * SLD + j * 16 + r16] = (ok && v > 0.f) ? v : 0.f;
+                        }
+                    }
+                __syncthreads();
+                pool_store(S);
+                return;
+            }
+        }
         // epilogue of the 16x16 accumulators (lane: column l & 15, rows 4 (l >> 4) + r): scale / bias (+ residual) (ReLU), fp32
         // out; a row tile of 16 rows goes through a per-wave LDS slab (rows padded by 4 floats: the four row groups of a
         // ds_write_b32 land on different banks) and leaves as 16-byte stores
@@ -892,6 +972,32 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         fused_chain128(a, acc, smem, lds_base, m0, wave, lane);
         return;
     }
+    if constexpr (POOLABLE && MODE == 0) {
+        if (a.pool) {      // 32x32 accumulators (lane: column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)); bf16 output: the maximum of
+                           // fp32 values rounded once equals the maximum of the rounded values (rounding is monotonic)
+            constexpr int SLD = BN + 4;
+            static_assert(BM * SLD * 4 <= big_lds_bytes<MODE, BN, NST, NTH>(), "the pooling slab fits the ring");
+            float* S = smem;
+            const int half = lane >> 5, l32 = lane & 31;
+#pragma unroll
+            for (int i = 0; i < TM; i++)
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    const int n = wn * (BN / WN) + j * 32 + l32;
+                    const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int R = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        float v = acc[i][j][r] * sc + bi;
+                        v = bf2f(f2bf(v));      // rounded where the unfused path stores it
+                        S[R * SLD + n] = (pool_row_ok(R) && v > 0.f) ? v : 0.f;
+                    }
+                }
+            __syncthreads();
+            pool_store(S);
+            return;
+        }
+    }
     if constexpr (FUSE >= 5) {
         fused_bf16<BN, FUSE == 5 ? 0 : (32 << (FUSE - 5))>(a, acc, smem, lds_base, m0, wm, wn, wave, lane);
         return;
@@ -913,7 +1019,13 @@ static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
     }();
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     constexpr int bm = big_bm(BN, NTH);
-    const int tiles = ((a.M + bm - 1) / bm) * ((a.Cout + BN - 1) / BN);
+    int tiles = ((a.M + bm - 1) / bm) * ((a.Cout + BN - 1) / BN);
+    if (a.pool) {
+        if (!(NTH == 1024 && BN == 64 && (MODE == 4 || MODE == 0)) || a.Cout != 64 || a.pool_ph != POOL_PH || a.pool_pw != POOL_PW ||
+            a.ldc != a.Cout || a.res)
+            return odam_fail(1, "conv_gemm: pooled stem asked for where it does not apply");
+        tiles = a.B * ((a.Hp + POOL_PH - 1) / POOL_PH) * ((a.Wp + POOL_PW - 1) / POOL_PW);
+    }
     hipLaunchKernelGGL((conv_gemm_big_kernel<MODE, BN, NST, NTH>), dim3(tiles), dim3(NTH), bytes, stream, a);
     ODAM_HIP(hipGetLastError());
     return 0;

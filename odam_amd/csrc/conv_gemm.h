@@ -72,9 +72,18 @@ struct ConvGemmArgs {
     const void* G_Wt = nullptr;
     int dil = 1;                    // dilation of the taps (both axes): tap (ky, kx) reads input pixel (oy stride - pad + ky dil, ox stride - pad + kx dil);
                                     // the window loop and the bottleneck-on-the-tile launches take dil = 1 only
+    // Stem with the max-pool on the tile (conv_gemm_big_kernel, sixteen-wave 512 x 64 tiles only; launch_conv_gemm checks): pool = 1
+    // makes a tile a 2-D patch of (2 pool_ph + 1) x (2 pool_pw + 1) <= 512 conv outputs -- the 3 x 3 / stride 2 / pad 1 windows of
+    // pool_ph x pool_pw pooled pixels -- instead of 512 consecutive ones; after scale / bias / ReLU the patch is pooled in LDS and C
+    // receives the POOLED tensor [B, Hp, Wp, Cout] (ldc = Cout).  Patches overlap by one conv row / column (recomputed).  The
+    // ReLU makes zero padding equivalent to the -inf padding of max_pool2d.  M stays B Ho Wo (the conv's own size).
+    // pool_ph x pool_pw is fixed at POOL_PH x POOL_PW below (compile-time divisors in the kernel).
+    int pool = 0, pool_ph = 0, pool_pw = 0, Hp = 0, Wp = 0;
     int s1_window = 0;              // set by launch_conv_gemm (bf16 ring kernel, 3x3 stride 1): one LDS window per (channel slice, ky)
                                     //    serves the three horizontal taps (odam_config.h cg.s1)
 };
+
+constexpr int POOL_PH = 8, POOL_PW = 14;      // pooled pixels per patch: (2 * 8 + 1) x (2 * 14 + 1) = 493 conv outputs of a 512-row tile
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream);
 
@@ -89,6 +98,9 @@ void set_f32_mode(int mode);
 int f32_mode();
 // whether launch_conv_gemm would run `a` (with its F_* fields set) on the fused kernel right now
 bool fused_second_ok(const ConvGemmArgs& a);    // the mode fp32 layers run in right now (0 when the ring kernel is switched off altogether)
+
+// whether launch_conv_gemm would run `a` (pool fields set) with the max-pool on the tile (odam_config.h: stem.pool)
+bool pooled_stem_ok(const ConvGemmArgs& a);
 
 // bf16: whether launch_conv_gemm would run `a` (F_Wt [+ G_Wt] set) as one bottleneck launch (odam_config.h: cg.fuse_bf16)
 bool fused_bf16_ok(const ConvGemmArgs& a);

@@ -381,6 +381,25 @@ bool fused_bf16_ok(const ConvGemmArgs& a) {
     return big_eligible(a, a.Cout);
 }
 
+// the stem with the max-pool on the tile: what launch_conv_gemm needs to run `a` (pool fields set) on the sixteen-wave 512 x 64
+// tiles of the 16x16x32 split loop -- the kernel that has the pooling epilogue
+bool pooled_stem_ok(const ConvGemmArgs& a) {
+    const bool bf = a.dtype == ODAM_CG_BF16;
+    if (!g_big_mode || !(odam_cfg::get(odam_cfg::CG_TILES) & 8) || odam_cfg::get(odam_cfg::STEM_POOL) == 0) return false;
+    if (bf) {       // the sixteen-wave bf16 tiles take conv1 as a row convolution (pixel stride < row length), not a 3x3 stride 1
+        if (!(a.lda > 0 && a.lda < a.Cin) && g_big_mode < 2) return false;
+        if (a.KH * a.KW == 9 && a.stride == 1) return false;
+        if (a.out_f32) return false;
+    } else {
+        if (g_big_f32 != 2 || !a.Wt3 || odam_cfg::get(odam_cfg::CG_PRESPLIT) == 0 || odam_cfg::get(odam_cfg::CG_MFMA16) == 0) return false;
+        if (a.Kpad % 32 != 0 || (long)a.Cout * a.Kpad * 6 >= 0x7fffffffL) return false;
+    }
+    if (a.Cout != 64 || a.ldc != 64 || a.res || !a.relu) return false;
+    if (a.pool_ph != POOL_PH || a.pool_pw != POOL_PW) return false;
+    if (a.Hp != (a.Ho + 2 - 3) / 2 + 1 || a.Wp != (a.Wo + 2 - 3) / 2 + 1) return false;
+    return big_eligible(a, 64) && ((a.M + 511) / 512 >= 256 || odam_cfg::get(odam_cfg::CG_PIN));
+}
+
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     const int epc = (a.dtype == ODAM_CG_BF16) ? 8 : 4;
     if (a.Kpad % (8 * epc) != 0 || a.Cin < epc || (a.Cin & (a.Cin - 1)) != 0 || a.KW > 7 || a.KH * a.KW > 64)
@@ -388,6 +407,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
     if (a.k_order && (a.Cin % (8 * epc) != 0 || a.KH * a.KW > 32 || a.Kpad / (8 * epc) >= 2048))
         return odam_fail(1, "conv_gemm: k_order 1 needs Cin % k-tile == 0, at most 32 taps, fewer than 2048 k-tiles");
     if (a.M <= 0 || a.Cout <= 0) return 0;
+    if (a.pool) {
+        if (!pooled_stem_ok(a)) return odam_fail(1, "conv_gemm: pooled stem asked for where it does not apply (check pooled_stem_ok)");
+        return a.dtype == ODAM_CG_BF16 ? launch_big_bf16(64, 1024, a, stream) : launch_big_f32(4, 64, 1024, a, stream);
+    }
     if (a.F_Wt3) {
         if (!fused_second_ok(a)) return odam_fail(1, "conv_gemm: fused second layer asked for where it does not apply (check fused_second_ok)");
         return launch_big_fused(a, stream);

@@ -6,6 +6,7 @@
 // (post-norm encoder/decoder), src/models/position_encoding.py (sine embedding, passed in precomputed).
 // Layout: activations NHWC / [B*L, C] batch-major rows; every contraction runs on conv_gemm.
 #include <hip/hip_runtime.h>
+#include <atomic>
 
 #include <algorithm>
 #include <cmath>
@@ -319,7 +320,9 @@ int fused_c2c3_t(odam_detr* m, const Conv& c2, const Conv& c3, const void* x, in
 
 // conv1 over the framed image (forward_impl): the arguments run_conv cannot derive -- output width from the true image,
 // pixel stride smaller than the row length
-int stem_rows_t(odam_detr* m, int B, hipStream_t st) {
+static std::atomic<long long> g_pooled_stem_launches{0};
+// *pooled: in: try the max-pool on the tile (ConvGemmArgs::pool; output then goes to `pooled_out` [B, H2, W2, 64]); out: whether it ran so
+int stem_rows_t(odam_detr* m, int B, hipStream_t st, void* pooled_out = nullptr, bool* pooled = nullptr) {
     const Conv& c = m->stem_rows;
     const odam_detr_cfg& g = m->cfg;
     ConvGemmArgs a{};
@@ -329,6 +332,13 @@ int stem_rows_t(odam_detr* m, int B, hipStream_t st) {
     a.Ho = m->H1; a.Wo = m->W1;
     a.Cout = c.Cout; a.KH = 7; a.KW = 1; a.stride = 2; a.pad = 0; a.Kpad = c.Kpad;
     a.relu = 1; a.M = B * a.Ho * a.Wo; a.ldc = c.Cout; a.k_order = c.k_order;
+    if (pooled) {
+        // patches of 17 x 29 conv outputs = 8 x 14 pooled pixels (493 of the tile's 512 rows; 14 % of the conv recomputed at the seams)
+        a.pool = 1; a.pool_ph = odam_cg::POOL_PH; a.pool_pw = odam_cg::POOL_PW; a.Hp = m->H2; a.Wp = m->W2; a.C = pooled_out;
+        *pooled = odam_cg::pooled_stem_ok(a);
+        if (!*pooled) { a.pool = 0; a.C = m->stem_out; }
+        else g_pooled_stem_launches.fetch_add(1);
+    }
     if (!m->profile) return odam_cg::launch_conv_gemm(a, st);
     if (m->ev_used + 2 > m->ev.size()) {
         for (int k = 0; k < 2; k++) {
@@ -590,17 +600,18 @@ static int forward_impl(odam_detr* m, const float* img, int B, const unsigned ch
         // convolution with "Cin" = 32 floats per row, pixel stride lda = 4, no padding, K = 224 instead of 147 + pad --
         // a third of the products are zeros, on a path that is 2-3x faster than the 128x64 tiles of the fp32 instruction.
         const bool rows_ok = odam_cfg::get(odam_cfg::STEM_ROWS) != 0;
+        bool pooled = false;
         const long Mst = (long)B * m->H1 * m->W1;
         const bool rows_mode = dt ? (m->stem_rows.w != nullptr && odam_cfg::get(odam_cfg::CG_RING) != 0)
                                   : (m->stem_rows.w3 != nullptr && odam_cg::f32_mode() == 2);
         if (rows_ok && rows_mode && (Mst >= 192L * 256 || odam_cfg::get(odam_cfg::CG_PIN))) {
             RC(odam_dk::launch_nchw_to_nhwc4_framed(img, m->x4, B, c.img_h, c.img_w, dt, st));
-            RC(stem_rows_t(m, B, st));
+            RC(stem_rows_t(m, B, st, m->bufA, &pooled));
         } else {
             RC(odam_dk::launch_nchw_to_nhwc4(img, m->x4, B, c.img_h, c.img_w, dt, st));
             RC(conv_t(m, m->stem, m->x4, B, c.img_h, c.img_w, nullptr, true, m->stem_out, st));
         }
-        RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, dt, st));
+        if (!pooled) RC(odam_dk::launch_maxpool3x3s2(m->stem_out, m->bufA, B, m->H1, m->W1, 64, m->H2, m->W2, dt, st));
     }
     char* cur = m->bufA;
     char* nxt = m->bufB;
@@ -818,6 +829,8 @@ extern "C" int odam_op_conv_f32_mode(int mode) {
     odam_cg::set_f32_mode(mode);
     return 0;
 }
+
+extern "C" long long odam_op_pooled_stem_launches(void) { return g_pooled_stem_launches.load(); }
 
 extern "C" int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O,
                                  int ldo, int B, int H, int Lq, int Lk, void* stream) {

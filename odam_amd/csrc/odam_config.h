@@ -25,6 +25,7 @@ enum Key {
     SQ_SPLIT,       // super-quadric fit: workgroups per object at most (default 16)
     SQ_SPLIT_WAIT,  // ... bounded wait for a partner's rows, 100 MHz ticks (default 3000; 0 = never wait)
     SQ_LANES,       // ... lanes per view in the extent search (default 0 = chosen by the cost model)
+    STEM_POOL,      // conv1's 3x3 / stride 2 max-pool on the tile of the row-convolution stem (fp32 split mode, sixteen-wave tiles): default 1
     CG_PIN,         // 1: the kernel (tile shape, matrix instruction, fusion) chosen for a layer does not depend on how many rows it has --
                     // every size-dependent choice is taken as for a problem that fills the device, so a frame's result is bit-identical
                     // whatever batch or shard it arrives in (odam_amd/pipeline.py; slower for small batches).  Default 0

@@ -657,7 +657,7 @@ def test_bf16_r101_full_size_vs_bf16_faithful_oracle(measured):
 
 
 @pytest.mark.parametrize("cfg", ["cg.ut=0", "cg.tiles=0", "cg.tiles=7", "cg.tiles=15", "cg.force=2", "cg.ring=2", "cg.ring=0", "cg.ring=2,cg.presplit=0", "cg.f32=0",
-                                 "att.x3=0,cg.fuse=1", "stem.rows=0,cg.fuse=0", "cg.s1=0", "cg.fuse_bf16=0", "cg.fuse_bf16=1,att.bf16_mfma=0", "cg.mfma16=0"])
+                                 "att.x3=0,cg.fuse=1", "stem.rows=0,cg.fuse=0", "stem.pool=0", "cg.s1=0", "cg.fuse_bf16=0", "cg.fuse_bf16=1,att.bf16_mfma=0", "cg.mfma16=0"])
 def test_conv_gemm_alternative_paths(cfg):
     """Every surviving switch of the library's config table (include/odam_config.h): the register-staged gather (what layers too
     large for 31-bit buffer offsets fall back to), the 4-wave tiles, the four-stage small-tile pipeline, the ring kernel
@@ -673,7 +673,7 @@ def test_conv_gemm_alternative_paths(cfg):
     sel = "conv_gemm_vs_torch or conv_gemm_bf16"
     if cfg in ("cg.f32=0", "cg.mfma16=0"):      # the reference-run goldens and the oracle comparisons must hold on the fp32 instruction as well
         sel += " or reference_golden or vs_oracle or mixed_size"
-    if "stem.rows" in cfg or "cg.fuse=" in cfg:
+    if "stem." in cfg or "cg.fuse=" in cfg:
         sel = "reference_golden or vs_oracle"
     if "att.x3" in cfg:
         sel = "attention_vs_torch or reference_golden or vs_oracle or mixed_size"
@@ -682,6 +682,36 @@ def test_conv_gemm_alternative_paths(cfg):
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-k", sel],
                        env={**os.environ, "ODAM_CONFIG": cfg, "ODAM_NESTED": "1"}, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_pooled_stem_is_bit_identical():
+    """conv1 with the 3x3 / stride 2 max-pool on its tile (odam_config stem.pool, ConvGemmArgs::pool: 2-D patches of conv outputs
+    pooled in LDS, the 1.75 GB stem tensor of a 32-frame batch never written) against conv1 + the max-pool kernel: the same
+    products in the same order and an exact maximum, so every output of the forward is equal bit for bit -- at full size (3 frames:
+    patches at all four image borders, a ragged last patch column; fp32 and bf16) and on a small odd-sized input through the pinned
+    kernel choice."""
+    from odam_amd import _lib, detector, weights
+    sd = weights.make_state_dict(seed=0, scene=True)
+    try:
+        for shape, pin, dtype in (((3, 3, 800, 1066), 0, "fp32"), ((2, 3, 230, 310), 1, "fp32"), ((3, 3, 800, 1066), 0, "bf16")):
+            _lib.set_config("cg.pin", pin)
+            det = detector.Detector(max_batch=shape[0], device=DEV, n_streams=1, dtype=dtype)
+            det.load_state_dict(sd)
+            torch.manual_seed(3)
+            img = torch.randn(*shape, device=DEV)
+            outs = []
+            L = _lib.lib()
+            L.odam_op_pooled_stem_launches.restype = ctypes.c_longlong
+            for v in (1, 0):
+                _lib.set_config("stem.pool", v)
+                n0 = L.odam_op_pooled_stem_launches()
+                outs.append({k: t.clone() for k, t in det(img).items() if torch.is_tensor(t)})
+                assert L.odam_op_pooled_stem_launches() - n0 == v      # the path under test is the one that ran
+            det.close()
+            for k in KEYS:
+                assert torch.equal(outs[0][k], outs[1][k]), (shape, dtype, k)
+    finally:
+        _lib.set_config("stem.pool", 1); _lib.set_config("cg.pin", 0)
 
 
 def test_mixed_size_batch_vs_reference(golden):
