@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--force-collectives", action="store_true", help="initialise the process group and run both "
                     "all-gathers even in a world of one (RCCL call path on a single GPU)")
+    ap.add_argument("--native-collectives", action="store_true", help="both all-gathers through the library's own RCCL communicator "
+                    "(include/odam_comm.h: odam_allgather_detections) instead of torch.distributed")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered detections and fitted rows of the last step here (.npz)")
     ap.add_argument("--full-chain", action="store_true", help="secondary block: the whole driver chain of run_processor.py:70-83 on the "
                     "ranks of this job (detect shard -> all-gather -> association replayed on every rank -> fit of the RESULTING tracks "
@@ -131,8 +133,10 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=ws)
     device = f"cuda:{local_rank}"
+    if args.native_collectives and (ws > 1 or args.force_collectives):
+        parallel.use_native_collectives(device)
 
-    coll_dev = device if args.backend == "nccl" else "cpu"
+    coll_dev = device if (args.backend == "nccl" or args.native_collectives) else "cpu"
     N = args.frames
     f0, f1 = parallel.frame_shard(N, rank, ws)
     K = synth.K_SCANNET
@@ -282,7 +286,8 @@ def main():
         "config": {"workload": f"one scene: {N} frames 640x480 -> 800x1066, DETR-R50 detect + 2 passes of "
                                f"200-step SQ fit over {len(tracks)} objects (10-300 views), fp32",
                    "frames": N, "objects": len(tracks), "detector_batch": args.batch, "detector_streams": args.streams,
-                   "parallelism": f"frames and objects sharded over {ws} GPU(s)" + (", RCCL all-gather" if ws > 1 else "")},
+                   "parallelism": f"frames and objects sharded over {ws} GPU(s)" + (", RCCL all-gather" if ws > 1 else "") +
+                                  (" through odam_allgather_detections (include/odam_comm.h)" if args.native_collectives and ws > 1 else "")},
         "library_config": _lib.config(),      # every kernel-selecting switch in force (include/odam_config.h); defaults unless ODAM_CONFIG says otherwise
         "detections_per_scene": n_det,
         "detections_per_frame": n_det / N,

@@ -17,6 +17,46 @@ MAX_DETS = 30   # processor.py:318-319
 DET_COLS = 15   # the 64 shape-code columns are constant -1 with no_code=True (processor.py:286-287)
 
 
+_NATIVE = {}      # device string -> (handle, world, rank): the library's own RCCL communicator (include/odam_comm.h)
+
+
+def use_native_collectives(device):
+    """Route both all-gathers through the library's C ABI (include/odam_comm.h: ncclAllGather on the librccl the process has
+    mapped) instead of torch.distributed.  Collective over the ranks of the current process group: rank 0 draws the RCCL unique
+    id, torch.distributed carries its 128 bytes to the others (any backend), every rank creates its communicator on `device`.
+    Needs an initialised process group (a world of one included).  Returns the communicator's (world, rank)."""
+    import ctypes
+    from . import _lib
+    device = str(torch.device(device))
+    if device in _NATIVE:
+        return _NATIVE[device][1:]
+    rank, ws = dist.get_rank(), dist.get_world_size()
+    L = _lib.lib()
+    box = [None]
+    if rank == 0:
+        buf = (ctypes.c_ubyte * 128)()
+        _lib.check(L.odam_comm_unique_id(buf), "odam_comm_unique_id")
+        box[0] = bytes(buf)
+    dist.broadcast_object_list(box, src=0)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(torch.device(device)):
+        _lib.check(L.odam_comm_create((ctypes.c_ubyte * 128).from_buffer_copy(box[0]), ctypes.c_int(ws), ctypes.c_int(rank),
+                                      ctypes.byref(h)), "odam_comm_create")
+    _NATIVE[device] = (h, ws, rank)
+    return ws, rank
+
+
+def close_native_collectives():
+    from . import _lib
+    for h, _, _ in _NATIVE.values():
+        _lib.lib().odam_comm_destroy(h)
+    _NATIVE.clear()
+
+
+def _native(device):
+    return _NATIVE.get(str(torch.device(device))) if device is not None and str(device) != "cpu" else None
+
+
 def world():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
@@ -75,6 +115,26 @@ def allgather_detections(blk, cnt, n_frames, device=None, force=False):
     dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
     per = -(-n_frames // ws)  # padded shard length so all_gather_into_tensor sees equal shapes
     W = MAX_DETS * DET_COLS
+    nat = _native(dev)
+    if nat is not None:      # the library's own collective (include/odam_comm.h, odam_allgather_detections): block and counts stay separate
+        import ctypes
+        from . import _lib
+        hb = np.full((per, MAX_DETS, DET_COLS), -1.0, np.float32)
+        hc = np.zeros(per, np.int32)
+        hb[:len(cnt)] = blk; hc[:len(cnt)] = cnt
+        db, dc = torch.from_numpy(hb).to(dev), torch.from_numpy(hc).to(dev)
+        ab = torch.empty((ws, per, MAX_DETS, DET_COLS), dtype=torch.float32, device=dev)
+        ac = torch.empty((ws, per), dtype=torch.int32, device=dev)
+        with torch.cuda.device(torch.device(dev)):
+            _lib.check(_lib.lib().odam_allgather_detections(nat[0], _lib.ptr(db), _lib.ptr(dc), ctypes.c_int(per), _lib.ptr(ab), _lib.ptr(ac),
+                                                            ctypes.c_void_p(torch.cuda.current_stream(torch.device(dev)).cuda_stream)),
+                       "odam_allgather_detections")
+        gb, gc = ab.cpu().numpy(), ac.cpu().numpy()
+        ob, oc = [], []
+        for r in range(ws):
+            s, e = frame_shard(n_frames, r, ws)
+            ob.append(gb[r, :e - s]); oc.append(gc[r, :e - s])
+        return np.concatenate(ob), np.concatenate(oc)
     host = np.full((per, W + 1), -1.0, np.float32)
     host[:, W] = 0.0
     host[:len(cnt), :W] = blk.reshape(len(cnt), W)
@@ -108,6 +168,23 @@ def allgather_rows(local, n_total, owner_lists, device=None, force=False):
         return out
     dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
     per = max(len(o) for o in owner_lists)
+    nat = _native(dev)
+    if nat is not None:
+        import ctypes
+        from . import _lib
+        pad = torch.zeros((per,) + local.shape[1:], dtype=torch.float32, device=dev)
+        if len(local):
+            pad[:len(local)] = torch.from_numpy(local).to(dev)
+        g = torch.empty((ws * per,) + local.shape[1:], dtype=torch.float32, device=dev)
+        with torch.cuda.device(torch.device(dev)):
+            _lib.check(_lib.lib().odam_allgather_f32(nat[0], _lib.ptr(pad), ctypes.c_longlong(pad.numel()), _lib.ptr(g),
+                                                     ctypes.c_void_p(torch.cuda.current_stream(torch.device(dev)).cuda_stream)), "odam_allgather_f32")
+        g = g.cpu().numpy()
+        out = np.zeros((n_total,) + local.shape[1:], np.float32)
+        for r in range(ws):
+            idx = owner_lists[r]
+            out[idx] = g[r * per: r * per + len(idx)]
+        return out
     pad = torch.zeros((per,) + local.shape[1:], dtype=torch.float32, device=dev)
     if len(local):
         pad[:len(local)] = torch.from_numpy(local).to(dev)

@@ -1,7 +1,8 @@
 """The N > 1 code path of the hot path itself on ONE GPU: two ranks share the device (gloo between them) and run the
 whole bench step -- detect own frame shard -> all-gather of detections -> fit own objects -> all-gather of fits -- and the
 result equals the one-rank run bit for bit.  A third run drives the same collectives through RCCL in a world of one
-(backend "nccl"), the call path the 8-GPU driver run takes."""
+(backend "nccl"), the call path the 8-GPU driver run takes; a fourth through the library's own RCCL communicator
+(include/odam_comm.h), also a world of one."""
 import os
 import subprocess
 import sys
@@ -30,9 +31,14 @@ def test_two_ranks_on_one_device_equal_one_rank(tmp_path):
           "--master-port", port, bench, "--gpus", "2", "--backend", "gloo", "--one-device", "--dump", b] + ARGS)
     _run([sys.executable, bench, "--gpus", "1", "--force-collectives", "--dump", c] + ARGS,
          env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(int(port) + 1), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
-    za, zb, zc = np.load(a), np.load(b), np.load(c)
+    # ... and through the library's own communicator (include/odam_comm.h: odam_allgather_detections / odam_allgather_f32 on RCCL, the
+    # unique id carried by a gloo group), world of one
+    d = str(tmp_path / "d.npz")
+    _run([sys.executable, bench, "--gpus", "1", "--force-collectives", "--native-collectives", "--backend", "gloo", "--dump", d] + ARGS,
+         env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(int(port) + 2), "RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    za, zb, zc, zd = np.load(a), np.load(b), np.load(c), np.load(d)
     assert za["cnt"].sum() >= 96 * 5                       # the scene weights give real detection load
-    for z in (zb, zc):
+    for z in (zb, zc, zd):
         assert np.array_equal(za["cnt"], z["cnt"])
         assert np.array_equal(za["blk"].view(np.uint32), z["blk"].view(np.uint32))          # detections: bit for bit
         assert np.array_equal(za["fitted"].view(np.uint32), z["fitted"].view(np.uint32))    # fitted parameters + boxes
