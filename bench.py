@@ -108,9 +108,10 @@ def main():
     ap.add_argument("--native-collectives", action="store_true", help="both all-gathers through the library's own RCCL communicator "
                     "(include/odam_comm.h: odam_allgather_detections) instead of torch.distributed")
     ap.add_argument("--dump", default="", help="rank 0 writes the gathered detections and fitted rows of the last step here (.npz)")
-    ap.add_argument("--full-chain", action="store_true", help="secondary block: the whole driver chain of run_processor.py:70-83 on the "
-                    "ranks of this job (detect shard -> all-gather -> association replayed on every rank -> fit of the RESULTING tracks "
-                    "-> merge -> fit; odam_amd/pipeline.py)")
+    ap.add_argument("--full-chain", action="store_true", default=True, help="secondary block (on by default): the whole driver chain of "
+                    "run_processor.py:70-83 on the ranks of this job (detect shard -> all-gather -> association replayed on every rank -> fit of "
+                    "the RESULTING tracks -> merge -> fit; odam_amd/pipeline.py)")
+    ap.add_argument("--no-full-chain", dest="full_chain", action="store_false")
     ap.add_argument("--chain-frames", type=int, default=0, help="frames of the --full-chain block (0 = --frames)")
     ap.add_argument("--chain-chunk", type=int, default=0, help="frames per all-gather of the --full-chain block (0 = the whole scene)")
     ap.add_argument("--dump-chain", default="", help="every rank r writes tracks, fits and merge result of the --full-chain block to <path>.r<r>.npz")
@@ -379,8 +380,14 @@ def main():
                                   "measured": "streaming-formulation bytes (12000 + 80 F + 40 per object-step) x 200 steps / launch "
                                               "duration (HIP events): what an HBM-streaming formulation would move; this kernel "
                                               "sees each view's 80 bytes through L2 only"}}
-    if args.full_chain:
-        result["full_chain"] = full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, ws)
+    if args.full_chain and not args.no_secondary:
+        if ws == 1:
+            try:
+                result["full_chain"] = full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, ws)
+            except Exception as e:      # noqa: BLE001 -- a secondary figure must not take the line down
+                result["full_chain"] = {"error": repr(e)}
+        else:       # collective: every rank is inside; an exception on one rank would strand the others, so it is not caught here
+            result["full_chain"] = full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, ws)
     if rank == 0 and ws == 1 and not args.no_config4:
         del frames
         detector.close()

@@ -13,5 +13,5 @@ cp $O/r4_bench_prof/t_kernel_stats.csv $O/r4_bench_steps1_kernel_stats.csv 2>/de
 rm -rf $O/r4_bench_prof
 cd $R
 bash tests/native/sq_stamps.sh > $O/r4_sq_phase_stamps.txt 2>&1
-python3 bench.py --steps 3 --warmup 1 --full-chain > $O/r4_bench_line.json 2> $O/r4_bench_line.err
+python3 bench.py --steps 3 --warmup 1 > $O/r4_bench_line.json 2> $O/r4_bench_line.err
 tail -c 600 $O/r4_bench_line.json

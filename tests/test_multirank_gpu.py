@@ -13,7 +13,7 @@ import pytest
 from conftest import REPO
 
 pytestmark = pytest.mark.gpu
-ARGS = ["--frames", "96", "--objects", "6", "--steps", "1", "--warmup", "0", "--batch", "16", "--no-cpu-baseline", "--no-config4"]
+ARGS = ["--frames", "96", "--objects", "6", "--steps", "1", "--warmup", "0", "--batch", "16", "--no-cpu-baseline", "--no-config4", "--no-full-chain"]
 
 
 def _run(cmd, env=None):
