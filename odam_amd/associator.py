@@ -38,7 +38,7 @@ class TrackWindows:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().odam_trackwin_create(max_tracks, self.WINDOW, ctypes.byref(self._h)), "odam_trackwin_create")
         self.lengths = []           # observations per track, as appended (the host's check against its own track list)
-        self.marks = []             # per track: (frame id and centre of its first observation, ... of its last) -- see in_step()
+        self.marks = np.zeros((0, 3))      # per track: frame id of its first observation, frame id and world x of its last -- see in_step()
 
     def _stream(self):
         return ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
@@ -47,22 +47,25 @@ class TrackWindows:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().odam_trackwin_reset(self._h, self._stream()), "odam_trackwin_reset")
         self.lengths = []
-        self.marks = []
+        self.marks = np.zeros((0, 3))
 
     @staticmethod
-    def _mark(row):
-        return (float(row[0]), float(row[9]), float(row[10]), float(row[11]))
+    def _marks_of(tracks):
+        """[T, 3] float64: frame id of the first observation, frame id and world x of the last one (one pass over the list)"""
+        n = len(tracks)
+        out = np.empty((n, 3))
+        out[:, 0] = np.fromiter((t[0, 0] for t in tracks), np.float64, n)
+        out[:, 1] = np.fromiter((t[-1, 0] for t in tracks), np.float64, n)
+        out[:, 2] = np.fromiter((t[-1, 9] for t in tracks), np.float64, n)
+        return out
 
     def in_step(self, tracks):
         """True when the mirror holds exactly `tracks` as far as the host can tell without reading rows back: the same number of
-        observations per track AND the same first / last observation (frame id, world centre) -- a track list that was
+        observations per track AND the same first / last observation (frame ids, world x of the last one) -- a track list that was
         replaced or edited at equal lengths (a restore, a test) is caught as well."""
-        if len(tracks) != len(self.lengths):
+        if [len(t) for t in tracks] != self.lengths:
             return False
-        for t, n, m in zip(tracks, self.lengths, self.marks):
-            if len(t) != n or (n and (self._mark(t[0]), self._mark(t[-1])) != m):
-                return False
-        return True
+        return len(tracks) == 0 or np.array_equal(self._marks_of(tracks), self.marks[:len(tracks)])
 
     def load(self, tracks):
         """(re)build the mirror from a host track list in one upload (include/odam_assoc.h, odam_trackwin_load)"""
@@ -76,7 +79,9 @@ class TrackWindows:
             _lib.check(_lib.lib().odam_trackwin_load(self._h, ctypes.c_int(T), lens.ctypes.data_as(ctypes.c_void_p),
                                                      rows.ctypes.data_as(ctypes.c_void_p), self._stream()), "odam_trackwin_load")
         self.lengths = lens.tolist()
-        self.marks = [(self._mark(t[0]), self._mark(t[-1])) if len(t) else None for t in tracks]
+        if any(n == 0 for n in self.lengths):
+            raise _lib.OdamError("TrackWindows: a track without observations")
+        self.marks = self._marks_of(tracks)
 
     def append(self, track_ids, rows82):
         """rows82 [n, 82] float64 track rows (processor.py:98-108); track_ids [n]: existing index or len(lengths) + j for new ones"""
@@ -87,14 +92,17 @@ class TrackWindows:
             with torch.cuda.device(self.device):
                 _lib.check(_lib.lib().odam_trackwin_append(self._h, ctypes.c_int(n), ids[i0:].ctypes.data_as(ctypes.c_void_p),
                                                            rows[i0:].ctypes.data_as(ctypes.c_void_p), self._stream()), "odam_trackwin_append")
-        for t, row in zip(ids.tolist(), np.asarray(rows82, np.float64)):
-            m = self._mark(row)
+        r = np.asarray(rows82, np.float64)
+        n_new = int((ids >= len(self.lengths)).sum())
+        if n_new:
+            self.marks = np.concatenate([self.marks, np.zeros((n_new, 3))])
+        for t, row in zip(ids.tolist(), r):
             if t == len(self.lengths):
                 self.lengths.append(1)
-                self.marks.append((m, m))
+                self.marks[t, 0] = row[0]
             else:
                 self.lengths[t] += 1
-                self.marks[t] = (self.marks[t][0] if self.marks[t] else m, m)
+            self.marks[t, 1] = row[0]; self.marks[t, 2] = row[9]
 
     def build(self, proj_px_dev, T_cw, cam_azi, img_w, img_h):
         T = len(self.lengths)
@@ -248,7 +256,9 @@ class Associator:
         if len(valid) != 1:
             raise _lib.OdamError("batch size 1 only (what OdamProcess.process_frame passes)")
         n_tracks, n_det = valid[0]
-        Z = self.assignment_checked(in_data["tracks"], in_data["detections"][0], n_tracks, n_det)
+        # ONE download of the log assignment: both consumers -- the Hungarian step here and process_frame's score matrix
+        # (processor.py:337-339: predictions['pred'][0][0].cpu().exp()) -- read it on the host
+        Z = self.assignment_checked(in_data["tracks"], in_data["detections"][0], n_tracks, n_det).cpu()
         pred = [Z[None]]
         match = [hungarian_matching(Z[:-1, :-1].exp(), threshold)]
         return {"pred": pred, "loss": 0, "matches": match}

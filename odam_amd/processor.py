@@ -201,6 +201,7 @@ class OdamProcess:
             return None
         if not w.in_step(self.tracks):                        # first use, or somebody edited self.tracks: rebuild the mirror
             w.load(self.tracks)
+        self._win_checked = len(self.usable_frames)           # _attach_to_tracks of this frame need not check again
         return w
 
     def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100, proj_px=None):
@@ -320,7 +321,8 @@ class OdamProcess:
         matches scoring below `score_threshold` are dropped (index -1 reads the dustbin row, as in the reference)."""
         rows = self._track_rows(detections, T_wc, with_code=not self.no_code)
         win = getattr(self, "_win", None)
-        in_step = win is not None and win.in_step(self.tracks)      # the device mirror matches the tracks as they stand
+        # the device mirror matches the tracks as they stand: checked by _windows() in this very frame, or checked now
+        in_step = win is not None and (getattr(self, "_win_checked", -1) == len(self.usable_frames) or win.in_step(self.tracks))
         ids, picked = [], []
         for det_id, track_id in enumerate(pred_match):
             if score_mat[track_id, det_id] < self.score_threshold:
