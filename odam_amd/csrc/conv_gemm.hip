@@ -9,9 +9,10 @@ namespace odam_cg {
 // NST: LDS stages.  2 = one tile in flight under the tile being multiplied (two workgroups per CU hide the rest).
 // 4 (UT only; small, latency-bound problems that leave most CUs with one workgroup): three tiles in flight, retired
 // with a counted s_waitcnt so the DMA queue stays full across the per-tile barrier.
-template <int BM, int BN, int WM, int WN, bool BF16, bool UT, int NST = 2>
+template <int BM, int BN, int WM, int WN, bool BF16, bool UT, int NST = 2, bool X3 = false>
 __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a) {
     static_assert(NST == 2 || (UT && (NST & (NST - 1)) == 0), "deep pipelines are LDS-DMA only");
+    static_assert(!X3 || (UT && !BF16), "split products: fp32 operands on the LDS-DMA path");
     using T = typename std::conditional<BF16, unsigned short, float>::type;
     constexpr int EPC = BF16 ? 8 : 4;   // elements per 16-byte chunk
     constexpr int BKE = 8 * EPC;        // elements per k-tile (32 fp32 / 64 bf16)
@@ -215,6 +216,54 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     auto mma_tile = [&](int cur, auto&& issue_next) {
         const float* Ab = &As[(cur * BM + wm * (BM / WM) + frag_row) * LDS_LD + frag_k];
         const float* Bb = &Bs[(cur * BN + wn * (BN / WN) + frag_row) * LDS_LD + frag_k];
+        if constexpr (X3) {
+            // the exact three-way bf16 split of both operands (cg_common.hpp cg_split8), six products per 16 k on v_mfma_f32_32x32x16_bf16:
+            // lane (row, half) takes its 8 consecutive k of step s from chunks 4 s + 2 half, + 1 of the row
+            const int sw = (frag_row >> 1) & 7, hf = lane >> 5;
+            float4 a0[TM], a1[TM], b0[TN], b1[TN];
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+                a0[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + (((2 * hf) ^ sw) << 2));
+                a1[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + (((2 * hf + 1) ^ sw) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; j++) {
+                b0[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + (((2 * hf) ^ sw) << 2));
+                b1[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + (((2 * hf + 1) ^ sw) << 2));
+            }
+            issue_next();
+#pragma unroll
+            for (int st = 0; st < 2; st++) {
+                uint4 ah[TM], am[TM], al[TM], bh[TN], bm[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; i++) cg_split8(a0[i], a1[i], ah[i], am[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < TN; j++) cg_split8(b0[j], b1[j], bh[j], bm[j], bl[j]);
+                if (st == 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; i++) {
+                        a0[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + (((4 + 2 * hf) ^ sw) << 2));
+                        a1[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + (((4 + 2 * hf + 1) ^ sw) << 2));
+                    }
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {
+                        b0[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + (((4 + 2 * hf) ^ sw) << 2));
+                        b1[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_LD + (((4 + 2 * hf + 1) ^ sw) << 2));
+                    }
+                }
+#define ODAM_MMS(x, y) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), acc[i][j], 0, 0, 0)
+#pragma unroll
+                for (int i = 0; i < TM; i++)
+#pragma unroll
+                    for (int j = 0; j < TN; j++) {      // smallest products first
+                        ODAM_MMS(al[i], bh[j]); ODAM_MMS(am[i], bm[j]); ODAM_MMS(ah[i], bl[j]);
+                        ODAM_MMS(am[i], bh[j]); ODAM_MMS(ah[i], bm[j]);
+                        ODAM_MMS(ah[i], bh[j]);
+                    }
+#undef ODAM_MMS
+            }
+            return;
+        }
         float4 af[2][TM], bf[2][TN];
 #pragma unroll
         for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_LD + frag_q[0]);
@@ -346,7 +395,12 @@ static int launch_cfg(const ConvGemmArgs& a, hipStream_t stream) {
         if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, true, NST_UT>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, false>), g, b, 0, stream, a);
     } else {
-        if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, true, NST_UT>), g, b, 0, stream, a);
+        // fp32 split mode reaches the layers too small for the ring kernel as well (cg.small_x3): the same six exact products on
+        // v_mfma_f32_32x32x16_bf16, both operands split in registers.  Forward of 2 / 8 / 16 frames 4.89 -> 4.59 / 10.24 -> 9.66 /
+        // 17.36 -> 16.84 ms (same box, A/B by config); a batch of 32 has few such layers left (30.45 -> 30.32)
+        if (ut && g_big_f32 == 2 && odam_cfg::get(odam_cfg::CG_SMALL_X3) != 0)
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, true, NST_UT, true>), g, b, 0, stream, a);
+        else if (ut) hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, true, NST_UT>), g, b, 0, stream, a);
         else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, false, false>), g, b, 0, stream, a);
     }
     ODAM_HIP(hipGetLastError());

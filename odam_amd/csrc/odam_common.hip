@@ -18,6 +18,7 @@ const Entry TABLE[N_KEYS] = {
     {"assoc.persist", 1, 0, 1},  {"sq.split", 16, 1, 16},     {"sq.split_wait", 3000, 0, 100000000}, {"sq.lanes", 0, 0, 64},
     {"stem.pool", 1, 0, 1},
     {"cg.pin", 0, 0, 1},
+    {"cg.small_x3", 1, 0, 1},
 };
 std::atomic<int> g_val[N_KEYS];
 std::atomic<bool> g_init{false};

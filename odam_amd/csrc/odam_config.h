@@ -29,6 +29,8 @@ enum Key {
     CG_PIN,         // 1: the kernel (tile shape, matrix instruction, fusion) chosen for a layer does not depend on how many rows it has --
                     // every size-dependent choice is taken as for a problem that fills the device, so a frame's result is bit-identical
                     // whatever batch or shard it arrives in (odam_amd/pipeline.py; slower for small batches).  Default 0
+    CG_SMALL_X3,    // fp32 split mode (cg.f32 = 2) on the small tiles too -- the layers the ring kernel does not take (few rows, decoder, heads):
+                    // both operands split in registers, six products on the bf16 matrix instruction.  Default 1; 0 = v_mfma_f32_32x32x2_f32 there
     N_KEYS
 };
 int get(Key k);

@@ -657,12 +657,12 @@ def test_bf16_r101_full_size_vs_bf16_faithful_oracle(measured):
 
 
 @pytest.mark.parametrize("cfg", ["cg.ut=0", "cg.tiles=0", "cg.tiles=7", "cg.tiles=15", "cg.force=2", "cg.ring=2", "cg.ring=0", "cg.ring=2,cg.presplit=0", "cg.f32=0",
-                                 "att.x3=0,cg.fuse=1", "stem.rows=0,cg.fuse=0", "stem.pool=0", "cg.s1=0", "cg.fuse_bf16=0", "cg.fuse_bf16=1,att.bf16_mfma=0", "cg.mfma16=0"])
+                                 "att.x3=0,cg.fuse=1", "stem.rows=0,cg.fuse=0", "stem.pool=0", "cg.s1=0", "cg.fuse_bf16=0", "cg.fuse_bf16=1,att.bf16_mfma=0", "cg.mfma16=0", "cg.small_x3=0"])
 def test_conv_gemm_alternative_paths(cfg):
     """Every surviving switch of the library's config table (include/odam_config.h): the register-staged gather (what layers too
     large for 31-bit buffer offsets fall back to), the 4-wave tiles, the four-stage small-tile pipeline, the ring kernel
     forced onto / kept off every eligible shape, fp32 split without pre-split filters, the fp32 matrix instruction everywhere,
-    attention on the fp32 instruction, bottlenecks as separate launches (fp32 and bf16), conv1 on the small tiles, the bf16 3x3
+    attention on the fp32 instruction, the small tiles on the fp32 instruction, bottlenecks as separate launches (fp32 and bf16), conv1 on the small tiles, the bf16 3x3
     through the generic tap gather: same parity.  The nested run's host side (odam_amd/_lib.py) pushes ODAM_CONFIG through
     odam_config_set when it loads the library."""
     import os
@@ -671,7 +671,7 @@ def test_conv_gemm_alternative_paths(cfg):
     if os.environ.get("ODAM_NESTED"):
         pytest.skip("already inside the nested run")
     sel = "conv_gemm_vs_torch or conv_gemm_bf16"
-    if cfg in ("cg.f32=0", "cg.mfma16=0"):      # the reference-run goldens and the oracle comparisons must hold on the fp32 instruction as well
+    if cfg in ("cg.f32=0", "cg.mfma16=0", "cg.small_x3=0"):      # the reference-run goldens and the oracle comparisons must hold on the fp32 instruction as well
         sel += " or reference_golden or vs_oracle or mixed_size"
     if "stem." in cfg or "cg.fuse=" in cfg:
         sel = "reference_golden or vs_oracle"
