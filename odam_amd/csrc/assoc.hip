@@ -472,10 +472,163 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn32_kernel(const float* __restri
     if (tid == 0 && err && *err && lost_count) __hip_atomic_fetch_add(lost_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- Sinkhorn on ONE wavefront: <= 128 rows, <= 32 columns -----------------------------------------------------------------------
+// The iteration of log_sinkhorn_iterations (associator.py:283-312) on scaling factors instead of potentials.  With
+// K_rc = exp(Z_rc + u_r + v_c) (the coupling at the potentials reached so far), a_r, b_c the factors since then, an iteration is
+//     a_r = mu_r / sum_c K_rc b_c        b_c = nu_c / sum_r K_rc a_r
+// -- multiply-adds and two reciprocals; no exp / log / max, no LDS and no barrier.  Every J iterations the factors are ABSORBED:
+// u += log a, v += log b, K recomputed from Z, u, v, a = b = 1.  In exact arithmetic this is the log-space iteration; in float32
+// it stays so as long as the factors of J iterations stay far inside the float range (they are checked at every absorption:
+// 1e-18 .. 1e18) -- an entry of K that underflows is one whose mass is below e^-87 of a unit AT the current potentials, which the
+// log-space sum drops in the same way; and it is recomputed at the next absorption.  The potentials start at u = -(row maximum),
+// v = 0, so that no entry of K overflows whatever the size of the scores (the hand-built scene weights reach +-1000).  A failed
+// check restarts the whole loop with J = 1 (absorb after every iteration), then in log space -- same launch, wave-uniform decision.
+// Layout: lane = row (RB rows per lane), its K row in NC registers.  The column sums are one TRANSPOSING reduction (sk_wave.h): a
+// level combines two registers into one -- the lanes whose level bit is clear keep the first column and receive the partner
+// lane's share of it, the others the second -- so 32 columns cost 16 + 8 + 4 + 2 + 1 exchanges, not 32 x 6, and end with column
+// c's total in lane sk_lane(c): b is ONE register (lane = column), one reciprocal per iteration; the row sums read it back
+// through v_readlane.
+#include "sk_wave.h"
+
+template <int RB, int NC>
+__global__ __launch_bounds__(64) void sinkhorn_wave_kernel(const float* __restrict__ scores, int lds, int m, int n, float alpha, int iters,
+                                                           float* __restrict__ out, const int* __restrict__ n_dev,
+                                                           const unsigned* __restrict__ err, unsigned* lost_count, int first_mode) {
+    constexpr int P = NC <= 8 ? 8 : NC <= 16 ? 16 : 32;
+    if (n_dev) n = *n_dev;
+    const int lane = threadIdx.x, M1 = m + 1, N1 = n + 1;
+    const float inv = 1.0f / ((float)m + (float)n);          // exp(norm)
+    const float norm = -logf((float)m + (float)n);
+    float z[RB][NC], rho[RB], mu[RB], u[RB], vc[NC];
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        const int r = lane + 64 * j;
+        const bool valid = r < M1;
+        rho[j] = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            z[j][c] = (valid && c < N1) ? ((r < m && c < n) ? scores[(size_t)r * lds + c] : alpha) : -INFINITY;
+            rho[j] = fmaxf(rho[j], z[j][c]);
+        }
+        mu[j] = valid ? (r < m ? inv : (float)n * inv) : 0.0f;
+    }
+    const int cl = sk_lane(lane & 31) & (P - 1);             // the column whose total this lane receives
+    const float nu = cl < n ? inv : (cl == n ? (float)m * inv : 0.0f);
+    auto bcast = [&](float x, float (&o)[NC]) {             // lane = column -> every lane holds all columns
+#pragma unroll
+        for (int c = 0; c < NC; c++) o[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), sk_lane(c)));
+    };
+    bool done = false;
+    for (int mode = first_mode; mode < 2 && !done; mode++) {
+        const int J = mode == 0 ? 10 : 1;
+        float K[RB][NC], a[RB], vl = 0.0f, b = nu != 0.0f ? 1.0f : 0.0f;
+        bool good = true;
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+            u[j] = mu[j] != 0.0f ? -rho[j] : 0.0f;
+            a[j] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NC; c++) K[j][c] = expf(z[j][c] + u[j]);          // exp(-inf) = 0 outside the matrix
+        }
+        for (int it0 = 0; it0 < iters; it0 += J) {
+            const int ne = iters - it0 < J ? iters - it0 : J;
+            for (int e = 0; e < ne; e++) {
+                float bc[NC];
+                bcast(b, bc);
+#pragma unroll
+                for (int j = 0; j < RB; j++) {
+                    float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+                    for (int c = 0; c < NC; c += 2) { s0 = fmaf(K[j][c], bc[c], s0); s1 = fmaf(K[j][c + 1], bc[c + 1], s1); }
+                    a[j] = mu[j] != 0.0f ? mu[j] * __builtin_amdgcn_rcpf(s0 + s1) : 0.0f;
+                }
+                float t[32];
+#pragma unroll
+                for (int c = 0; c < 32; c++) {
+                    if (c < NC) {
+                        t[c] = K[0][c] * a[0];
+#pragma unroll
+                        for (int j = 1; j < RB; j++) t[c] = fmaf(K[j][c], a[j], t[c]);
+                    } else t[c] = 0.0f;
+                }
+                const float tot = sk_colsum<P>(t, lane);
+                b = nu != 0.0f ? nu * __builtin_amdgcn_rcpf(tot) : 0.0f;
+            }
+            // absorb the factors into the potentials
+            good = good && (nu == 0.0f || (b > 1e-18f && b < 1e18f));
+            vl += nu != 0.0f ? logf(b) : 0.0f;
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+                good = good && (mu[j] == 0.0f || (a[j] > 1e-18f && a[j] < 1e18f));
+                u[j] += mu[j] != 0.0f ? logf(a[j]) : 0.0f;
+            }
+            if (it0 + J < iters) {
+                bcast(vl, vc);
+#pragma unroll
+                for (int j = 0; j < RB; j++)
+#pragma unroll
+                    for (int c = 0; c < NC; c++) K[j][c] = expf(z[j][c] + u[j] + vc[c]);
+                b = nu != 0.0f ? 1.0f : 0.0f;
+            }
+        }
+        bcast(vl, vc);
+        done = __all(good);
+    }
+    if (!done) {
+        // log space with the same layout: a row's logsumexp is per lane, a column's a 64-lane reduction
+        const float log_mu_last = logf((float)n) + norm, log_nu_last = logf((float)m) + norm;
+#pragma unroll
+        for (int c = 0; c < NC; c++) vc[c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < RB; j++) u[j] = 0.0f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < RB; j++) {
+                const int r = lane + 64 * j;
+                float mx = -INFINITY, sum = 0.0f;
+#pragma unroll
+                for (int c = 0; c < NC; c++) mx = fmaxf(mx, z[j][c] + vc[c]);
+#pragma unroll
+                for (int c = 0; c < NC; c++) sum += expf(z[j][c] + vc[c] - mx);          // exp(-inf) = 0 outside the matrix
+                u[j] = r < M1 ? ((r < m) ? norm : log_mu_last) - (logf(sum) + mx) : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                float mx = -INFINITY;
+#pragma unroll
+                for (int j = 0; j < RB; j++) mx = fmaxf(mx, z[j][c] + u[j]);
+                mx = sk_wave_max(mx);
+                float sum = 0.0f;
+#pragma unroll
+                for (int j = 0; j < RB; j++) sum += expf(z[j][c] + u[j] - mx);
+                sum = sk_wave_sum(sum);
+                vc[c] = c < N1 ? ((c < n) ? norm : log_nu_last) - (logf(sum) + mx) : 0.0f;
+            }
+        }
+    }
+    const bool lost = err && *err;
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        const int r = lane + 64 * j;
+        if (r < M1) {
+#pragma unroll
+            for (int c = 0; c < NC; c++)
+                if (c < N1) out[(size_t)r * N1 + c] = lost ? NAN : z[j][c] + u[j] + vc[c] - norm;
+        }
+    }
+    if (lane == 0 && lost && lost_count) __hip_atomic_fetch_add(lost_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // log_optimal_transport on the device: the 31-column kernel where it applies, the general one otherwise
 static int launch_sinkhorn(const float* scores, int lds_, int m_, int n_, int n_cap, float alpha, int iters, float* Z_out,
                            const int* n_dev, hipStream_t st, const unsigned* err = nullptr, unsigned* lost_count = nullptr) {
-    if (n_cap + 1 <= 32 && m_ + 1 <= 1100) {        // 1100 rows of 33 floats + u + v fit the 150 KB of dynamic LDS
+    if (n_cap + 1 <= 32 && m_ + 1 <= 128 && odam_cfg::get(odam_cfg::ASSOC_SK_FAST) != 0) {       // one wavefront, registers only
+        const int nc = (n_cap + 1 + 7) >> 3;
+#define ODAM_SKW(RB, NC) hipLaunchKernelGGL((sinkhorn_wave_kernel<RB, NC>), dim3(1), dim3(64), 0, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err, lost_count, odam_cfg::get(odam_cfg::ASSOC_SK_FAST) - 1)
+        if (m_ + 1 <= 64) { if (nc == 1) ODAM_SKW(1, 8); else if (nc == 2) ODAM_SKW(1, 16); else if (nc == 3) ODAM_SKW(1, 24); else ODAM_SKW(1, 32); }
+        else { if (nc == 1) ODAM_SKW(2, 8); else if (nc == 2) ODAM_SKW(2, 16); else if (nc == 3) ODAM_SKW(2, 24); else ODAM_SKW(2, 32); }
+#undef ODAM_SKW
+    } else if (n_cap + 1 <= 32 && m_ + 1 <= 1100) {        // 1100 rows of 33 floats + u + v fit the 150 KB of dynamic LDS
         const size_t lds = ((size_t)(m_ + 1) * 33 + (m_ + 1) + 32) * sizeof(float);
         hipLaunchKernelGGL(sinkhorn32_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err, lost_count);
     } else {

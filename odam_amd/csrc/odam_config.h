@@ -31,6 +31,9 @@ enum Key {
                     // whatever batch or shard it arrives in (odam_amd/pipeline.py; slower for small batches).  Default 0
     CG_SMALL_X3,    // fp32 split mode (cg.f32 = 2) on the small tiles too -- the layers the ring kernel does not take (few rows, decoder, heads):
                     // both operands split in registers, six products on the bf16 matrix instruction.  Default 1; 0 = v_mfma_f32_32x32x2_f32 there
+    ASSOC_SK_FAST,  // Sinkhorn on one wavefront (<= 128 rows, <= 32 columns; assoc.hip sinkhorn_wave_kernel): 1 (default) scaling factors absorbed
+                    // into the potentials every 10 iterations, restarting with 1 and then in log space if a factor leaves its range;
+                    // 2 / 3 = start at that rung (tests); 0 = the sixteen-wave log-space kernel
     N_KEYS
 };
 int get(Key k);

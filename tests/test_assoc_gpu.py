@@ -22,6 +22,53 @@ def test_sinkhorn_kernel_vs_reference(golden):
     assert np.abs(out.cpu().numpy() - z["ot_Z"]).max() <= 2e-4     # 100 log-space iterations in fp32
 
 
+def _sinkhorn_f64(sc, alpha, iters):
+    """log_optimal_transport (associator.py:283-312) in float64"""
+    m, n = sc.shape
+    Z = np.full((m + 1, n + 1), alpha, np.float64); Z[:m, :n] = sc
+    norm = -np.log(m + n)
+    log_mu = np.full(m + 1, norm); log_mu[-1] = np.log(n) + norm
+    log_nu = np.full(n + 1, norm); log_nu[-1] = np.log(m) + norm
+    u, v = np.zeros(m + 1), np.zeros(n + 1)
+    lse = lambda x, ax: np.log(np.exp(x - x.max(ax, keepdims=True)).sum(ax)) + x.max(ax)
+    for _ in range(iters):
+        u = log_mu - lse(Z + v[None, :], 1)
+        v = log_nu - lse(Z + u[:, None], 0)
+    return Z + u[:, None] + v[None, :] - norm
+
+
+@pytest.mark.parametrize("m,n,scale", [(1, 1, 3.0), (5, 7, 3.0), (42, 21, 8.0), (63, 30, 8.0), (64, 31, 4.0), (100, 12, 8.0), (127, 30, 20.0),
+                                       (128, 5, 3.0), (300, 30, 8.0), (42, 21, 150.0), (90, 30, 400.0),
+                                       (5, 4, 1.0), (5, 3, 2.0), (40, 20, 0.5), (20, 30, 300.0)])
+def test_sinkhorn_rows_on_lanes_vs_float64(m, n, scale):
+    """The one-wavefront Sinkhorn kernel (odam_config assoc.sk_fast; <= 128 rows incl. the dustbin) on every rung of its ladder -- scaling
+    factors absorbed every 10 iterations, after every iteration, log space -- and the sixteen-wave log-space kernel (more rows, or
+    assoc.sk_fast = 0) against the float64 iteration: scores of every size, incl. the +-1000 the hand-built scene weights reach and a
+    constant offset of 100 against the dustbin score (process_tracks_net.npz is such a case)."""
+    from odam_amd import _lib
+    rng = np.random.default_rng(m * 1000 + n)
+    sc = (rng.standard_normal((m, n)) * scale).astype(np.float32)
+    if (m + n) % 3 == 0:
+        sc += 100.0
+    ref = _sinkhorn_f64(sc.astype(np.float64), 1.0, 100)
+    d = torch.from_numpy(sc).to(DEV)
+    outs = []
+    for fast in (1, 2, 3, 0):
+        _lib.set_config("assoc.sk_fast", fast)
+        try:
+            out = torch.empty(m + 1, n + 1, device=DEV)
+            _lib.check(_lib.lib().odam_assoc_sinkhorn(_lib.ptr(d), n, m, n, ctypes.c_float(1.0), 100, _lib.ptr(out),
+                                                      ctypes.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)), "sinkhorn")
+            outs.append(out.cpu().numpy().astype(np.float64))
+        finally:
+            _lib.set_config("assoc.sk_fast", 1)
+    tol = 2e-5 * max(1.0, float(np.abs(ref).max()))       # float32 sums of <= 129 terms, absolute in log space
+    for o in outs:
+        assert np.isfinite(o).all()
+        assert np.abs(o - ref).max() <= tol, (np.abs(o - ref).max(), tol)
+        assert (np.abs(np.exp(o) - np.exp(ref)) / np.maximum(np.exp(ref), 1.0)).max() <= 2 * tol      # entries are probabilities x (m + n)
+
+
 def test_forward_vs_reference_associator(golden):
     from odam_amd import associator, weights
     z = golden("assoc.npz")
