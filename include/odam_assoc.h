@@ -78,6 +78,21 @@ int odam_trackwin_append(odam_trackwin* w, int n, const int* track_ids, const do
 int odam_trackwin_load(odam_trackwin* w, int T, const int* lengths, const double* rows14, void* stream);
 int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_px, const double* cam15, float* out, void* stream);
 
+/* The host side of OdamProcess._prepare_tracks (src/processor.py:172-180) inside the store: every _append also extends running sums of
+ * the track's centre, dimensions (row after row -- numpy's axis-0 reduce) and keeps its azimuths (reduced pairwise, as numpy reduces
+ * a 1-D array), so the parameter rows a frame needs -- mean centre, mean azimuth, sqrt(max(mean dims, 0.05) / 2), exponents -0 -- come
+ * without touching the host track list.
+ *   _load_sums:    after _load: cols7 [host][sum_t lengths[t]][7] = columns 6..12 of EVERY observation, track after track.
+ *   _params:       out [host][T][9] float32, bit for bit what the numpy code of the reference computes; code 4 if the sums do not
+ *                  cover exactly T tracks (appends skipped an id, or a _load without _load_sums).
+ *   _build_tracks: _params -> upload -> odam_sq_project_extents on `sq` (include/odam_sq.h) -> _build: the whole device chain of a
+ *                  frame's track input in one call; T_cw12_K9 [host][21] as odam_sq_project_extents takes it. */
+struct odam_sq_ctx;
+int odam_trackwin_load_sums(odam_trackwin* w, int T, const int* lengths, const double* cols7);
+int odam_trackwin_params(odam_trackwin* w, int T, float* out);
+int odam_trackwin_build_tracks(odam_trackwin* w, struct odam_sq_ctx* sq, int T, const double* T_cw12_K9, double cam_azi, double img_w,
+                               double img_h, float* out, void* stream);
+
 /* diagnostics of the persistent matching kernel: enable != 0 makes the following forwards record a 100 MHz timestamp of
  * workgroup 0 at kernel start and after every stage (5 per GNN layer, final projection, score matrix, Sinkhorn loop);
  * out [host][n <= 128], if not null, receives the stamps of the last forward (synchronises the device). */

@@ -82,6 +82,10 @@ class TrackWindows:
         if any(n == 0 for n in self.lengths):
             raise _lib.OdamError("TrackWindows: a track without observations")
         self.marks = self._marks_of(tracks)
+        # ... and the store's running sums (odam_trackwin_load_sums): dims, centre and azimuth of EVERY observation
+        cols = np.ascontiguousarray(np.concatenate([np.asarray(t, np.float64)[:, 6:13] for t in tracks], axis=0)) if T else np.zeros((0, 7))
+        _lib.check(_lib.lib().odam_trackwin_load_sums(self._h, ctypes.c_int(T), lens.ctypes.data_as(ctypes.c_void_p),
+                                                      cols.ctypes.data_as(ctypes.c_void_p)), "odam_trackwin_load_sums")
 
     def append(self, track_ids, rows82):
         """rows82 [n, 82] float64 track rows (processor.py:98-108); track_ids [n]: existing index or len(lengths) + j for new ones"""
@@ -111,6 +115,14 @@ class TrackWindows:
         with torch.cuda.device(self.device):
             _lib.check(_lib.lib().odam_trackwin_build(self._h, ctypes.c_int(T), _lib.ptr(proj_px_dev), cam.ctypes.data_as(ctypes.c_void_p),
                                                       _lib.ptr(out), self._stream()), "odam_trackwin_build")
+        return out
+
+    def params(self):
+        """[T, 9] float32 parameter rows of the track surfaces from the store's running sums (odam_trackwin_params) -- what
+        OdamProcess._prepare_tracks computes from the host track list (src/processor.py:172-180), bit for bit"""
+        T = len(self.lengths)
+        out = np.zeros((T, 9), np.float32)
+        _lib.check(_lib.lib().odam_trackwin_params(self._h, ctypes.c_int(T), out.ctypes.data_as(ctypes.c_void_p)), "odam_trackwin_params")
         return out
 
     def close(self):

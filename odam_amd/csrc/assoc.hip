@@ -997,6 +997,17 @@ struct odam_trackwin {
     unsigned slot = 0;
     hipEvent_t copied[8] = {};  // recorded behind the upload from pinned slot i: the host rewrites a slot only after its copy has run
     bool copied_armed[8] = {};
+    // host side of OdamProcess._prepare_tracks (src/processor.py:172-180): what the surface of a track is evaluated from -- the
+    // means of all its observations' centre, azimuth and dimensions -- kept as running sums, extended by every append
+    struct Sums { long n = 0; double st[3] = {0, 0, 0}, sd[3] = {0, 0, 0}; std::vector<double> az; };
+    std::vector<Sums> sums;
+    bool sums_ok = true;        // false once an append skipped ids or a load came without the full columns
+    float* h_params = nullptr;  // pinned [8][max_tracks][9]
+    float* d_params = nullptr;  // [max_tracks][9]
+    double* d_proj = nullptr;   // [max_tracks][4]
+    hipEvent_t params_copied[8] = {};
+    bool params_armed[8] = {};
+    unsigned params_slot = 0;
 };
 
 namespace {
@@ -1092,6 +1103,13 @@ extern "C" int odam_trackwin_create(int max_tracks, int window, odam_trackwin** 
 extern "C" int odam_trackwin_destroy(odam_trackwin* w) {
     if (!w) return 0;
     for (int i = 0; i < 8; i++) {
+        if (w->params_armed[i]) (void)hipEventSynchronize(w->params_copied[i]);
+        if (w->params_copied[i]) (void)hipEventDestroy(w->params_copied[i]);
+    }
+    if (w->h_params) (void)hipHostFree(w->h_params);
+    if (w->d_params) (void)hipFree(w->d_params);
+    if (w->d_proj) (void)hipFree(w->d_proj);
+    for (int i = 0; i < 8; i++) {
         if (w->copied_armed[i]) (void)hipEventSynchronize(w->copied[i]);      // no upload may still be reading the pinned ring
         (void)hipEventDestroy(w->copied[i]);
     }
@@ -1103,6 +1121,7 @@ extern "C" int odam_trackwin_destroy(odam_trackwin* w) {
 extern "C" int odam_trackwin_reset(odam_trackwin* w, void* stream) {
     if (!w) return odam_fail(1, "odam_trackwin_reset: null handle");
     ODAM_HIP(hipMemsetAsync(w->count, 0, sizeof(int) * (size_t)w->max_tracks, (hipStream_t)stream));
+    w->sums.clear(); w->sums_ok = true;
     return 0;
 }
 
@@ -1126,6 +1145,16 @@ extern "C" int odam_trackwin_append(odam_trackwin* w, int n, const int* track_id
     w->copied_armed[si] = true;
     hipLaunchKernelGGL(trackwin_append_kernel, dim3(n), dim3(64), 0, st, w->d_stage, n, w->rows, w->count, w->window);
     ODAM_HIP(hipGetLastError());
+    for (int i = 0; i < n; i++) {
+        const size_t t = (size_t)track_ids[i];
+        if (t > w->sums.size()) w->sums_ok = false;        // a gap in the ids: no sums for the skipped tracks
+        if (t >= w->sums.size()) w->sums.resize(t + 1);
+        odam_trackwin::Sums& q = w->sums[t];
+        const double* r = rows14 + (size_t)i * TW_COLS;
+        q.n++;
+        for (int c = 0; c < 3; c++) { q.sd[c] += r[6 + c]; q.st[c] += r[9 + c]; }      // row after row: numpy's axis-0 reduce of an [n, 3] block
+        q.az.push_back(r[12]);
+    }
     return 0;
 }
 
@@ -1136,6 +1165,7 @@ extern "C" int odam_trackwin_load(odam_trackwin* w, int T, const int* lengths, c
     if (!w || T < 0 || T > w->max_tracks || (T && (!lengths || !rows14))) return odam_fail(1, "odam_trackwin_load: bad argument");
     hipStream_t st = (hipStream_t)stream;
     ODAM_HIP(hipMemsetAsync(w->count, 0, sizeof(int) * (size_t)w->max_tracks, st));
+    w->sums.clear(); w->sums_ok = T == 0;
     if (T == 0) return 0;
     std::vector<int> meta(2 * (size_t)T);      // [t] = first row of track t in rows14, [T + t] = its length
     long total = 0;
@@ -1161,6 +1191,105 @@ extern "C" int odam_trackwin_load(odam_trackwin* w, int T, const int* lengths, c
     if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = odam_fail(2, "odam_trackwin_load: stream synchronisation failed");
     (void)hipFree(d_rows); (void)hipFree(d_meta);
     return rc;
+}
+
+// np.add.reduce of a 1-D float64 array (numpy/core/src/umath/loops_utils.h.src, pairwise sum, started from the identity):
+// fewer than 8 values one after the other; up to 128 in eight interleaved partial sums combined as a tree, the tail after; longer
+// arrays halved (the first half a multiple of 8) -- tests/test_assoc_gpu.py checks it against numpy bit for bit
+static double np_pairwise(const double* a, size_t n) {
+    if (n < 8) {
+        double r = 0.0;
+        for (size_t i = 0; i < n; i++) r += a[i];
+        return r;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        size_t i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise(a, n2) + np_pairwise(a + n2, n - n2);
+}
+
+// the sums of a host track list in one go (after odam_trackwin_load): cols7 [host][sum_t lengths[t]][7] = columns 6..12 (dims x3,
+// t_wo x3, az_wo) of EVERY observation of track 0, then of track 1, ...
+extern "C" int odam_trackwin_load_sums(odam_trackwin* w, int T, const int* lengths, const double* cols7) {
+    if (!w || T < 0 || T > w->max_tracks || (T && (!lengths || !cols7))) return odam_fail(1, "odam_trackwin_load_sums: bad argument");
+    w->sums.assign((size_t)T, odam_trackwin::Sums());
+    const double* r = cols7;
+    for (int t = 0; t < T; t++) {
+        odam_trackwin::Sums& q = w->sums[t];
+        if (lengths[t] < 1) return odam_fail(1, "odam_trackwin_load_sums: a track without observations");
+        q.n = lengths[t];
+        q.az.resize((size_t)lengths[t]);
+        for (int i = 0; i < lengths[t]; i++, r += 7) {
+            for (int c = 0; c < 3; c++) { q.sd[c] += r[c]; q.st[c] += r[3 + c]; }
+            q.az[i] = r[6];
+        }
+    }
+    w->sums_ok = true;
+    return 0;
+}
+
+// parameter rows the surfaces of the tracks are evaluated from, as sq.init_params / _prepare_tracks build them (processor.py:172-180):
+// mean centre, mean azimuth, sqrt(max(mean dims, 0.05) / 2), shape exponents -0;  out [host][T][9] float32
+extern "C" int odam_trackwin_params(odam_trackwin* w, int T, float* out) {
+    if (!w || T < 0 || (T && !out)) return odam_fail(1, "odam_trackwin_params: bad argument");
+    if (!w->sums_ok || (size_t)T != w->sums.size()) return odam_fail(4, "odam_trackwin_params: the running sums do not cover these tracks (load them: odam_trackwin_load_sums)");
+    for (int t = 0; t < T; t++) {
+        const odam_trackwin::Sums& q = w->sums[t];
+        const double n = (double)q.n;
+        float* o = out + (size_t)t * 9;
+        for (int c = 0; c < 3; c++) o[c] = (float)(q.st[c] / n);
+        o[3] = (float)((0.0 + np_pairwise(q.az.data(), q.az.size())) / n);
+        for (int c = 0; c < 3; c++) {
+            const double d = q.sd[c] / n;
+            o[4 + c] = (float)std::sqrt((d > 0.05 ? d : 0.05) / 2);       // np.maximum(., 0.05); NaN stays NaN in numpy -- not reachable, dims come from a sigmoid
+        }
+        o[7] = o[8] = -0.0f;
+    }
+    return 0;
+}
+
+// One call for OdamProcess._prepare_tracks: parameter rows (above) -> upload -> odam_sq_project_extents on `sq` -> the window tensor
+// out [dev][T][79][window] for the camera T_cw12_K9 = rows 0..2 of inv(T_wc) (12) + K (9), azimuth cam_azi, image size.  Stream-ordered.
+extern "C" int odam_sq_project_extents(struct odam_sq_ctx* ctx, int n, const float* params, const double* T_cw12_K9, double* out_px, void* stream);
+extern "C" int odam_trackwin_build_tracks(odam_trackwin* w, struct odam_sq_ctx* sq, int T, const double* T_cw12_K9, double cam_azi,
+                                          double img_w, double img_h, float* out, void* stream) {
+    if (!w || !sq || T < 0 || T > w->max_tracks || (T && (!T_cw12_K9 || !out))) return odam_fail(1, "odam_trackwin_build_tracks: bad argument");
+    if (T == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!w->h_params) {
+        if (hipHostMalloc((void**)&w->h_params, sizeof(float) * 8 * (size_t)w->max_tracks * 9, hipHostMallocDefault) != hipSuccess ||
+            hipMalloc((void**)&w->d_params, sizeof(float) * (size_t)w->max_tracks * 9) != hipSuccess ||
+            hipMalloc((void**)&w->d_proj, sizeof(double) * (size_t)w->max_tracks * 4) != hipSuccess) {
+            if (w->h_params) { (void)hipHostFree(w->h_params); w->h_params = nullptr; }
+            if (w->d_params) { (void)hipFree(w->d_params); w->d_params = nullptr; }
+            return odam_fail(2, "odam_trackwin_build_tracks: allocation failed");
+        }
+        for (int i = 0; i < 8; i++) ODAM_HIP(hipEventCreateWithFlags(&w->params_copied[i], hipEventDisableTiming));
+    }
+    const int si = (int)(w->params_slot++ & 7);
+    if (w->params_armed[si]) ODAM_HIP(hipEventSynchronize(w->params_copied[si]));
+    float* hp = w->h_params + (size_t)si * w->max_tracks * 9;
+    if (int rc = odam_trackwin_params(w, T, hp)) return rc;
+    ODAM_HIP(hipMemcpyAsync(w->d_params, hp, sizeof(float) * (size_t)T * 9, hipMemcpyHostToDevice, st));
+    ODAM_HIP(hipEventRecord(w->params_copied[si], st));
+    w->params_armed[si] = true;
+    if (int rc = odam_sq_project_extents(sq, T, w->d_params, T_cw12_K9, w->d_proj, stream)) return rc;
+    double cam15[15];
+    for (int i = 0; i < 12; i++) cam15[i] = T_cw12_K9[i];
+    cam15[12] = cam_azi; cam15[13] = img_w; cam15[14] = img_h;
+    ODAM_HIP(hipMemcpyAsync(w->d_cam, cam15, sizeof(cam15), hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
+    hipLaunchKernelGGL(trackwin_build_kernel, dim3(T), dim3(128), 0, st, w->rows, w->count, w->window, w->d_proj, w->d_cam, out);
+    ODAM_HIP(hipGetLastError());
+    return 0;
 }
 
 extern "C" int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_px, const double* cam15, float* out, void* stream) {

@@ -237,6 +237,14 @@ class OdamProcess:
     def _prepare_tracks(self, T_wc, n_times=100):
         cam_azi = get_cam_azi(T_wc)
         tracks = self.tracks                         # read-only here (the reference deep-copies and scribbles on the copy)
+        fitter = self._fitter()
+        win = self._windows() if len(tracks) and n_times == getattr(getattr(self, "_win", None), "WINDOW", 100) else None
+        if win is not None and hasattr(fitter, "build_track_windows"):
+            # the device mirror is in step with `tracks` (checked by _windows()): the per-track means below come from its running
+            # sums, and surface extents + window tensor follow in the same native call (odam_trackwin_build_tracks) -- nothing
+            # of this frame's track input is computed or touched on the host
+            m = self.sequence_meta
+            return fitter.build_track_windows(win, np.linalg.inv(T_wc), m.K, cam_azi, m.img_w, m.img_h)
         # one batched surface evaluation for all tracks (reference: one SuperQuadric + sampler call each);
         # parameters as sq.init_params builds them: mean centre, mean azimuth, sqrt(mean dims / 2), shapes -0
         params = np.zeros((len(tracks), 9))
@@ -270,8 +278,6 @@ class OdamProcess:
             params[i, 4:7] = np.maximum(s_d / n, 0.05)    # np.clip(., 0.05, inf)
         params[:, 4:7] = np.sqrt(params[:, 4:7] / 2)
         params = params.astype(np.float32)
-        fitter = self._fitter()
-        win = self._windows() if len(tracks) and n_times == getattr(getattr(self, "_win", None), "WINDOW", 100) else None
         if win is not None:
             # everything after the per-track means on the device: surface extents (odam_sq_project_extents), then the
             # [T, 79, n_times] window tensor in the current camera frame (odam_trackwin_build) -- nothing comes back to the host

@@ -237,6 +237,31 @@ def _project_extents(self, params, T_cw, K, on_device=False):
 SqFitter.project_extents = _project_extents
 
 
+def _build_track_windows(self, win, T_cw, K, cam_azi, img_w, img_h):
+    """The whole device chain of OdamProcess._prepare_tracks in one native call (include/odam_assoc.h, odam_trackwin_build_tracks):
+    parameter rows from the window store's running sums -> surface extents on this fitter -> [T, 79, window] float32 track input
+    for the camera T_cw.  `win`: associator.TrackWindows on this fitter's device, in step with the host tracks."""
+    dev = self.device
+    T = len(win.lengths)
+    out = torch.empty(T, 79, win.WINDOW, device=dev, dtype=torch.float32)
+    cam = np.ascontiguousarray(np.concatenate([np.asarray(T_cw, np.float64)[:3].reshape(-1), np.asarray(K, np.float64)[:3, :3].reshape(-1)]))
+    with torch.cuda.device(dev), self._lock:
+        cur = torch.cuda.current_stream(dev)
+        stream = cur.cuda_stream
+        if self._last is not None and self._last[0] != stream:
+            cur.wait_event(self._last[1])
+        _lib.check(_lib.lib().odam_trackwin_build_tracks(win._h, self._h, ctypes.c_int(T), cam.ctypes.data_as(ctypes.c_void_p),
+                                                         ctypes.c_double(cam_azi), ctypes.c_double(img_w), ctypes.c_double(img_h),
+                                                         _lib.ptr(out), ctypes.c_void_p(stream)), "odam_trackwin_build_tracks")
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._last = (stream, ev)
+    return out
+
+
+SqFitter.build_track_windows = _build_track_windows
+
+
 def host_sample(a, e):
     """odam_sq_sample: (a[3], e[2]) -> etas[1000], omegas[1000] float32 (host)."""
     a = np.ascontiguousarray(a, np.float32)

@@ -274,7 +274,7 @@ def test_track_windows_rebuild_and_queued_appends_equal_the_host_path():
     Q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
     T_wc = np.eye(4); T_wc[:3, :3] = Q; T_wc[:3, 3] = rs.normal(size=3)
     cam_azi = get_cam_azi(T_wc)
-    lengths = [1, 2, 99, 100, 101, 260, 37] + list(rs.randint(1, 230, 33))
+    lengths = [1, 2, 99, 100, 101, 260, 37, 7, 8, 9, 128, 129, 136, 257] + list(rs.randint(1, 230, 26))
     tracks = _random_tracks(rs, lengths)
     proj = rs.uniform(-200, 900, (len(tracks), 4))
 
@@ -285,10 +285,24 @@ def test_track_windows_rebuild_and_queued_appends_equal_the_host_path():
         out = win.build(torch.from_numpy(proj).to("cuda:0"), np.linalg.inv(T_wc), cam_azi, 640, 480)
         return out.cpu().numpy()
 
+    def host_params(tr):
+        """the means a track's surface is evaluated from, as the reference's _prepare_tracks takes them (src/processor.py:188-193:
+        np.mean of the azimuth, centre and dimension columns, np.clip, sqrt(dims / 2), shapes -0) -> float32 rows (sq.init_params)"""
+        p = np.zeros((len(tr), 9)); p[:, 7:] = -0.0
+        for i, t in enumerate(tr):
+            p[i, :3] = np.mean(t[:, 9:12], axis=0)
+            p[i, 3] = np.mean(t[:, 12], axis=0)
+            p[i, 4:7] = np.sqrt(np.clip(np.mean(t[:, 6:9], axis=0), a_min=0.05, a_max=np.inf) / 2)
+        return p.astype(np.float32)
+
+    def same_bits(a, b):
+        return a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
     win = TrackWindows("cuda:0")
     win.load(tracks)                                                    # (a)
     assert win.in_step(tracks)
     assert np.array_equal(device(win), host(tracks))
+    assert same_bits(win.params(), host_params(tracks))                 # running sums of the store == numpy's reductions, bit for bit
 
     # (b) observation j of every track that has one, one append call each (ids unique per call), all queued behind ~50 ms of
     # device work so that far more than eight uploads are pending when the host refills the ring
@@ -301,6 +315,7 @@ def test_track_windows_rebuild_and_queued_appends_equal_the_host_path():
         win.append(ids, np.stack([tracks[i][j] for i in ids]))
     assert win.in_step(tracks)
     assert np.array_equal(device(win), host(tracks))
+    assert same_bits(win.params(), host_params(tracks))                 # ... extended append by append (pairwise azimuth sums of 1..260 values)
     del busy
 
     # (c) same lengths, one track replaced: the marks differ, OdamProcess._windows() would rebuild
@@ -309,4 +324,15 @@ def test_track_windows_rebuild_and_queued_appends_equal_the_host_path():
     assert not win.in_step(edited)
     win.load(edited)
     assert np.array_equal(device(win), host(edited))
+    assert same_bits(win.params(), host_params(edited))
+    # (d) the whole chain in one native call (odam_trackwin_build_tracks: sums -> parameter rows -> surface extents -> window tensor)
+    # against the same steps taken one by one
+    from odam_amd import sq
+    fitter = sq.SqFitter("cuda:0", 1)
+    K = np.array([[577.87, 0, 319.5], [0, 577.87, 239.5], [0, 0, 1.0]])
+    T_cw = np.linalg.inv(T_wc)
+    one = fitter.build_track_windows(win, T_cw, K, cam_azi, 640, 480).cpu().numpy()
+    proj_dev = fitter.project_extents(host_params(edited), T_cw, K, on_device=True)
+    steps = win.build(proj_dev, T_cw, cam_azi, 640, 480).cpu().numpy()
+    assert np.array_equal(one, steps)
     win.close()
