@@ -617,17 +617,25 @@ __global__ __launch_bounds__(64) void sinkhorn_wave_kernel(const float* __restri
         }
     }
     if (lane == 0 && lost && lost_count) __hip_atomic_fetch_add(lost_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // err = the persistent matching kernel's flag word (bar + 1): that launch is over (stream order) and its flag has been read
+    // above -- leave generation, flag and the group counters at zero for the next launch (saves a memset per frame)
+    if (err && lane <= PG_GROUPS) {
+        unsigned* bar = const_cast<unsigned*>(err) - 1;
+        if (lane == 0) { bar[0] = 0u; bar[1] = 0u; }
+        else bar[32 * lane] = 0u;
+    }
 }
 
 // log_optimal_transport on the device: the 31-column kernel where it applies, the general one otherwise
 static int launch_sinkhorn(const float* scores, int lds_, int m_, int n_, int n_cap, float alpha, int iters, float* Z_out,
-                           const int* n_dev, hipStream_t st, const unsigned* err = nullptr, unsigned* lost_count = nullptr) {
+                           const int* n_dev, hipStream_t st, const unsigned* err = nullptr, unsigned* lost_count = nullptr, bool* cleans_bar = nullptr) {
     if (n_cap + 1 <= 32 && m_ + 1 <= 128 && odam_cfg::get(odam_cfg::ASSOC_SK_FAST) != 0) {       // one wavefront, registers only
         const int nc = (n_cap + 1 + 7) >> 3;
 #define ODAM_SKW(RB, NC) hipLaunchKernelGGL((sinkhorn_wave_kernel<RB, NC>), dim3(1), dim3(64), 0, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err, lost_count, odam_cfg::get(odam_cfg::ASSOC_SK_FAST) - 1)
         if (m_ + 1 <= 64) { if (nc == 1) ODAM_SKW(1, 8); else if (nc == 2) ODAM_SKW(1, 16); else if (nc == 3) ODAM_SKW(1, 24); else ODAM_SKW(1, 32); }
         else { if (nc == 1) ODAM_SKW(2, 8); else if (nc == 2) ODAM_SKW(2, 16); else if (nc == 3) ODAM_SKW(2, 24); else ODAM_SKW(2, 32); }
 #undef ODAM_SKW
+        if (cleans_bar) *cleans_bar = err != nullptr;
     } else if (n_cap + 1 <= 32 && m_ + 1 <= 1100) {        // 1100 rows of 33 floats + u + v fit the 150 KB of dynamic LDS
         const size_t lds = ((size_t)(m_ + 1) * 33 + (m_ + 1) + 32) * sizeof(float);
         hipLaunchKernelGGL(sinkhorn32_kernel, dim3(1), dim3(SK_NT), lds, st, scores, lds_, m_, n_, alpha, iters, Z_out, n_dev, err, lost_count);
@@ -677,6 +685,7 @@ struct odam_assoc {
     unsigned* lost_count = nullptr;          // pinned host word: launches abandoned at a barrier so far (the Sinkhorn kernel bumps it)
     unsigned long long* stamps = nullptr;    // device, 128 entries; written only while want_stamps
     bool want_stamps = false;
+    bool bar_clean = false;                  // the counters are zero: the one-wavefront Sinkhorn kernel zeroes them behind the launch that used them
 
     int alloc(float** p, size_t n) {
         ODAM_HIP(hipMalloc((void**)p, n * sizeof(float)));
@@ -870,16 +879,19 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
                            float* Z_out, hipStream_t st, bool allow_persist = true) {
     const int N = T * NT;
     // encoder + frame-index encoding (associator.py:222-229)
-    hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
     float* X = m->catTr;                      // [T + 30][512]: fused tracks, then the detection slots
     float* XD = X + (size_t)T * 512;
     const int MX = T + ND;
     hipLaunchKernelGGL(prepare_kernel, dim3(ND), dim3(256), 0, st, detections, ND, ND, m->div_term, m->featD, XD);
     ODAM_HIP(hipGetLastError());
-    RC(lin(m->enc0, m->feat, FPAD, N, nullptr, true, m->h256, D, nullptr, st));
-    RC(lin(m->enc2, m->h256, D, N, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
+    // (the detections' branch -- these three launches on 30 rows -- on a second stream beside the tracks' branch, forked and joined by
+    //  events: measured, no change of the loop's 0.79-0.81 ms per frame; not kept)
     RC(lin(m->enc0, m->featD, FPAD, ND, nullptr, true, m->h256, D, nullptr, st));
     RC(lin(m->enc2, m->h256, D, ND, XD, false, XD, 512, nullptr, st));
+    hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
+    ODAM_HIP(hipGetLastError());
+    RC(lin(m->enc0, m->feat, FPAD, N, nullptr, true, m->h256, D, nullptr, st));
+    RC(lin(m->enc2, m->h256, D, N, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
     // fuser: self-attention over each track's 100 time steps (associator.py:143-160, 230)
     for (const Prop& P : m->fuser)
         RC(prop_forward_self(P, m->catT, N, T, NT, m->kv, m->att, m->h512, st));
@@ -901,7 +913,9 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         g.T = T;
         g.bar = m->bar; g.timeout_ticks = m->timeout_ticks;
         g.stamps = m->want_stamps ? m->stamps : nullptr;
-        ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * 32 * (1 + PG_GROUPS), st));     // counters and the error flag start from zero every launch
+        // counters and the error flag start from zero every launch: zeroed here, unless the Sinkhorn kernel behind the previous launch did it
+        if (!m->bar_clean) ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * 32 * (1 + PG_GROUPS), st));
+        m->bar_clean = false;
         hipLaunchKernelGGL(gnn_persistent_kernel, dim3(PG_WG), dim3(PG_NT), 0, st, g);
         ODAM_HIP(hipGetLastError());
         // The score matrix keeps its own launch on the tiles of conv_gemm.hip: with saturated scores (the hand-built scene
@@ -911,7 +925,10 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         const float* mD = m->mT + (size_t)T * D;
         Lin sc; sc.w = const_cast<float*>(mD); sc.b = nullptr; sc.K = D; sc.N = ND;
         RC(lin(sc, m->mT, D, T, nullptr, false, m->scores, 32, m->sc16, st));
-        return launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, nullptr, st, m->bar + 1, m->lost_count);
+        bool cleaned = false;
+        const int rc = launch_sinkhorn(m->scores, 32, T, n_det, n_det, m->bin_score, m->iters, Z_out, nullptr, st, m->bar + 1, m->lost_count, &cleaned);
+        m->bar_clean = rc == 0 && cleaned;
+        return rc;
     }
     for (size_t i = 0; i < m->gnn.size(); i++) {
         const Prop& P = m->gnn[i];
@@ -993,7 +1010,7 @@ struct odam_trackwin {
     int* count = nullptr;       // [max_tracks] observations appended so far
     double* stage = nullptr;    // pinned [8][32][14 + 1]: rows + track id of one append
     double* d_stage = nullptr;  // device copy of one slot
-    double* d_cam = nullptr;    // [16]
+    double* d_cam = nullptr;    // [16] (unused since the camera travels in the kernel arguments; kept so the handle layout of create / destroy stays as tested)
     unsigned slot = 0;
     hipEvent_t copied[8] = {};  // recorded behind the upload from pinned slot i: the host rewrites a slot only after its copy has run
     bool copied_armed[8] = {};
@@ -1037,9 +1054,11 @@ __global__ __launch_bounds__(128) void trackwin_load_kernel(const double* __rest
 }
 
 // out [T][79][window] float32; cam: T_cw rows 0..2 (12), cam_azi, img_w, img_h
+struct Cam15 { double v[15]; };      // travels in the kernel arguments
 __global__ __launch_bounds__(128) void trackwin_build_kernel(const double* __restrict__ rows, const int* __restrict__ count, int window,
-                                                             const double* __restrict__ proj_px, const double* __restrict__ cam,
+                                                             const double* __restrict__ proj_px, const Cam15 camv,
                                                              float* __restrict__ out) {
+    const double* cam = camv.v;
     const int t = blockIdx.x, l = threadIdx.x;
     if (l >= window) return;
     const int c = count[t], k = c < window ? c : window;
@@ -1283,11 +1302,10 @@ extern "C" int odam_trackwin_build_tracks(odam_trackwin* w, struct odam_sq_ctx* 
     ODAM_HIP(hipEventRecord(w->params_copied[si], st));
     w->params_armed[si] = true;
     if (int rc = odam_sq_project_extents(sq, T, w->d_params, T_cw12_K9, w->d_proj, stream)) return rc;
-    double cam15[15];
-    for (int i = 0; i < 12; i++) cam15[i] = T_cw12_K9[i];
-    cam15[12] = cam_azi; cam15[13] = img_w; cam15[14] = img_h;
-    ODAM_HIP(hipMemcpyAsync(w->d_cam, cam15, sizeof(cam15), hipMemcpyHostToDevice, st));      // pageable source: staged before the call returns
-    hipLaunchKernelGGL(trackwin_build_kernel, dim3(T), dim3(128), 0, st, w->rows, w->count, w->window, w->d_proj, w->d_cam, out);
+    Cam15 cam;
+    for (int i = 0; i < 12; i++) cam.v[i] = T_cw12_K9[i];
+    cam.v[12] = cam_azi; cam.v[13] = img_w; cam.v[14] = img_h;
+    hipLaunchKernelGGL(trackwin_build_kernel, dim3(T), dim3(128), 0, st, w->rows, w->count, w->window, w->d_proj, cam, out);
     ODAM_HIP(hipGetLastError());
     return 0;
 }
@@ -1296,8 +1314,9 @@ extern "C" int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_p
     if (!w || T < 0 || T > w->max_tracks || (T && (!proj_px || !cam15 || !out))) return odam_fail(1, "odam_trackwin_build: bad argument");
     if (T == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
-    ODAM_HIP(hipMemcpyAsync(w->d_cam, cam15, sizeof(double) * 15, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(trackwin_build_kernel, dim3(T), dim3(128), 0, st, w->rows, w->count, w->window, proj_px, w->d_cam, out);
+    Cam15 cam;
+    for (int i = 0; i < 15; i++) cam.v[i] = cam15[i];
+    hipLaunchKernelGGL(trackwin_build_kernel, dim3(T), dim3(128), 0, st, w->rows, w->count, w->window, proj_px, cam, out);
     ODAM_HIP(hipGetLastError());
     return 0;
 }

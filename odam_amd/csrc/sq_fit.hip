@@ -693,7 +693,7 @@ struct odam_sq_ctx {
     // odam_sq_project_extents: surface points of the tracks of one frame (grow-only)
     float* d_proj_pts = nullptr;
     size_t proj_pts_n = 0;
-    double* d_cam = nullptr;      // [21]: T_cw rows 0..2 (12), K (9)
+    double* d_cam = nullptr;      // (unused: the camera travels in the kernel arguments)
 };
 
 static std::vector<float> sampler_draws() {
@@ -865,7 +865,9 @@ extern "C" int odam_sq_points_batch(odam_sq_ctx* ctx, int n, const float* params
 // frame.  One workgroup per track: points from odam_sq_points_batch's kernel, then the same float64 products per point and a
 // min / max reduction -- 32 bytes per track come back instead of 12 KB of points and 48,000 host flops.
 namespace {
-__global__ __launch_bounds__(256) void project_extent_kernel(const float* __restrict__ pts, const double* __restrict__ cam, double* __restrict__ out) {
+struct Cam21 { double v[21]; };      // T_cw rows 0..2 (12), K (9): travels in the kernel arguments, no upload of its own
+__global__ __launch_bounds__(256) void project_extent_kernel(const float* __restrict__ pts, const Cam21 camv, double* __restrict__ out) {
+    const double* cam = camv.v;
     __shared__ double red[4][4];
     const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* p = pts + (size_t)t * N_PTS * 3;
@@ -912,10 +914,10 @@ extern "C" int odam_sq_project_extents(odam_sq_ctx* ctx, int n, const float* par
         ODAM_HIP(hipMalloc((void**)&ctx->d_proj_pts, cap * N_PTS * 3 * sizeof(float)));
         ctx->proj_pts_n = cap;
     }
-    if (!ctx->d_cam) ODAM_HIP(hipMalloc((void**)&ctx->d_cam, 21 * sizeof(double)));
-    ODAM_HIP(hipMemcpyAsync(ctx->d_cam, T_cw12_K9, 21 * sizeof(double), hipMemcpyHostToDevice, st));   // pageable source: staged by the runtime before it returns
     if (int rc = odam_sq_points_batch(ctx, n, params, ctx->d_proj_pts, stream)) return rc;
-    hipLaunchKernelGGL(project_extent_kernel, dim3(n), dim3(256), 0, st, ctx->d_proj_pts, ctx->d_cam, out_px);
+    Cam21 cam;
+    for (int i = 0; i < 21; i++) cam.v[i] = T_cw12_K9[i];
+    hipLaunchKernelGGL(project_extent_kernel, dim3(n), dim3(256), 0, st, ctx->d_proj_pts, cam, out_px);
     ODAM_HIP(hipGetLastError());
     return ODAM_OK;
 }
