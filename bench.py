@@ -278,7 +278,8 @@ def main():
                         "split of both operands (a = hi + mid + lo, no rounding) and six products on v_mfma_f32_32x32x16_bf16 "
                         "(dropped terms < 2^-24 |a b|): max error vs float64 0.8-1.4e-7 of sum |a b|, the fp32 matrix instruction's "
                         "own chain 1.1-1.9e-7 (tests/native/x3_probe.hip); every parity test passes unchanged in this mode; "
-                        "smaller layers use v_mfma_f32_32x32x2_f32") if split_mode else "v_mfma_f32_32x32x2_f32 (ODAM_CG_BIG_F32=0)",
+                        "smaller layers take the same six products on 64- / 128-row tiles (cg.small_x3; layers whose input channels "
+                        "are not a multiple of 32 stay on v_mfma_f32_32x32x2_f32)") if split_mode else "v_mfma_f32_32x32x2_f32 (ODAM_CG_BIG_F32=0)",
         "fp32_matrix_instruction_only": ({"value": f32_instr, "unit": "frames/s", "note": "same scene, one timed pass with "
                                           "odam_op_conv_f32_mode(0): every layer on v_mfma_f32_32x32x2_f32"} if f32_instr else None),
         "data": "synthetic (seeded 640x480 uint8 RGB stream resident in HBM, put through the reference transform on the "
@@ -324,7 +325,7 @@ def main():
                               "algorithmic_gflop_per_launch_avg": conv_flops / max(n_launch, 1) / 1e9,
                               "kernel": "conv_gemm (fp32 implicit-GEMM conv / linear: 256-row LDS-DMA ring kernel with the exact bf16 split "
                                         "for layers that fill the device -- layer1 / layer2 bottlenecks as one launch each: 3x3 + expand + "
-                                        "residual, in layer1 also the next reduce --, 128x128 tiles on v_mfma_f32_32x32x2_f32 otherwise)"
+                                        "residual, in layer1 also the next reduce --, 128x128 / 64x64 tiles with the same split otherwise)"
                               if split_mode else "conv_gemm_kernel (fp32 implicit-GEMM conv / linear, v_mfma_f32_32x32x2_f32)",
                               "launches_per_forward": n_launch,
                               "algorithmic_gflop_per_frame": flops_per_frame / 1e9,
