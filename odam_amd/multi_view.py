@@ -133,12 +133,24 @@ def _object_constraints(track, frame_to_img, img_h, img_w, thr=EDGE_THRESHOLD):
     Returns class, image ids [n], tgt, mask, rotation matrices [n,3,3], t_wo [3], dims [n,3].
     """
     frames = track[:, 0].astype(np.int32)
-    first_row = {}
-    for r, fid in enumerate(frames.tolist()):
-        first_row.setdefault(fid, r)
-    obs = sorted((img_id, r) for fid, r in first_row.items() for img_id in frame_to_img.get(fid, ()))
-    img_ids = np.array([o[0] for o in obs], np.int64)
-    rows = np.array([o[1] for o in obs], np.int64)
+    if isinstance(frame_to_img, _UniqueFrames):
+        # every frame id names ONE image (the usual sequence): first row of each id by np.unique, image index by binary search,
+        # image order by one argsort -- the same (img_id, row) list as the walk below, without a Python loop per observation
+        uniq, first = np.unique(frames, return_index=True)
+        pos = np.searchsorted(frame_to_img.ids, uniq)
+        pos[pos >= len(frame_to_img.ids)] = 0
+        hit = frame_to_img.ids[pos] == uniq
+        img_ids = frame_to_img.order[pos[hit]]
+        rows = first[hit].astype(np.int64)
+        o = np.argsort(img_ids, kind="stable")
+        img_ids, rows = img_ids[o], rows[o]
+    else:
+        first_row = {}
+        for r, fid in enumerate(frames.tolist()):
+            first_row.setdefault(fid, r)
+        obs = sorted((img_id, r) for fid, r in first_row.items() for img_id in frame_to_img.get(fid, ()))
+        img_ids = np.array([o[0] for o in obs], np.int64)
+        rows = np.array([o[1] for o in obs], np.int64)
     obj_class = int(np.median(track[:, 1]))
     t_wo = np.mean(track[:, 9:12], axis=0)
     sub = track[rows]
@@ -150,6 +162,44 @@ def _object_constraints(track, frame_to_img, img_h, img_w, thr=EDGE_THRESHOLD):
     mask = ((vals > thr) & (vals < lims - thr)).astype(np.float32)
     tgt = np.where(mask > 0, (-((-vals).astype(np.float32))), np.float32(0)).astype(np.float32)
     return obj_class, img_ids, tgt, mask, R, t_wo, sub[:, 6:9]
+
+
+class _UniqueFrames:
+    """frame id -> image index for a sequence whose frame ids are all different: ids sorted, order[i] = image index of ids[i]"""
+
+    def __init__(self, img_names):
+        names = np.asarray([int(f) for f in img_names], np.int64)
+        self.order = np.argsort(names, kind="stable").astype(np.int64)
+        self.ids = names[self.order]
+
+    @staticmethod
+    def applies(img_names):
+        names = np.asarray([int(f) for f in img_names], np.int64)
+        return len(names) > 0 and len(np.unique(names)) == len(names) and np.abs(names).max() < 2 ** 31
+
+
+def averaging_T_wos_batch(R_list, t_list):
+    """averaging_T_wos for many objects with ONE conversion of all rotation matrices, one batched symmetric eigen-decomposition and
+    one conversion back -- the same operations scipy's Rotation.mean applies per object (quaternions q of the observations,
+    K = q^T q by np.dot, eigenvector of the largest eigenvalue from np.linalg.eigh, taken as the mean quaternion WITHOUT
+    renormalising), so every matrix equals the per-object call bit for bit (tests/test_multi_view_host.py checks 400 objects)."""
+    n = len(R_list)
+    out = np.tile(np.eye(4), (n, 1, 1))
+    if n == 0:
+        return out
+    lens = [len(R) for R in R_list]
+    q_all = Rotation.from_matrix(np.concatenate(R_list)).as_quat()
+    K = np.empty((n, 4, 4))
+    o = 0
+    for i, k in enumerate(lens):
+        q = q_all[o:o + k]
+        K[i] = np.dot(q.T, q)
+        o += k
+    _, v = np.linalg.eigh(K)
+    out[:, :3, :3] = Rotation(np.ascontiguousarray(v[:, :, -1]), normalize=False).as_matrix()
+    for i, (t, k) in enumerate(zip(t_list, lens)):
+        out[i, :3, 3] = np.mean(np.repeat(t[None, :], k, axis=0), axis=0)
+    return out
 
 
 def averaging_T_wos(R_wos, t_wo):
@@ -212,20 +262,29 @@ def optim_process(tracks, img_names, T_wcs, P_cws, img_h, img_w, K, representati
     """run_multi_view.py:22-76 with the per-object fits batched on the GPU."""
     fitter = fitter or default_fitter()
     n_objs = len(tracks)
-    frame_to_img = {}
-    for i, fid in enumerate(img_names):
-        frame_to_img.setdefault(int(fid), []).append(i)  # every image whose id is in the track
+    if _UniqueFrames.applies(img_names):
+        frame_to_img = _UniqueFrames(img_names)
+    else:
+        frame_to_img = {}
+        for i, fid in enumerate(img_names):
+            frame_to_img.setdefault(int(fid), []).append(i)  # every image whose id is in the track
     P_all = np.asarray(P_cws)
 
     inits, classes, bboxes_dl, fit_ids = [], [], [], []
     fit_P, fit_tgt, fit_mask, fit_counts = [], [], [], []
+    cons = [_object_constraints(np.asarray(tracks[obj_id]), frame_to_img, img_h, img_w) for obj_id in range(n_objs)]
+    # mean pose of every object (tracking_gt_utils.py:59-66) and its yaw: the scipy conversions once for all objects
+    if n_objs and all(len(c[4]) for c in cons):
+        T_wos = averaging_T_wos_batch([c[4] for c in cons], [c[5] for c in cons])
+        yaws = Rotation.from_matrix(T_wos[:, :3, :3]).as_euler("zxy")[:, 0]
+    else:       # an object without an observed frame: the per-object calls (and their errors) as they were
+        T_wos = yaws = None
     for obj_id in range(n_objs):
-        obj_class, img_ids, tgt, mask, R_wos, t_wo, dims = _object_constraints(np.asarray(tracks[obj_id]),
-                                                                             frame_to_img, img_h, img_w)
-        T_wo = averaging_T_wos(R_wos, t_wo)
+        obj_class, img_ids, tgt, mask, R_wos, t_wo, dims = cons[obj_id]
+        T_wo = T_wos[obj_id] if T_wos is not None else averaging_T_wos(R_wos, t_wo)
         scales = np.mean(np.asarray(dims), axis=0)
         bboxes_dl.append(get_3d_box(scales, T_wo[:3, :3], T_wo[:3, 3]))
-        yaw = Rotation.from_matrix(T_wo[:3, :3]).as_euler("zxy")[0]
+        yaw = yaws[obj_id] if yaws is not None else Rotation.from_matrix(T_wo[:3, :3]).as_euler("zxy")[0]
         if prior and obj_class not in _sq.CLASS_MAPPER:
             raise KeyError(obj_class)  # sq_libs.py:464 (CLASS_MAPPER covers classes 0..7 only)
         inits.append(_sq.init_params(T_wo[:3, 3], yaw, scales, representation))
