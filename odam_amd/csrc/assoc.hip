@@ -870,6 +870,11 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
         if (m->resident_capacity < PG_WG) m->persist = false;
     }
     m->host.clear();
+    // alloc() zeroes every buffer with hipMemset, which is ordered on the NULL stream and may still be pending when it returns: a
+    // caller that works on a non-blocking stream of its own would otherwise see its first results wiped by a late memset
+#ifndef ODAM_TEST_NO_CREATE_SYNC      // (tests build the library without it once, to see the regression test fail)
+    ODAM_HIP(hipStreamSynchronize(nullptr));
+#endif
     m->finalized = true;
     return 0;
 }
@@ -1108,6 +1113,16 @@ extern "C" int odam_trackwin_create(int max_tracks, int window, odam_trackwin** 
         delete w;
         return odam_fail(2, "odam_trackwin_create: allocation failed");
     }
+    // the memset above is ordered on the NULL stream and may still be pending: it must not land behind a load / append that the
+    // caller issues on a non-blocking stream of its own (it did: the counts of a freshly loaded store were zeroed -- GPU test
+    // test_stores_created_while_the_default_stream_is_busy)
+#ifndef ODAM_TEST_NO_CREATE_SYNC
+    if (hipStreamSynchronize(nullptr) != hipSuccess) {
+        (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->stage);
+        delete w;
+        return odam_fail(2, "odam_trackwin_create: synchronisation failed");
+    }
+#endif
     for (int i = 0; i < 8; i++)
         if (hipEventCreateWithFlags(&w->copied[i], hipEventDisableTiming) != hipSuccess) {
             for (int j = 0; j < i; j++) (void)hipEventDestroy(w->copied[j]);

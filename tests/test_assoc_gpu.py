@@ -1,6 +1,7 @@
 """gfx950 association network (GNN + fused Sinkhorn) against the reference Associator's outputs
 (tests/golden/assoc.npz, made by importing src/models/associator.py on the CPU)."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -336,3 +337,48 @@ def test_track_windows_rebuild_and_queued_appends_equal_the_host_path():
     steps = win.build(proj_dev, T_cw, cam_azi, 640, 480).cpu().numpy()
     assert np.array_equal(one, steps)
     win.close()
+
+
+def test_stores_created_while_the_default_stream_is_busy():
+    """A caller may run the association on a stream of its own (torch.cuda.stream) while other work sits on the default stream --
+    bench.py's overlapped mode does, with the detector in another thread.  Buffers the library zeroes when it CREATES a store must be
+    zero before the create call returns: hipMemset is ordered on the NULL stream, and a memset still queued there behind foreign
+    work landed after the caller's first load on its own stream (track counts back to zero -> windows of -1).  Track store and
+    association handle created and used on a side stream behind ~100 ms of work on the default stream, against the default-stream run."""
+    import torch
+    from odam_amd import associator, weights
+    from odam_amd.associator import TrackWindows
+    from odam_amd.processor import OdamProcess, get_cam_azi
+    rs = np.random.RandomState(5)
+    proc = OdamProcess(None, None, None, None)
+    proc.init_sequence(np.array([[577.87, 0, 319.5], [0, 577.87, 239.5], [0, 0, 1.0]]), 480, 640)
+    Q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+    T_wc = np.eye(4); T_wc[:3, :3] = Q; T_wc[:3, 3] = rs.normal(size=3)
+    cam_azi = get_cam_azi(T_wc)
+    tracks = _random_tracks(rs, [3, 120, 40, 7])
+    proj = rs.uniform(-200, 900, (len(tracks), 4))
+    want = np.ascontiguousarray(proc._preprocess_tracks(tracks, T_wc, cam_azi, proj_px=proj).transpose(0, 2, 1))
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "assoc.npz"))
+    tr, de, Zr = z["c0_tracks"], z["c0_det"], z["c0_Z"]
+    T, n_det = Zr.shape[0] - 1, Zr.shape[1] - 1
+    cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
+    sd = weights.make_associator_state_dict(2, 8, seed=0)
+    a0 = associator.Associator(cfg, max_tracks=64, device=DEV); a0.load_state_dict(sd)
+    Z0 = a0.assignment_checked(torch.from_numpy(tr), torch.from_numpy(de), T, n_det).cpu().numpy()
+    a0.close()
+    busy = torch.randn(8192, 8192, device=DEV)
+    side = torch.cuda.Stream()
+    for _ in range(30):
+        busy = busy @ busy * 1e-4                     # queued on the default stream
+    with torch.cuda.stream(side):
+        win = TrackWindows(DEV)
+        win.load(tracks)
+        got = win.build(torch.from_numpy(proj).to(DEV), np.linalg.inv(T_wc), cam_azi, 640, 480)
+        a1 = associator.Associator(cfg, max_tracks=64, device=DEV); a1.load_state_dict(sd)
+        Z1 = a1.assignment_checked(torch.from_numpy(tr), torch.from_numpy(de), T, n_det)
+        side.synchronize()
+        got, Z1 = got.cpu().numpy(), Z1.cpu().numpy()
+    torch.cuda.synchronize()
+    assert np.array_equal(got, want)
+    assert np.array_equal(Z1, Z0)
+    win.close(); a1.close()
