@@ -227,6 +227,13 @@ class Associator:
             _lib.lib().odam_assoc_destroy(old_h)
         self._lost_seen = 0
 
+    def set_persistent(self, on):
+        """matching GNN as one persistent launch (the default where the device can hold its 256 workgroups at once) or as the launch
+        sequence.  A caller that runs the association on a stream restricted to a share of the compute units
+        (odam_amd.streams.cu_masked_stream) must switch the persistent launch off: its workgroups wait for each other and would
+        never all become resident (the bounded wait would abandon every launch and re-run it through the sequence)."""
+        _lib.check(_lib.lib().odam_assoc_set_persistent(self._handle(), ctypes.c_int(1 if on else 0)), "odam_assoc_set_persistent")
+
     def assignment(self, tracks, detections, n_tracks, n_det, sequence=False):
         """tracks [T,79,100], detections [1,79,30] or [79,30] (any device) -> Z [(T+1),(n_det+1)] device tensor.
         Stream-ordered; sequence=True takes the launch-sequence path (no device-wide barrier).

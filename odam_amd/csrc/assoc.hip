@@ -21,6 +21,7 @@
 #include "../../include/odam_assoc.h"
 #include "conv_gemm.h"
 #include "detr_kernels.h"
+#include "sk_wave.h"
 #include "odam_config.h"
 #include "odam_err.h"
 
@@ -488,8 +489,6 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn32_kernel(const float* __restri
 // lane's share of it, the others the second -- so 32 columns cost 16 + 8 + 4 + 2 + 1 exchanges, not 32 x 6, and end with column
 // c's total in lane sk_lane(c): b is ONE register (lane = column), one reciprocal per iteration; the row sums read it back
 // through v_readlane.
-#include "sk_wave.h"
-
 template <int RB, int NC>
 __global__ __launch_bounds__(64) void sinkhorn_wave_kernel(const float* __restrict__ scores, int lds, int m, int n, float alpha, int iters,
                                                            float* __restrict__ out, const int* __restrict__ n_dev,
@@ -687,15 +686,25 @@ struct odam_assoc {
     bool want_stamps = false;
     bool bar_clean = false;                  // the counters are zero: the one-wavefront Sinkhorn kernel zeroes them behind the launch that used them
 
+    // Zeroing goes through a private non-blocking stream that finalize waits for: hipMemset would be ordered on the NULL stream -- it
+    // may still be pending when it returns (and then land behind the first results of a caller that works on a stream of its own),
+    // and waiting for the NULL stream instead would wait for whatever another thread has queued there (a detector's chunk copies).
+    hipStream_t init_stream = nullptr;
     int alloc(float** p, size_t n) {
         ODAM_HIP(hipMalloc((void**)p, n * sizeof(float)));
-        ODAM_HIP(hipMemset(*p, 0, n * sizeof(float)));
+        if (!init_stream) ODAM_HIP(hipStreamCreateWithFlags(&init_stream, hipStreamNonBlocking));
+        ODAM_HIP(hipMemsetAsync(*p, 0, n * sizeof(float), init_stream));
         allocs.push_back(*p);
+        return 0;
+    }
+    int init_done() {
+        if (init_stream) { ODAM_HIP(hipStreamSynchronize(init_stream)); ODAM_HIP(hipStreamDestroy(init_stream)); init_stream = nullptr; }
         return 0;
     }
     int upload(float** p, const std::vector<float>& v) {
         if (int rc = alloc(p, v.size())) return rc;
-        ODAM_HIP(hipMemcpy(*p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+        ODAM_HIP(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, init_stream));   // behind the memset of the same buffer
+        ODAM_HIP(hipStreamSynchronize(init_stream));        // v may be a temporary
         return 0;
     }
 };
@@ -789,6 +798,7 @@ extern "C" int odam_assoc_create(int max_tracks, int n_self_layers, const int* g
 extern "C" int odam_assoc_destroy(odam_assoc* m) {
     if (!m) return 0;
     if (m->lost_count) (void)hipHostFree(m->lost_count);
+    if (m->init_stream) { (void)hipStreamSynchronize(m->init_stream); (void)hipStreamDestroy(m->init_stream); }
     for (void* p : m->allocs) (void)hipFree(p);
     delete m;
     return 0;
@@ -870,11 +880,8 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
         if (m->resident_capacity < PG_WG) m->persist = false;
     }
     m->host.clear();
-    // alloc() zeroes every buffer with hipMemset, which is ordered on the NULL stream and may still be pending when it returns: a
-    // caller that works on a non-blocking stream of its own would otherwise see its first results wiped by a late memset
-#ifndef ODAM_TEST_NO_CREATE_SYNC      // (tests build the library without it once, to see the regression test fail)
-    ODAM_HIP(hipStreamSynchronize(nullptr));
-#endif
+    // every buffer alloc() zeroed is zero from here on (see alloc)
+    RC(m->init_done());
     m->finalized = true;
     return 0;
 }
@@ -1016,6 +1023,8 @@ struct odam_trackwin {
     double* stage = nullptr;    // pinned [8][32][14 + 1]: rows + track id of one append
     double* d_stage = nullptr;  // device copy of one slot
     double* d_cam = nullptr;    // [16] (unused since the camera travels in the kernel arguments; kept so the handle layout of create / destroy stays as tested)
+    double* h_load = nullptr;   // pinned [max_tracks][window][14]: what odam_trackwin_load's kernel reads (mapped host memory; allocated once -- the
+    int* h_load_meta = nullptr; // load path has no allocation, no hipFree (it waits for every stream of the device) and no copy command)
     unsigned slot = 0;
     hipEvent_t copied[8] = {};  // recorded behind the upload from pinned slot i: the host rewrites a slot only after its copy has run
     bool copied_armed[8] = {};
@@ -1103,30 +1112,40 @@ extern "C" int odam_trackwin_create(int max_tracks, int window, odam_trackwin** 
         hipMalloc((void**)&w->count, sizeof(int) * (size_t)max_tracks) != hipSuccess ||
         hipMalloc((void**)&w->d_stage, sizeof(double) * 32 * (TW_COLS + 1)) != hipSuccess ||
         hipMalloc((void**)&w->d_cam, sizeof(double) * 16) != hipSuccess ||
-        hipHostMalloc((void**)&w->stage, sizeof(double) * 8 * 32 * (TW_COLS + 1), hipHostMallocDefault) != hipSuccess ||
-        hipMemset(w->count, 0, sizeof(int) * (size_t)max_tracks) != hipSuccess) {
+        hipHostMalloc((void**)&w->h_load, sizeof(double) * (size_t)max_tracks * window * TW_COLS, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&w->h_load_meta, sizeof(int) * 2 * (size_t)max_tracks, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&w->stage, sizeof(double) * 8 * 32 * (TW_COLS + 1), hipHostMallocDefault) != hipSuccess) {
         if (w->rows) (void)hipFree(w->rows);
         if (w->count) (void)hipFree(w->count);
         if (w->d_stage) (void)hipFree(w->d_stage);
         if (w->d_cam) (void)hipFree(w->d_cam);
+        if (w->h_load) (void)hipHostFree(w->h_load);
+        if (w->h_load_meta) (void)hipHostFree(w->h_load_meta);
         if (w->stage) (void)hipHostFree(w->stage);
         delete w;
         return odam_fail(2, "odam_trackwin_create: allocation failed");
     }
-    // the memset above is ordered on the NULL stream and may still be pending: it must not land behind a load / append that the
-    // caller issues on a non-blocking stream of its own (it did: the counts of a freshly loaded store were zeroed -- GPU test
-    // test_stores_created_while_the_default_stream_is_busy)
-#ifndef ODAM_TEST_NO_CREATE_SYNC
-    if (hipStreamSynchronize(nullptr) != hipSuccess) {
-        (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->stage);
-        delete w;
-        return odam_fail(2, "odam_trackwin_create: synchronisation failed");
+    // counts start at zero, and are zero when this call returns: through a private non-blocking stream -- hipMemset would be
+    // ordered on the NULL stream, may still be pending when it returns and then land behind a load / append the caller issues on
+    // a stream of its own (it did: the counts of a freshly loaded store went back to zero -- GPU test
+    // test_stores_created_while_the_default_stream_is_busy); waiting for the NULL stream instead would wait for whatever another
+    // thread has queued there
+    {
+        hipStream_t init = nullptr;
+        const bool ok = hipStreamCreateWithFlags(&init, hipStreamNonBlocking) == hipSuccess &&
+                        hipMemsetAsync(w->count, 0, sizeof(int) * (size_t)max_tracks, init) == hipSuccess &&
+                        hipStreamSynchronize(init) == hipSuccess;
+        if (init) (void)hipStreamDestroy(init);
+        if (!ok) {
+            (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->h_load); (void)hipHostFree(w->h_load_meta); (void)hipHostFree(w->stage);
+            delete w;
+            return odam_fail(2, "odam_trackwin_create: initialisation failed");
+        }
     }
-#endif
     for (int i = 0; i < 8; i++)
         if (hipEventCreateWithFlags(&w->copied[i], hipEventDisableTiming) != hipSuccess) {
             for (int j = 0; j < i; j++) (void)hipEventDestroy(w->copied[j]);
-            (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->stage);
+            (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->h_load); (void)hipHostFree(w->h_load_meta); (void)hipHostFree(w->stage);
             delete w;
             return odam_fail(2, "odam_trackwin_create: event creation failed");
         }
@@ -1147,7 +1166,7 @@ extern "C" int odam_trackwin_destroy(odam_trackwin* w) {
         if (w->copied_armed[i]) (void)hipEventSynchronize(w->copied[i]);      // no upload may still be reading the pinned ring
         (void)hipEventDestroy(w->copied[i]);
     }
-    (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->stage);
+    (void)hipFree(w->rows); (void)hipFree(w->count); (void)hipFree(w->d_stage); (void)hipFree(w->d_cam); (void)hipHostFree(w->h_load); (void)hipHostFree(w->h_load_meta); (void)hipHostFree(w->stage);
     delete w;
     return 0;
 }
@@ -1208,22 +1227,17 @@ extern "C" int odam_trackwin_load(odam_trackwin* w, int T, const int* lengths, c
         meta[t] = (int)total; meta[T + t] = lengths[t];
         total += lengths[t] < w->window ? lengths[t] : w->window;
     }
-    double* d_rows = nullptr; int* d_meta = nullptr;
-    if (hipMalloc((void**)&d_rows, sizeof(double) * (size_t)(total ? total : 1) * TW_COLS) != hipSuccess ||
-        hipMalloc((void**)&d_meta, sizeof(int) * 2 * (size_t)T) != hipSuccess) {
-        if (d_rows) (void)hipFree(d_rows);
-        return odam_fail(2, "odam_trackwin_load: allocation failed");
-    }
+    // The kernel reads the handle's pinned staging itself (mapped host memory, sized for max_tracks full windows at creation): no
+    // allocation here, no hipFree (it waits for every stream of the device -- for a detector running beside this caller) and no
+    // copy command (free: every load ends with a stream synchronisation, so the staging is the caller's again when this returns).
     int rc = 0;
-    if (hipMemcpyAsync(d_rows, rows14, sizeof(double) * (size_t)total * TW_COLS, hipMemcpyHostToDevice, st) != hipSuccess ||
-        hipMemcpyAsync(d_meta, meta.data(), sizeof(int) * 2 * (size_t)T, hipMemcpyHostToDevice, st) != hipSuccess)
-        rc = odam_fail(2, "odam_trackwin_load: upload failed");
-    if (!rc) {
-        hipLaunchKernelGGL(trackwin_load_kernel, dim3(T), dim3(128), 0, st, d_rows, d_meta, T, w->rows, w->count, w->window);
+    std::memcpy(w->h_load, rows14, sizeof(double) * (size_t)total * TW_COLS);
+    std::memcpy(w->h_load_meta, meta.data(), sizeof(int) * 2 * (size_t)T);
+    {
+        hipLaunchKernelGGL(trackwin_load_kernel, dim3(T), dim3(128), 0, st, w->h_load, w->h_load_meta, T, w->rows, w->count, w->window);
         if (hipGetLastError() != hipSuccess) rc = odam_fail(2, "odam_trackwin_load: launch failed");
     }
     if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = odam_fail(2, "odam_trackwin_load: stream synchronisation failed");
-    (void)hipFree(d_rows); (void)hipFree(d_meta);
     return rc;
 }
 
