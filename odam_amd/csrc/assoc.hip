@@ -153,6 +153,7 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict
 // Barrier: two levels -- 8 group counters (workgroup id % 8; 32 arrivals each on its own line), the last arrival of a group
 // bumps the global generation every workgroup polls; the spin is bounded so a lost workgroup cannot hang the device.
 constexpr int PG_WG = 256, PG_NT = 256, PG_NW = PG_NT / 64, PG_MAXL = 16, PG_GROUPS = 8;
+constexpr int PG_BAR_WORDS = 32 * (1 + 2 * PG_GROUPS);     // generation + flag line, 8 group counters, 8 per-XCD counters (each on its own 128-byte line)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GnnLayerW { const float *qkv_w, *qkv_b, *mg_w, *mg_b, *m0_w, *m0_b, *m2_w, *m2_b; int cross; };
@@ -161,6 +162,7 @@ struct GnnArgs {
     int n_layers;
     const float *fin_w, *fin_b;
     float *X, *kv, *att, *h, *mT;     // [MX][512], [MX][768], [MX][256], [MX][512], [MX + 2][256]
+    float* kv2;                       // second [MX][768] (the row-partitioned kernel alternates between the two by layer)
     int T;
     unsigned* bar;                    // [0] generation, [1] error flag (a barrier timed out), [32 (1 + g)] group counters; zeroed before every launch
     unsigned long long timeout_ticks; // bound of one barrier wait in 100 MHz ticks (0: give up at the first barrier -- tests)
@@ -354,6 +356,177 @@ __global__ __launch_bounds__(PG_NT) void gnn_persistent_kernel(GnnArgs a) {
     }
 #undef PG_BARRIER
     stage_gemm<D, false>(a.X, 512, a.fin_w, a.fin_b, MX, D, nullptr, a.mT, D, red, wave, lane);
+    stamp();
+}
+
+// ---- the same network, ROWS DEALT TO THE XCDs: one device-wide barrier per layer instead of five -------------------------------------
+// Of a layer's five stages only the attention needs rows of other workgroups' making in bulk -- keys and values of ALL rows; the
+// projections and the MLP are row-wise.  Workgroup b of a plain launch always runs on XCD b mod 8 (tests/native/xcd_probe.hip), and an
+// exchange among the 32 workgroups of one XCD -- plain stores, sc1 loads that hit that XCD's L2, a workgroup-scope counter executed
+// in that L2 -- costs 1.1 us where the device-wide form costs 4.9 (tests/native/xcd_barrier_probe.hip).  So XCD x owns rows
+// [x R, (x + 1) R), R = ceil(rows / 8): its workgroups project q | k | v of those rows (stored sc1: the one thing that crosses XCDs),
+// all 256 workgroups meet ONCE, then attention, merge and the two MLP layers of those rows run behind XCD-local barriers.  Every
+// output element is computed exactly as in gnn_persistent_kernel (same 16x16 blocks, same K split over the four waves): the two
+// kernels agree bit for bit.  k | v alternate between two buffers by layer: a fast XCD may project layer l + 1 while a slow one still
+// reads layer l's keys (the device barrier of layer l + 1 is what frees buffer l & 1 again).
+__device__ __forceinline__ bool xcd_barrier(unsigned* bar, unsigned* cnt, unsigned& target, unsigned long long timeout_ticks, int* lost) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have reached the L2 the readers will hit
+    __syncthreads();
+    target += PG_WG / PG_GROUPS;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bool ok = timeout_ticks != 0;
+        const unsigned long long t0 = wall_clock64();
+        for (int spins = 0; ok; ++spins) {
+            unsigned g, e;      // sc0 sc1: past the vector L1 (an sc0-only poll can spin on a stale line)
+            asm volatile("global_load_dword %0, %2, off sc0 sc1\n\tglobal_load_dword %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(g), "=&v"(e) : "v"(cnt), "v"(bar + 1) : "memory");
+            if (e) { ok = false; break; }
+            if ((int)(g - target) >= 0) break;
+            __builtin_amdgcn_s_sleep(1);
+            if ((spins & 63) == 63 && wall_clock64() - t0 > timeout_ticks) ok = false;
+        }
+        if (!ok) __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lost = ok ? 0 : 1;
+    }
+    __syncthreads();
+    return *lost == 0;
+}
+
+// stage_gemm over rows [r0, r0 + nR) only, blocks dealt over the nw workgroups of this XCD (wi = 0 .. nw - 1); FAR: the output is read
+// by other XCDs (sc1 store), otherwise a plain store that the XCD-local barrier drains
+template <int K, bool RELU, bool FAR>
+__device__ void stage_gemm_rows(const float* X, int lda, const float* W, const float* b, int r0, int nR, int N, const float* res,
+                                float* Y, int ldc, float* red, int wave, int lane, int wi, int nw) {
+    constexpr int KW = K / PG_NW, NL = KW / 16;
+    const int RB = (nR + 15) >> 4, CB = N >> 4, rlim = r0 + nR;
+    const int li = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t xb = coh_buf(X), yb = coh_buf(Y), rsb = coh_buf(res ? res : Y);
+    for (int item = wi; item < RB * CB; item += nw) {
+        const int rb = item / CB, cb = item - rb * CB;
+        const int r = r0 + rb * 16 + li;
+        const int xo = (r < rlim ? r : rlim - 1) * lda + wave * KW + 4 * kq;
+        const float* wp = W + (size_t)(cb * 16 + li) * K + wave * KW + 4 * kq;
+        float4 a[NL], w[NL];
+#pragma unroll
+        for (int t = 0; t < NL; t++) {
+            a[t] = coh_ld4(xb, xo + 16 * t);
+            w[t] = *reinterpret_cast<const float4*>(wp + 16 * t);
+        }
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NL; t++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].x, w[t].x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].y, w[t].y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].z, w[t].z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t].w, w[t].w, acc1, 0, 0, 0);
+        }
+        const f32x4 part = acc0 + acc1;
+        if (wave) *reinterpret_cast<f32x4*>(red + ((wave - 1) * 64 + lane) * 4) = part;
+        __syncthreads();
+        if (wave == 0) {
+            f32x4 tot = part;
+#pragma unroll
+            for (int w2 = 0; w2 < PG_NW - 1; w2++) tot += *reinterpret_cast<const f32x4*>(red + (w2 * 64 + lane) * 4);
+            const int col = cb * 16 + li;
+            const float bias = b ? b[col] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int row = r0 + rb * 16 + 4 * kq + i;
+                if (row < rlim) {
+                    float v = tot[i] + bias;
+                    if (res) v += coh_ld(rsb, row * ldc + col);
+                    if (RELU) v = fmaxf(v, 0.0f);
+                    if (FAR) coh_st(yb, row * ldc + col, v);
+                    else Y[(size_t)row * ldc + col] = v;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// stage_attn for the queries [r0, r0 + nR) (items dealt over the n_waves wavefronts of this XCD); keys and values of every row come
+// from kv (sc1 loads), the output stays in this XCD (plain store)
+__device__ void stage_attn_rows(const float* kv, int T, int cross, float* att, float* sc, int r0, int nR, int wave_x, int n_waves, int lane) {
+    const __amdgpu_buffer_rsrc_t kb = coh_buf(kv);
+    for (int item = wave_x; item < nR * 4; item += n_waves) {
+        const int q = r0 + (item >> 2), hd = item & 3;
+        const bool is_track = q < T;
+        const bool src_tracks = is_track != (cross != 0);
+        const int src0 = src_tracks ? 0 : T, nsrc = src_tracks ? T : ND;
+        const int qo = q * 768 + hd * 64;
+        float4 qq[16];
+#pragma unroll
+        for (int d = 0; d < 16; d++) qq[d] = coh_ld4(kb, qo + 4 * d);
+        float run_max = -INFINITY, run_sum = 0.0f, o = 0.0f;
+        for (int j0 = 0; j0 < nsrc; j0 += 64) {
+            const int j = j0 + lane, nj = nsrc - j0 < 64 ? nsrc - j0 : 64;
+            const int ko = (src0 + (j < nsrc ? j : nsrc - 1)) * 768 + 256 + hd * 64;
+            const int vo = (src0 + j0) * 768 + 512 + hd * 64 + lane;
+            float4 kk[16];
+            float vv[64];
+#pragma unroll
+            for (int d = 0; d < 16; d++) kk[d] = coh_ld4(kb, ko + 4 * d);
+#pragma unroll
+            for (int jj = 0; jj < 64; jj++) vv[jj] = coh_ld(kb, vo + (jj < nj ? jj : nj - 1) * 768);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < 16; d++) {
+                acc += qq[d].x * kk[d].x; acc += qq[d].y * kk[d].y; acc += qq[d].z * kk[d].z; acc += qq[d].w * kk[d].w;
+            }
+            const float sdot = j < nsrc ? acc * 0.125f : -INFINITY;
+            const float mx = fmaxf(run_max, wave_max64(sdot));
+            const float p = j < nsrc ? expf(sdot - mx) : 0.0f;
+            const float corr = expf(run_max - mx);
+            run_sum = run_sum * corr + wave_sum64(p);
+            run_max = mx;
+            sc[lane] = p;
+            __builtin_amdgcn_wave_barrier();
+            o *= corr;
+#pragma unroll
+            for (int jj = 0; jj < 64; jj++) o += (jj < nj ? sc[jj] : 0.0f) * vv[jj];
+            __builtin_amdgcn_wave_barrier();
+        }
+        att[(size_t)q * 256 + hd * 64 + lane] = o / run_sum;
+    }
+}
+
+__global__ __launch_bounds__(PG_NT) void gnn_rowpart_kernel(GnnArgs a) {
+    __shared__ float red[(PG_NW - 1) * 64 * 4];
+    __shared__ float scs[PG_NW * 64];
+    __shared__ int lost;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & (PG_GROUPS - 1), wi = blockIdx.x >> 3, nw = PG_WG / PG_GROUPS;
+    const int T = a.T, MX = T + ND;
+    const int R = (MX + PG_GROUPS - 1) / PG_GROUPS;
+    const int r0 = xcd * R, nR = MX - r0 < 0 ? 0 : (MX - r0 < R ? MX - r0 : R);      // the rows of this XCD (the last XCDs may have none)
+    const int wave_x = wave * nw + wi, n_waves = nw * PG_NW;
+    unsigned target = 0, target_x = 0;
+    unsigned* cnt_x = a.bar + 32 * (1 + PG_GROUPS + xcd);
+    int n_stamp = 0;
+    auto stamp = [&] { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[n_stamp++] = wall_clock64(); };
+#define PG_BARRIER() do { if (!grid_barrier(a.bar, target, a.timeout_ticks, &lost)) return; stamp(); } while (0)
+#define PX_BARRIER() do { if (!xcd_barrier(a.bar, cnt_x, target_x, a.timeout_ticks, &lost)) return; stamp(); } while (0)
+    stamp();
+    float* sc = scs + wave * 64;
+    for (int l = 0; l < a.n_layers; l++) {
+        const GnnLayerW& P = a.L[l];
+        float* kv = (l & 1) ? a.kv2 : a.kv;
+        stage_gemm_rows<D, false, true>(a.X, 512, P.qkv_w, P.qkv_b, r0, nR, 3 * D, nullptr, kv, 3 * D, red, wave, lane, wi, nw);
+        PG_BARRIER();
+        stage_attn_rows(kv, T, P.cross, a.att, sc, r0, nR, wave_x, n_waves, lane);
+        PX_BARRIER();
+        stage_gemm_rows<D, false, false>(a.att, D, P.mg_w, P.mg_b, r0, nR, D, nullptr, a.X + D, 512, red, wave, lane, wi, nw);
+        PX_BARRIER();
+        stage_gemm_rows<2 * D, true, false>(a.X, 512, P.m0_w, P.m0_b, r0, nR, 2 * D, nullptr, a.h, 2 * D, red, wave, lane, wi, nw);
+        PX_BARRIER();
+        stage_gemm_rows<2 * D, false, false>(a.h, 2 * D, P.m2_w, P.m2_b, r0, nR, D, a.X, a.X, 512, red, wave, lane, wi, nw);
+        PX_BARRIER();
+    }
+#undef PG_BARRIER
+#undef PX_BARRIER
+    stage_gemm_rows<D, false, false>(a.X, 512, a.fin_w, a.fin_b, r0, nR, D, nullptr, a.mT, D, red, wave, lane, wi, nw);
     stamp();
 }
 
@@ -617,8 +790,8 @@ __global__ __launch_bounds__(64) void sinkhorn_wave_kernel(const float* __restri
     }
     if (lane == 0 && lost && lost_count) __hip_atomic_fetch_add(lost_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // err = the persistent matching kernel's flag word (bar + 1): that launch is over (stream order) and its flag has been read
-    // above -- leave generation, flag and the group counters at zero for the next launch (saves a memset per frame)
-    if (err && lane <= PG_GROUPS) {
+    // above -- leave generation, flag, the group counters and the per-XCD counters at zero for the next launch (saves a memset per frame)
+    if (err && lane <= 2 * PG_GROUPS) {
         unsigned* bar = const_cast<unsigned*>(err) - 1;
         if (lane == 0) { bar[0] = 0u; bar[1] = 0u; }
         else bar[32 * lane] = 0u;
@@ -674,7 +847,7 @@ struct odam_assoc {
     float *div_term = nullptr, *sc16 = nullptr;
     // workspace
     float *feat = nullptr, *h256 = nullptr, *catT = nullptr, *kv = nullptr, *att = nullptr, *h512 = nullptr;
-    float *kvX = nullptr, *attX = nullptr, *hX = nullptr;
+    float *kvX = nullptr, *kvX2 = nullptr, *attX = nullptr, *hX = nullptr;
     float *catTr = nullptr, *featD = nullptr, *mT = nullptr, *scores = nullptr;
     // persistent matching kernel: barrier counters (+ error flag), zeroed on the stream before every launch
     unsigned* bar = nullptr;
@@ -847,14 +1020,14 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     // fused tracks [T] and the 30 detection slots share one row block (detections start at row T of the frame) so the
     // shared-weight GNN layers see both sets as ONE matrix
     RC(m->alloc(&m->catTr, (T + ND) * 512)); RC(m->alloc(&m->featD, ND * FPAD));
-    RC(m->alloc(&m->kvX, (T + ND) * 768)); RC(m->alloc(&m->attX, (T + ND) * D));
+    RC(m->alloc(&m->kvX, (T + ND) * 768)); RC(m->alloc(&m->kvX2, (T + ND) * 768)); RC(m->alloc(&m->attX, (T + ND) * D));
     RC(m->alloc(&m->hX, (T + ND) * 512));
     RC(m->alloc(&m->mT, (T + ND + 2) * D)); RC(m->alloc(&m->scores, T * 32));   // the score block reads 32 detection rows
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     ODAM_HIP(hipFuncSetAttribute((const void*)sinkhorn32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     {
         float* b = nullptr;
-        RC(m->alloc(&b, 32 * (1 + PG_GROUPS)));
+        RC(m->alloc(&b, PG_BAR_WORDS));
         m->bar = reinterpret_cast<unsigned*>(b);
     }
     {
@@ -921,14 +1094,15 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         }
         g.n_layers = (int)m->gnn.size();
         g.fin_w = m->final_proj.w; g.fin_b = m->final_proj.b;
-        g.X = X; g.kv = m->kvX; g.att = m->attX; g.h = m->hX; g.mT = m->mT;
+        g.X = X; g.kv = m->kvX; g.kv2 = m->kvX2; g.att = m->attX; g.h = m->hX; g.mT = m->mT;
         g.T = T;
         g.bar = m->bar; g.timeout_ticks = m->timeout_ticks;
         g.stamps = m->want_stamps ? m->stamps : nullptr;
         // counters and the error flag start from zero every launch: zeroed here, unless the Sinkhorn kernel behind the previous launch did it
-        if (!m->bar_clean) ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * 32 * (1 + PG_GROUPS), st));
+        if (!m->bar_clean) ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * PG_BAR_WORDS, st));
         m->bar_clean = false;
-        hipLaunchKernelGGL(gnn_persistent_kernel, dim3(PG_WG), dim3(PG_NT), 0, st, g);
+        if (odam_cfg::get(odam_cfg::ASSOC_PERSIST) == 2) hipLaunchKernelGGL(gnn_rowpart_kernel, dim3(PG_WG), dim3(PG_NT), 0, st, g);
+        else hipLaunchKernelGGL(gnn_persistent_kernel, dim3(PG_WG), dim3(PG_NT), 0, st, g);
         ODAM_HIP(hipGetLastError());
         // The score matrix keeps its own launch on the tiles of conv_gemm.hip: with saturated scores (the hand-built scene
         // weights reach +-1000) the Sinkhorn loop shares a detection's mass equally among several tracks and which of them

@@ -21,7 +21,9 @@ enum Key {
     ATT_X3,         // fp32 attention through the exact bf16 split (default 1; 0 = fp32 matrix instruction)
     ATT_BF16_MFMA,  // bf16 attention on the bf16 matrix instruction (default 1)
     STEM_ROWS,      // conv1 as a 7x1 row convolution on the ring kernel where it fills the device (default 1)
-    ASSOC_PERSIST,  // association: matching GNN as one persistent launch where the residency gate allows (default 1)
+    ASSOC_PERSIST,  // association: matching GNN as one persistent launch where the residency gate allows: 2 (default) rows dealt to the XCDs, one
+                    // device-wide barrier per layer and XCD-local ones for the rest (gnn_rowpart_kernel); 1 five device-wide barriers per layer
+                    // (gnn_persistent_kernel; bit-identical); 0 the launch sequence
     SQ_SPLIT,       // super-quadric fit: workgroups per object at most (default 16)
     SQ_SPLIT_WAIT,  // ... bounded wait for a partner's rows, 100 MHz ticks (default 3000; 0 = never wait)
     SQ_LANES,       // ... lanes per view in the extent search (default 0 = chosen by the cost model)

@@ -107,7 +107,7 @@ def test_persistent_matching_kernel_vs_launch_sequence(golden):
         many.load_state_dict(sd)
         many._handle()                                     # the switch is read when the handle is finalised
     finally:
-        _lib.set_config("assoc.persist", 1)
+        _lib.set_config("assoc.persist", 2)
     g = torch.Generator().manual_seed(5)
     base_t = torch.from_numpy(z["c0_tracks"]); base_d = torch.from_numpy(z["c0_det"])
     for T, n in ((1, 1), (3, 30), (17, 9), (40, 21), (70, 30), (96, 5), (300, 30), (129, 17)):    # > 64 tracks: several key chunks
@@ -382,3 +382,32 @@ def test_stores_created_while_the_default_stream_is_busy():
     assert np.array_equal(got, want)
     assert np.array_equal(Z1, Z0)
     win.close(); a1.close()
+
+
+def test_row_partitioned_matching_kernel_equals_the_device_wide_one(golden):
+    """odam_config assoc.persist = 2 (default): the matching GNN with the rows dealt to the XCDs -- one device-wide barrier per layer, XCD-local
+    barriers and plain stores for the row-wise stages (csrc/assoc.hip gnn_rowpart_kernel) -- against assoc.persist = 1, five device-wide
+    barriers per layer: every output element is computed by the same instructions in the same order, so the assignment matrices are equal
+    bit for bit.  Reference-run cases plus row counts around the partition's edges (1 ... 157 rows: XCDs without rows, several 16-row
+    blocks per XCD)."""
+    import torch
+    from odam_amd import _lib, associator, weights
+    z = golden("assoc.npz")
+    cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
+    a = associator.Associator(cfg, max_tracks=128, device=DEV); a.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0))
+    rng = np.random.default_rng(0)
+    cases = [(z[f"c{c}_tracks"], z[f"c{c}_det"], z[f"c{c}_Z"].shape[0] - 1, z[f"c{c}_Z"].shape[1] - 1) for c in range(int(z["n_cases"]))]
+    for T in (1, 7, 8, 9, 63, 64, 65, 100, 127):
+        cases.append((rng.standard_normal((T, 79, 100)).astype(np.float32), rng.standard_normal((79, 30)).astype(np.float32), T, int(rng.integers(1, 31))))
+    try:
+        for tr, de, T, n in cases:
+            Z = {}
+            for v in (1, 2):
+                _lib.set_config("assoc.persist", v)
+                Z[v] = a.assignment_checked(torch.from_numpy(tr), torch.from_numpy(de), T, n).cpu().numpy()
+            assert np.isfinite(Z[2]).all()
+            assert np.array_equal(Z[1].view(np.uint32), Z[2].view(np.uint32)), (T, n)
+        assert a.lost_launches == 0
+    finally:
+        _lib.set_config("assoc.persist", 2)
+        a.close()
