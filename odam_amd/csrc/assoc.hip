@@ -1358,8 +1358,8 @@ extern "C" int odam_trackwin_append(odam_trackwin* w, int n, const int* track_id
     hipStream_t st = (hipStream_t)stream;
     for (int i = 0; i < n; i++)
         if (track_ids[i] < 0 || track_ids[i] >= w->max_tracks) return odam_fail(3, "odam_trackwin_append: track id outside the handle's capacity");
-    // The upload below is truly asynchronous (pinned source): the ring slot may be rewritten only once the copy that was issued
-    // from it eight appends ago has run -- appends can queue behind long kernels on the stream (a detector forward, a rebuild).
+    // The ring slot may be rewritten only once the kernel that read it eight appends ago has run -- appends can queue behind long
+    // kernels on the stream (a detector forward, a rebuild).
     const int si = (int)(w->slot++ & 7);
     if (w->copied_armed[si]) ODAM_HIP(hipEventSynchronize(w->copied[si]));
     double* slot = w->stage + (size_t)si * 32 * (TW_COLS + 1);
@@ -1367,11 +1367,12 @@ extern "C" int odam_trackwin_append(odam_trackwin* w, int n, const int* track_id
         for (int c = 0; c < TW_COLS; c++) slot[i * (TW_COLS + 1) + c] = rows14[i * TW_COLS + c];
         slot[i * (TW_COLS + 1) + TW_COLS] = (double)track_ids[i];
     }
-    ODAM_HIP(hipMemcpyAsync(w->d_stage, slot, sizeof(double) * (size_t)n * (TW_COLS + 1), hipMemcpyHostToDevice, st));
+    // the kernel reads the pinned slot itself (mapped host memory; <= 3.8 KB): no copy command in the frame's chain.  The slot is the
+    // host's again once that kernel has run -- the event behind it is what the next use of the slot waits for.
+    hipLaunchKernelGGL(trackwin_append_kernel, dim3(n), dim3(64), 0, st, slot, n, w->rows, w->count, w->window);
+    ODAM_HIP(hipGetLastError());
     ODAM_HIP(hipEventRecord(w->copied[si], st));
     w->copied_armed[si] = true;
-    hipLaunchKernelGGL(trackwin_append_kernel, dim3(n), dim3(64), 0, st, w->d_stage, n, w->rows, w->count, w->window);
-    ODAM_HIP(hipGetLastError());
     for (int i = 0; i < n; i++) {
         const size_t t = (size_t)track_ids[i];
         if (t > w->sums.size()) w->sums_ok = false;        // a gap in the ids: no sums for the skipped tracks
@@ -1501,10 +1502,11 @@ extern "C" int odam_trackwin_build_tracks(odam_trackwin* w, struct odam_sq_ctx* 
     if (w->params_armed[si]) ODAM_HIP(hipEventSynchronize(w->params_copied[si]));
     float* hp = w->h_params + (size_t)si * w->max_tracks * 9;
     if (int rc = odam_trackwin_params(w, T, hp)) return rc;
-    ODAM_HIP(hipMemcpyAsync(w->d_params, hp, sizeof(float) * (size_t)T * 9, hipMemcpyHostToDevice, st));
+    // the surface kernel reads the pinned rows itself (mapped host memory, 36 bytes per track): no copy command; the slot is free
+    // again when the launches that read it have run
+    if (int rc = odam_sq_project_extents(sq, T, hp, T_cw12_K9, w->d_proj, stream)) return rc;
     ODAM_HIP(hipEventRecord(w->params_copied[si], st));
     w->params_armed[si] = true;
-    if (int rc = odam_sq_project_extents(sq, T, w->d_params, T_cw12_K9, w->d_proj, stream)) return rc;
     Cam15 cam;
     for (int i = 0; i < 12; i++) cam.v[i] = T_cw12_K9[i];
     cam.v[12] = cam_azi; cam.v[13] = img_w; cam.v[14] = img_h;
