@@ -245,29 +245,48 @@ class Associator:
         if n_tracks > self.max_tracks:
             self._grow(n_tracks)
         tr = tracks.to(dev, torch.float32).contiguous()
-        de = detections.to(dev, torch.float32).reshape(79, 30).contiguous()
-        Z = torch.empty(n_tracks + 1, n_det + 1, device=dev, dtype=torch.float32)
+        _pinned = getattr(self, "_pin_mode", False) and (not detections.is_cuda) and detections.dtype == torch.float32
+        if _pinned:
+            # (inside assignment_checked only.)  The kernels read the detections from, and write Z to, pinned host memory themselves --
+            # no copy command either way; this call then waits for the stream itself, so what it returns is valid host data and the
+            # two buffers are free for the next frame
+            if getattr(self, "_pin", None) is None:
+                self._pin = (torch.empty(79 * 30, dtype=torch.float32).pin_memory(), torch.empty((self.MAX_TRACKS + 1) * 31, dtype=torch.float32).pin_memory())
+            de = self._pin[0].view(79, 30)
+            de.copy_(detections.reshape(79, 30))
+            Z = self._pin[1][:(n_tracks + 1) * (n_det + 1)].view(n_tracks + 1, n_det + 1)
+        else:
+            de = detections.to(dev, torch.float32).reshape(79, 30).contiguous()
+            Z = torch.empty(n_tracks + 1, n_det + 1, device=dev, dtype=torch.float32)
         L = _lib.lib()
         fn, what = (L.odam_assoc_forward_sequence, "odam_assoc_forward_sequence") if sequence else (L.odam_assoc_forward, "odam_assoc_forward")
         with torch.cuda.device(dev):
             _lib.check(fn(self._handle(), _lib.ptr(tr), ctypes.c_int(n_tracks), _lib.ptr(de), ctypes.c_int(n_det), _lib.ptr(Z),
                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), what)
+        if _pinned:
+            torch.cuda.current_stream(dev).synchronize()
         return Z
 
     def assignment_checked(self, tracks, detections, n_tracks, n_det):
         """assignment() + synchronisation + the lost-launch check: if the persistent matching kernel could not get all its
         workgroups resident within the barrier bound (a foreign kernel held the CUs), this frame is run again through the
         launch sequence in the same process and counted in self.lost_launches.  The reference cannot fail this way
-        (associator.py:202-268), so neither may the drop-in."""
-        Z = self.assignment(tracks, detections, n_tracks, n_det)
-        torch.cuda.current_stream(self.device).synchronize()
-        n = ctypes.c_uint(0)
-        _lib.check(_lib.lib().odam_assoc_lost_launches(self._handle(), ctypes.byref(n)), "odam_assoc_lost_launches")
-        if n.value != self._lost_seen:
-            self._lost_seen = n.value
-            self.lost_launches += 1
-            Z = self.assignment(tracks, detections, n_tracks, n_det, sequence=True)
-        return Z
+        (associator.py:202-268), so neither may the drop-in.  Returns Z on the host when the detections came from the host (the
+        kernels then read them from, and write Z to, pinned memory: no copy commands), on the device otherwise."""
+        self._pin_mode = True
+        try:
+            Z = self.assignment(tracks, detections, n_tracks, n_det)
+            torch.cuda.current_stream(self.device).synchronize()
+            n = ctypes.c_uint(0)
+            _lib.check(_lib.lib().odam_assoc_lost_launches(self._handle(), ctypes.byref(n)), "odam_assoc_lost_launches")
+            if n.value != self._lost_seen:
+                self._lost_seen = n.value
+                self.lost_launches += 1
+                Z = self.assignment(tracks, detections, n_tracks, n_det, sequence=True)
+                torch.cuda.current_stream(self.device).synchronize()
+        finally:
+            self._pin_mode = False
+        return Z if Z.is_cuda else Z.clone()      # (the pinned buffer is the next frame's)
 
     def __call__(self, in_data, threshold, eval_only=False, device="cuda"):
         """Associator.forward for the batch-of-one call of OdamProcess (associator.py:202-268, eval_only=True)"""
