@@ -54,8 +54,14 @@ __global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ 
 }
 
 // F.avg_pool1d over the L time steps of each track: out[s, c] = mean_l cat[(s*L + l), c]   (associator.py:231-232)
-__global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ cat, int L, float* __restrict__ out) {
+// ... and blocks T .. T + n_tail - 1 move the rows that follow the n_seq sequences in `cat` (the encoded detections, which went through
+// the encoder launches as 30 more rows of the same matrix) behind the means: out becomes the [T + 30] row block of the matching GNN
+__global__ __launch_bounds__(256) void time_mean_kernel(const float* __restrict__ cat, int L, float* __restrict__ out, int n_seq) {
     const int s = blockIdx.x, c = threadIdx.x;
+    if (s >= n_seq) {
+        out[(size_t)s * 512 + c] = cat[((size_t)n_seq * L + (s - n_seq)) * 512 + c];
+        return;
+    }
     const float* p = cat + (size_t)s * L * 512 + c;
     float acc = 0.0f;
     int l = 0;
@@ -1015,7 +1021,7 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
         m->gnn.push_back(P);
     }
     const size_t T = m->max_tracks, N = T * NT;
-    RC(m->alloc(&m->feat, N * FPAD)); RC(m->alloc(&m->h256, N * D)); RC(m->alloc(&m->catT, N * 512));
+    RC(m->alloc(&m->feat, (N + ND) * FPAD)); RC(m->alloc(&m->h256, (N + ND) * D)); RC(m->alloc(&m->catT, (N + ND) * 512));      // + the 30 detection rows behind the tracks'
     RC(m->alloc(&m->kv, N * 768)); RC(m->alloc(&m->att, N * D)); RC(m->alloc(&m->h512, N * 512));
     // fused tracks [T] and the 30 detection slots share one row block (detections start at row T of the frame) so the
     // shared-weight GNN layers see both sets as ONE matrix
@@ -1067,20 +1073,19 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
     float* X = m->catTr;                      // [T + 30][512]: fused tracks, then the detection slots
     float* XD = X + (size_t)T * 512;
     const int MX = T + ND;
-    hipLaunchKernelGGL(prepare_kernel, dim3(ND), dim3(256), 0, st, detections, ND, ND, m->div_term, m->featD, XD);
-    ODAM_HIP(hipGetLastError());
-    // (the detections' branch -- these three launches on 30 rows -- on a second stream beside the tracks' branch, forked and joined by
-    //  events: measured, no change of the loop's 0.79-0.81 ms per frame; not kept)
-    RC(lin(m->enc0, m->featD, FPAD, ND, nullptr, true, m->h256, D, nullptr, st));
-    RC(lin(m->enc2, m->h256, D, ND, XD, false, XD, 512, nullptr, st));
+    // The detections go through the encoder as 30 more rows of the tracks' matrix (rows N .. N + 29 of feat / catT: same weights, rows are
+    // independent, and the same tile shape serves 30 and 100 T + 30 rows -- one launch per layer instead of two); time_mean_kernel moves
+    // their encodings behind the track means afterwards.
+    // (the same three launches on a second stream beside the tracks' branch, forked and joined by events: measured, no change; not kept)
+    hipLaunchKernelGGL(prepare_kernel, dim3(ND), dim3(256), 0, st, detections, ND, ND, m->div_term, m->feat + (size_t)N * FPAD, m->catT + (size_t)N * 512);
     hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
     ODAM_HIP(hipGetLastError());
-    RC(lin(m->enc0, m->feat, FPAD, N, nullptr, true, m->h256, D, nullptr, st));
-    RC(lin(m->enc2, m->h256, D, N, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
+    RC(lin(m->enc0, m->feat, FPAD, N + ND, nullptr, true, m->h256, D, nullptr, st));
+    RC(lin(m->enc2, m->h256, D, N + ND, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
     // fuser: self-attention over each track's 100 time steps (associator.py:143-160, 230)
     for (const Prop& P : m->fuser)
         RC(prop_forward_self(P, m->catT, N, T, NT, m->kv, m->att, m->h512, st));
-    hipLaunchKernelGGL(time_mean_kernel, dim3(T), dim3(256), 0, st, m->catT, NT, X);
+    hipLaunchKernelGGL(time_mean_kernel, dim3(T + ND), dim3(256), 0, st, m->catT, NT, X, T);
     ODAM_HIP(hipGetLastError());
     // matching GNN between the fused tracks [T] and all 30 detection slots (associator.py:111-139, 240).  Both sets
     // go through the same weights, so every projection / MLP runs once on the [T + 30] row block; only the attention
