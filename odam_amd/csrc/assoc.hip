@@ -39,12 +39,16 @@ struct HostT { std::vector<long long> shape; std::vector<float> data; };
 // ---- kernels ------------------------------------------------------------------------------------------------------
 // in [n_seq, 79, L] channel-first (row 0 = frame index, rows 1..78 features) ->
 // feat [n_seq*L, 128] (features, zero padded) and cat[:, 0:256] = sine encoding of the frame index
+// A second input (in2: n_tok2 tokens of sequences of length L2) continues the token rows behind the first: tracks and detections in
+// one launch.
 __global__ __launch_bounds__(256) void prepare_kernel(const float* __restrict__ in, int L, int n_tok,
                                                       const float* __restrict__ div_term, float* __restrict__ feat,
-                                                      float* __restrict__ cat) {
+                                                      float* __restrict__ cat, const float* __restrict__ in2 = nullptr, int L2 = 1, int n_tok2 = 0) {
     const int tok = blockIdx.x;
-    if (tok >= n_tok) return;
-    const int s = tok / L, l = tok - s * L;
+    if (tok >= n_tok + n_tok2) return;
+    if (tok >= n_tok) { in = in2; L = L2; }
+    const int t = tok >= n_tok ? tok - n_tok : tok;
+    const int s = t / L, l = t - s * L;
     const float* src = in + (size_t)s * NF * L + l;
     const int c = threadIdx.x;
     if (c < FPAD) feat[(size_t)tok * FPAD + c] = (c < NF - 1) ? src[(size_t)(c + 1) * L] : 0.0f;
@@ -1077,8 +1081,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
     // independent, and the same tile shape serves 30 and 100 T + 30 rows -- one launch per layer instead of two); time_mean_kernel moves
     // their encodings behind the track means afterwards.
     // (the same three launches on a second stream beside the tracks' branch, forked and joined by events: measured, no change; not kept)
-    hipLaunchKernelGGL(prepare_kernel, dim3(ND), dim3(256), 0, st, detections, ND, ND, m->div_term, m->feat + (size_t)N * FPAD, m->catT + (size_t)N * 512);
-    hipLaunchKernelGGL(prepare_kernel, dim3(N), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT);
+    hipLaunchKernelGGL(prepare_kernel, dim3(N + ND), dim3(256), 0, st, tracks, NT, N, m->div_term, m->feat, m->catT, detections, ND, ND);
     ODAM_HIP(hipGetLastError());
     RC(lin(m->enc0, m->feat, FPAD, N + ND, nullptr, true, m->h256, D, nullptr, st));
     RC(lin(m->enc2, m->h256, D, N + ND, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
