@@ -27,9 +27,13 @@ int odam_assoc_finalize(odam_assoc* m);
 
 /* tracks [dev][T,79,100] and detections [dev][79,30] in the associator's input layout (channel 0 = frame index,
  * -1 padding; processor.py:49-68, 155-179); Z_out [dev][(T+1),(n_det+1)] = log assignment incl. dustbins.
- * Stream-ordered, no host synchronisation.  The encoder and the per-track fuser layers are launches on 100 T rows; the
- * matching GNN layers and the final projection run as ONE persistent launch (256 workgroups, device-wide barriers between
- * the stages, exchanged buffers coherent through sc1 accesses), then the score matrix and the Sinkhorn kernel.
+ * tracks, detections and Z_out may also be mapped pinned HOST memory (the kernels then read / write it themselves: no copy
+ * commands; what odam_amd.associator does inside its checked call).
+ * Stream-ordered, no host synchronisation.  The encoder and the per-track fuser layers are launches on 100 T + 30 rows; the
+ * matching GNN layers and the final projection run as ONE persistent launch of 256 workgroups -- by default with the rows dealt
+ * to the 8 XCDs: one device-wide barrier per layer (q | k | v exchanged through sc1 accesses), the row-wise stages behind
+ * XCD-local barriers (assoc.persist = 2); assoc.persist = 1: five device-wide barriers per layer, bit-identical results --,
+ * then the score matrix and the Sinkhorn kernel.
  * The persistent launch is used only when the runtime says all its workgroups can be resident at once on this device
  * (odam_assoc_info; never under a CU mask); the odam_config key assoc.persist = 0 (read when a handle is finalised) or
  * odam_assoc_set_persistent(m, 0) per handle issue the matching layers as separate launches instead.  The library reads no
