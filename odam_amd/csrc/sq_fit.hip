@@ -565,9 +565,11 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             float* xl = want_loss ? A.xloss + slot * (size_t)A.max_views * 4 : nullptr;
             const unsigned long long tag = (unsigned long long)(it + 1) << 32;
             if (wid == wj) {
+                // (the partners of an object share an XCD -- see the workgroup-id mapping above --, so the root only has to reach that XCD's
+                //  L2: a workgroup-scope store, read back below by loads that miss the vector L1 (sc0 sc1); tests/native/xcd_barrier_probe.hip)
                 if (lane < 9)
                     __hip_atomic_store(&xq[wj * 9 + lane], tag | (unsigned long long)__float_as_uint(L.xroot[wj * 9 + lane]),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (want_loss) {
                     for (int m = lane; m * keff + wj < F; m += 64) {
                         const int f = m * keff + wj;
@@ -582,8 +584,13 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                 const int jj = wid;
                 unsigned long long v = 0;
                 bool ok = lane >= 9;
+                auto peek = [&](const unsigned long long* q) {
+                    unsigned long long r;
+                    asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(q) : "memory");
+                    return r;
+                };
                 if (!ok) {
-                    v = __hip_atomic_load(&xq[jj * 9 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    v = peek(&xq[jj * 9 + lane]);
                     ok = (v >> 32) == (unsigned long long)(it + 1);
                 }
                 int ready = __all(ok);
@@ -592,7 +599,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                     while (!ready && wall_clock64() - t0 < A.split_wait_ticks) {
                         __builtin_amdgcn_s_sleep(1);
                         if (lane < 9 && !ok) {
-                            v = __hip_atomic_load(&xq[jj * 9 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v = peek(&xq[jj * 9 + lane]);
                             ok = (v >> 32) == (unsigned long long)(it + 1);
                         }
                         ready = __all(ok);
