@@ -1029,7 +1029,7 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
     RC(m->alloc(&m->kv, N * 768)); RC(m->alloc(&m->att, N * D)); RC(m->alloc(&m->h512, N * 512));
     // fused tracks [T] and the 30 detection slots share one row block (detections start at row T of the frame) so the
     // shared-weight GNN layers see both sets as ONE matrix
-    RC(m->alloc(&m->catTr, (T + ND) * 512)); RC(m->alloc(&m->featD, ND * FPAD));
+    RC(m->alloc(&m->catTr, (T + ND) * 512)); RC(m->alloc(&m->featD, ND * FPAD));      // (featD: unused since the detections ride in feat's last 30 rows)
     RC(m->alloc(&m->kvX, (T + ND) * 768)); RC(m->alloc(&m->kvX2, (T + ND) * 768)); RC(m->alloc(&m->attX, (T + ND) * D));
     RC(m->alloc(&m->hX, (T + ND) * 512));
     RC(m->alloc(&m->mT, (T + ND + 2) * D)); RC(m->alloc(&m->scores, T * 32));   // the score block reads 32 detection rows
@@ -1203,7 +1203,7 @@ struct odam_trackwin {
     double* rows = nullptr;     // [max_tracks][window][14]: frame id, class, bbox px x4, dims x3, t_wo x3, az_wo, score
     int* count = nullptr;       // [max_tracks] observations appended so far
     double* stage = nullptr;    // pinned [8][32][14 + 1]: rows + track id of one append
-    double* d_stage = nullptr;  // device copy of one slot
+    double* d_stage = nullptr;  // (unused since the append kernel reads the pinned slot itself; still allocated)
     double* d_cam = nullptr;    // [16] (unused since the camera travels in the kernel arguments; kept so the handle layout of create / destroy stays as tested)
     double* h_load = nullptr;   // pinned [max_tracks][window][14]: what odam_trackwin_load's kernel reads (mapped host memory; allocated once -- the
     int* h_load_meta = nullptr; // load path has no allocation, no hipFree (it waits for every stream of the device) and no copy command)
@@ -1216,7 +1216,7 @@ struct odam_trackwin {
     std::vector<Sums> sums;
     bool sums_ok = true;        // false once an append skipped ids or a load came without the full columns
     float* h_params = nullptr;  // pinned [8][max_tracks][9]
-    float* d_params = nullptr;  // [max_tracks][9]
+    float* d_params = nullptr;  // [max_tracks][9] (unused since the surface kernel reads the pinned rows itself; still allocated)
     double* d_proj = nullptr;   // [max_tracks][4]
     hipEvent_t params_copied[8] = {};
     bool params_armed[8] = {};
