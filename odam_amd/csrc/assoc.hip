@@ -1074,8 +1074,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
                            float* Z_out, hipStream_t st, bool allow_persist = true) {
     const int N = T * NT;
     // encoder + frame-index encoding (associator.py:222-229)
-    float* X = m->catTr;                      // [T + 30][512]: fused tracks, then the detection slots
-    float* XD = X + (size_t)T * 512;
+    float* X = m->catTr;                      // [T + 30][512]: fused tracks, then the detection slots (rows T ..)
     const int MX = T + ND;
     // The detections go through the encoder as 30 more rows of the tracks' matrix (rows N .. N + 29 of feat / catT: same weights, rows are
     // independent, and the same tile shape serves 30 and 100 T + 30 rows -- one launch per layer instead of two); time_mean_kernel moves
