@@ -5,3 +5,5 @@ python3 $R/tests/native/perf_sinkhorn.py 2>/dev/null > $O/r4_sinkhorn_alone.txt
 python3 $R/tests/native/perf_assoc_phases.py 2>/dev/null > $O/r4_assoc_phases.txt
 python3 $R/tests/native/perf_assoc_loop.py 2>/dev/null | head -30 > $O/r4_perf_assoc_loop.txt
 bash $R/tests/native/prof_assoc.sh > $O/r4_assoc_kernels.txt 2>&1
+python3 $R/tests/native/cmp_gnn_variants.py 2>/dev/null > $O/r4_gnn_variants.txt
+python3 $R/tests/native/soak_assoc.py 300 40 2>/dev/null | tail -1 > $O/r4_soak_assoc_line.txt
