@@ -36,6 +36,10 @@ PEAK_BF16_MFMA = 2.5e15          # MI355X_MICROARCH.md, dense v_mfma_f32_32x32x1
 # fp32 layers large enough for the 256-row kernel are multiplied on the bf16 matrix instruction through an exact
 # three-way split of both operands, six MFMAs per 16 k: the matrix peak for fp32 work in that mode
 PEAK_F32_SPLIT = PEAK_BF16_MFMA / 6
+# what the split loop's own instruction mix reaches in a bare kernel on this chip (six v_mfma_f32_16x16x32_bf16 per block, every
+# operand re-read from LDS, random data, every CU busy): tests/native/mfma_shape_probe.hip, profiles/r3_mfma_shape_probe.txt
+# ("shape 16": 334-337 TFLOP/s of fp32 work at the 2.05 GHz the chip holds under that load).  Quoted NEXT TO `frac`, never instead.
+INKERNEL_CEILING_F32_SPLIT = 334e12
 # PMC figures cannot be read from inside this process: they come from profiles/pmc_summary.json, which
 # tests/native/sum_pmc.py regenerates from the rocprofv3 --pmc passes of tests/native/run_pmc.sh (separate FETCH_SIZE /
 # WRITE_SIZE / SQ passes; the gfx950 x2 correction of FETCH_SIZE is applied there).  Missing or stale file -> null.
@@ -114,6 +118,8 @@ def main():
     ap.add_argument("--no-full-chain", dest="full_chain", action="store_false")
     ap.add_argument("--chain-frames", type=int, default=0, help="frames of the --full-chain block (0 = --frames)")
     ap.add_argument("--chain-chunk", type=int, default=0, help="frames per all-gather of the --full-chain block (0 = the whole scene)")
+    ap.add_argument("--chain-overlap", default="auto", choices=["auto", "on", "off"], help="--full-chain block: association of chunk i under the "
+                    "detection + gather of chunk i + 1 (pipeline.run_scene overlap; auto = on for more than one rank and more than one chunk)")
     ap.add_argument("--dump-chain", default="", help="every rank r writes tracks, fits and merge result of the --full-chain block to <path>.r<r>.npz")
     ap.add_argument("--only-chain", action="store_true", help="run nothing but the --full-chain block (tests)")
     args = ap.parse_args()
@@ -309,6 +315,11 @@ def main():
         peak = PEAK_F32_SPLIT if split_mode else PEAK_FP32_MFMA
         result["roofline"] = {"bound": "mfma", "achieved": ach / 1e12, "peak": peak / 1e12,
                               "unit": "TFLOP/s", "frac": ach / peak,
+                              "frac_vs_inkernel_ceiling": (ach / INKERNEL_CEILING_F32_SPLIT) if split_mode else None,
+                              "inkernel_ceiling": ({"value": INKERNEL_CEILING_F32_SPLIT / 1e12, "unit": "TFLOP/s",
+                                                    "source": "profiles/r3_mfma_shape_probe.txt (tests/native/mfma_shape_probe.hip: the split loop's "
+                                                              "instruction mix alone, operands from LDS, random data; the chip holds 2.05 GHz under it)"}
+                                                   if split_mode else None),
                               "peak_note": ("dense bf16 MFMA peak / 6 (six bf16 MFMAs per fp32 product block); for scale: the fp32 "
                                             "matrix instruction's peak is 157.3, i.e. achieved / 157.3 = %.2f" % (ach / PEAK_FP32_MFMA))
                               if split_mode else "v_mfma_f32_32x32x2_f32",
@@ -394,12 +405,18 @@ def main():
         detector.close()
         torch.cuda.empty_cache()
         result["config4"] = config4_block(device, args, pmc)
-    if rank == 0 and ws == 1 and not args.no_cpu_baseline:
+    elif rank == 0 and not args.no_config4:
+        result["config4"] = {"absent": "BASELINE configs[3] (DETR-R101, 800x600, 50 objects, bf16) is a ONE-GPU configuration: its block is "
+                                       "measured by the N = 1 line only (python bench.py --gpus 1)"}
+    if ws > 1 or args.force_collectives:
+        torch.distributed.destroy_process_group()       # the other ranks are done; the CPU baseline below is rank 0's alone
+    if rank == 0 and not args.no_cpu_baseline:
+        # every line carries it, the N > 1 lines too: rank 0, after the last collective, on the host cores of this box
+        if ws > 1:
+            torch.set_num_threads(max(1, min(16, os.cpu_count() or 16)))
         result["cpu_baseline"] = cpu_baseline(scene, tracks, N)
     if rank == 0:
         print(json.dumps(result))
-    if ws > 1 or args.force_collectives:
-        torch.distributed.destroy_process_group()
 
 
 def secondary_blocks(step, detector, chunk, frames, tracks, N, per_frame, scene, device, ms_step_s, det_phase_ms_step):
@@ -445,7 +462,7 @@ def secondary_blocks(step, detector, chunk, frames, tracks, N, per_frame, scene,
 def full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, ws):
     """The chain a user of the reference runs (run_processor.py:70-83) on this job's ranks, through odam_amd.pipeline.run_scene:
     every rank detects its frames, the detections are all-gathered, the sequential association loop (processor.py:306-345) is
-    replayed on every rank with the hand-written scene association weights (tests/scene_weights.py), the tracks THAT COME OUT are
+    replayed on every rank with the hand-written scene association weights (tools/scene_weights.py), the tracks THAT COME OUT are
     dealt over the ranks and fitted, gathered, merged (run_merge.py:79-130) and fitted again.  Timed once after one untimed pass
     over the first frames (handles, first tracks).  Not the headline metric: it contains the replicated association loop."""
     from odam_amd import pipeline
@@ -471,13 +488,15 @@ def full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, 
     if ws > 1:
         torch.distributed.barrier()
     s0 = time.perf_counter()
+    ov = {"auto": None, "on": True, "off": False}[args.chain_overlap]
     out = pipeline.run_scene(proc, n, ids, T, detect=detect, chunk=args.chain_chunk, device=coll_dev, force=args.force_collectives,
-                             stages=stages)
+                             stages=stages, overlap=ov)
     torch.cuda.synchronize()
     if ws > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - s0
     first = stages.pop("first_pass")
+    overlapped = bool(stages.pop("overlapped", False))
     if args.dump_chain:
         cat = lambda ts: np.concatenate([np.asarray(t).reshape(-1, 82) for t in ts]) if len(ts) else np.zeros((0, 82))
         np.savez(f"{args.dump_chain}.r{rank}.npz", tracks=cat(proc.tracks), track_len=[len(t) for t in proc.tracks],
@@ -489,14 +508,33 @@ def full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, 
            "tracks": len(proc.tracks), "objects_after_merge": len(out["tracks"]),
            "fitted_pass1": int(np.sum(first["fitted"])), "fitted_pass2": int(np.sum(out["fitted"])),
            "chunk_frames": args.chain_chunk or n, "lost_persistent_launches": net.lost_launches,
+           "association_overlapped_with_detection": overlapped,
            "note": "odam_amd.pipeline.run_scene: detect (sharded) -> all-gather -> association replayed on every rank -> fit of the "
                    "resulting tracks (sharded) -> all-gather -> merge -> fit (sharded) -> all-gather; wall clock of rank 0 between barriers"}
+    if not args.only_chain and not args.chain_chunk and args.chain_overlap == "auto":
+        # the same chain in chunks of 4 batches, association of chunk i under detection + gather of chunk i + 1 (pipeline.run_scene
+        # overlap=True) and, for comparison, the same chunks one after the other: what chunking + overlap buy on THIS number of ranks
+        ck = 4 * args.batch * max(ws, 1)
+        for key, flag in (("chunked", False), ("chunked_overlapped", True)):
+            proc.init_sequence(synth.K_SCANNET, synth.IMG_H, synth.IMG_W)
+            st2 = {}
+            torch.cuda.synchronize()
+            if ws > 1:
+                torch.distributed.barrier()
+            s0 = time.perf_counter()
+            pipeline.run_scene(proc, n, ids, T, detect=detect, chunk=ck, device=coll_dev, force=args.force_collectives, stages=st2, overlap=flag)
+            torch.cuda.synchronize()
+            if ws > 1:
+                torch.distributed.barrier()
+            d2 = time.perf_counter() - s0
+            st2.pop("first_pass"); st2.pop("overlapped", None)
+            res[key] = {"value": n / d2, "unit": "frames/s", "ms": 1e3 * d2, "chunk_frames": ck, "stages_ms": {k: 1e3 * v for k, v in st2.items()}}
     net.close()
     return res
 
 
 def _new_process(device, tracks_cap=128, fit_iters=1):
-    sys.path.insert(0, os.path.join(REPO, "tests"))
+    sys.path.insert(0, os.path.join(REPO, "tools"))
     import scene_weights
     from odam_amd import associator
     from odam_amd.processor import OdamProcess
@@ -515,7 +553,7 @@ def _new_process(device, tracks_cap=128, fit_iters=1):
 def association_block(per_frame, scene, device, N, ms_step_s, n_sample=200):
     """OdamProcess.process_frame (track preparation -> association network + Sinkhorn on the device -> Hungarian step ->
     attach) over the first n_sample frames' detections of this scene, with the hand-written scene association weights of
-    the whole-chain fixture (tests/scene_weights.py).  Sequential over frames and replicated on every rank."""
+    the whole-chain fixture (tools/scene_weights.py).  Sequential over frames and replicated on every rank."""
     proc, net = _new_process(device)
     n = min(n_sample, len(per_frame))
     ids, T = scene["img_names"], scene["T_wcs"]

@@ -60,6 +60,10 @@ int odam_assoc_info(odam_assoc* m, int* persistent, int* resident_capacity, int*
 /* bound of one barrier wait in microseconds (default 20000); 0 abandons every persistent launch at its first barrier
  * (tests of the fallback path) */
 int odam_assoc_set_barrier_timeout_us(odam_assoc* m, long long us);
+/* tests: with on != 0 the row-partitioned matching kernel (odam_config assoc.persist = 2) treats its workgroup placement as wrong
+ * -- the check it makes on every launch (the 32 workgroups of a group must run behind one L2: hardware XCC id compared inside the
+ * group) -- so the launch is abandoned, counted in odam_assoc_lost_launches and the frame re-run through the launch sequence */
+int odam_assoc_debug_misplace(odam_assoc* m, int on);
 
 /* ---- device-resident track windows: the device side of OdamProcess._preprocess_tracks (src/processor.py:133-170) ----
  * The observations of every live track stay on the device in the world frame (14 float64 each: frame id, class, bbox px x4,

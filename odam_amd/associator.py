@@ -230,7 +230,7 @@ class Associator:
     def set_persistent(self, on):
         """matching GNN as one persistent launch (the default where the device can hold its 256 workgroups at once) or as the launch
         sequence.  A caller that runs the association on a stream restricted to a share of the compute units
-        (odam_amd.streams.cu_masked_stream) must switch the persistent launch off: its workgroups wait for each other and would
+        (hipExtStreamCreateWithCUMask; tests/native/cumask_probe.hip) should switch the persistent launch off: its workgroups wait for each other and would
         never all become resident (the bounded wait would abandon every launch and re-run it through the sequence)."""
         _lib.check(_lib.lib().odam_assoc_set_persistent(self._handle(), ctypes.c_int(1 if on else 0)), "odam_assoc_set_persistent")
 
@@ -282,8 +282,16 @@ class Associator:
             if n.value != self._lost_seen:
                 self._lost_seen = n.value
                 self.lost_launches += 1
+                self._lost_in_a_row = getattr(self, "_lost_in_a_row", 0) + 1
                 Z = self.assignment(tracks, detections, n_tracks, n_det, sequence=True)
                 torch.cuda.current_stream(self.device).synchronize()
+                if self._lost_in_a_row >= 3:
+                    # three abandoned launches in a row are not a busy device but a condition that will not pass (the row-partitioned
+                    # kernel's placement check, a stream confined to a share of the compute units): stay on the launch sequence
+                    self.set_persistent(False)
+                    self.persistent_given_up = True
+            else:
+                self._lost_in_a_row = 0
         finally:
             self._pin_mode = False
         return Z if Z.is_cuda else Z.clone()      # (the pinned buffer is the next frame's)

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(SK_NT) void sinkhorn_kernel(const float* __restrict
 // Barrier: two levels -- 8 group counters (workgroup id % 8; 32 arrivals each on its own line), the last arrival of a group
 // bumps the global generation every workgroup polls; the spin is bounded so a lost workgroup cannot hang the device.
 constexpr int PG_WG = 256, PG_NT = 256, PG_NW = PG_NT / 64, PG_MAXL = 16, PG_GROUPS = 8;
-constexpr int PG_BAR_WORDS = 32 * (1 + 2 * PG_GROUPS);     // generation + flag line, 8 group counters, 8 per-XCD counters (each on its own 128-byte line)
+constexpr int PG_BAR_WORDS = 32 * (2 + 2 * PG_GROUPS);     // generation + flag line, 8 group counters, 8 per-XCD counters (each on its own 128-byte line),
+                                                           // one line of 8 placement words (gnn_rowpart_kernel: XCC id + 1 of each group)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GnnLayerW { const float *qkv_w, *qkv_b, *mg_w, *mg_b, *m0_w, *m0_b, *m2_w, *m2_b; int cross; };
@@ -177,6 +178,7 @@ struct GnnArgs {
     unsigned* bar;                    // [0] generation, [1] error flag (a barrier timed out), [32 (1 + g)] group counters; zeroed before every launch
     unsigned long long timeout_ticks; // bound of one barrier wait in 100 MHz ticks (0: give up at the first barrier -- tests)
     unsigned long long* stamps;       // diagnostics (odam_assoc_stage_stamps): 100 MHz timer of workgroup 0 after every stage, or null
+    int fake_misplaced;               // tests (odam_assoc_debug_misplace): gnn_rowpart_kernel's placement check behaves as if a group straddled XCDs
 };
 
 constexpr int SC1 = 16;      // cache-policy bit of the buffer intrinsics on gfx94x / gfx950
@@ -518,6 +520,19 @@ __global__ __launch_bounds__(PG_NT) void gnn_rowpart_kernel(GnnArgs a) {
     auto stamp = [&] { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[n_stamp++] = wall_clock64(); };
 #define PG_BARRIER() do { if (!grid_barrier(a.bar, target, a.timeout_ticks, &lost)) return; stamp(); } while (0)
 #define PX_BARRIER() do { if (!xcd_barrier(a.bar, cnt_x, target_x, a.timeout_ticks, &lost)) return; stamp(); } while (0)
+    // Placement check.  The XCD-local stages below are exchanged with plain stores and a workgroup-scope counter, which is right only
+    // if the 32 workgroups of a group (equal blockIdx mod 8) run behind ONE L2.  That is how the dispatcher has always placed a plain
+    // launch here (tests/native/xcd_probe.hip), but HIP promises nothing: every workgroup reads the hardware's XCC id and the first of a
+    // group to arrive records it; one that finds another id raises the launch's error flag -- every workgroup then returns at its
+    // first barrier, the Sinkhorn kernel reports the launch as lost and the host re-runs the frame through the launch sequence
+    // (and, after three such losses in a row, stays on it: associator.py).
+    if (tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) + 1u;       // HW_REG_XCC_ID [3:0], + 1: 0 = nobody yet
+        unsigned seen = 0u;
+        if (!__hip_atomic_compare_exchange_strong(a.bar + 32 * (1 + 2 * PG_GROUPS) + xcd, &seen, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+            (seen != xcc || a.fake_misplaced))
+            __hip_atomic_store(a.bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     stamp();
     float* sc = scs + wave * 64;
     for (int l = 0; l < a.n_layers; l++) {
@@ -801,10 +816,11 @@ __global__ __launch_bounds__(64) void sinkhorn_wave_kernel(const float* __restri
     if (lane == 0 && lost && lost_count) __hip_atomic_fetch_add(lost_count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     // err = the persistent matching kernel's flag word (bar + 1): that launch is over (stream order) and its flag has been read
     // above -- leave generation, flag, the group counters and the per-XCD counters at zero for the next launch (saves a memset per frame)
-    if (err && lane <= 2 * PG_GROUPS) {
+    if (err && lane <= 2 * PG_GROUPS + PG_GROUPS) {
         unsigned* bar = const_cast<unsigned*>(err) - 1;
         if (lane == 0) { bar[0] = 0u; bar[1] = 0u; }
-        else bar[32 * lane] = 0u;
+        else if (lane <= 2 * PG_GROUPS) bar[32 * lane] = 0u;
+        else bar[32 * (1 + 2 * PG_GROUPS) + (lane - 2 * PG_GROUPS - 1)] = 0u;      // the placement words of gnn_rowpart_kernel
     }
 }
 
@@ -867,6 +883,7 @@ struct odam_assoc {
     unsigned* lost_count = nullptr;          // pinned host word: launches abandoned at a barrier so far (the Sinkhorn kernel bumps it)
     unsigned long long* stamps = nullptr;    // device, 128 entries; written only while want_stamps
     bool want_stamps = false;
+    bool fake_misplaced = false;             // tests: odam_assoc_debug_misplace
     bool bar_clean = false;                  // the counters are zero: the one-wavefront Sinkhorn kernel zeroes them behind the launch that used them
 
     // Zeroing goes through a private non-blocking stream that finalize waits for: hipMemset would be ordered on the NULL stream -- it
@@ -1105,6 +1122,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         g.T = T;
         g.bar = m->bar; g.timeout_ticks = m->timeout_ticks;
         g.stamps = m->want_stamps ? m->stamps : nullptr;
+        g.fake_misplaced = m->fake_misplaced ? 1 : 0;
         // counters and the error flag start from zero every launch: zeroed here, unless the Sinkhorn kernel behind the previous launch did it
         if (!m->bar_clean) ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * PG_BAR_WORDS, st));
         m->bar_clean = false;
@@ -1182,6 +1200,12 @@ extern "C" int odam_assoc_info(odam_assoc* m, int* persistent, int* resident_cap
     if (persistent) *persistent = m->persist ? 1 : 0;
     if (resident_capacity) *resident_capacity = m->resident_capacity;
     if (workgroups) *workgroups = PG_WG;
+    return 0;
+}
+
+extern "C" int odam_assoc_debug_misplace(odam_assoc* m, int on) {
+    if (!m) return odam_fail(1, "odam_assoc_debug_misplace: null handle");
+    m->fake_misplaced = on != 0;
     return 0;
 }
 

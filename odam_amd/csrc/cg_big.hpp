@@ -103,6 +103,13 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     const int wm = wave / WN, wn = wave % WN;
     const int tiles_n = (a.Cout + BN - 1) / BN;
     int bid = blockIdx.x;
+#if CG_STAMP
+    const unsigned long long st_entry = __builtin_readcyclecounter();      // g_stamps[6]: entry -> main loop, [7]: main loop's end -> last store issued
+#endif
+    if (a.stagger > 0 && bid < 256 && ((bid >> 3) & 1)) {      // cg.stagger: every other CU of an XCD starts its first tile late
+        const unsigned long long t0 = __builtin_readcyclecounter(), dt = (unsigned long long)a.stagger << 10;
+        while (__builtin_readcyclecounter() - t0 < dt) __builtin_amdgcn_s_sleep(32);
+    }
     {
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -440,6 +447,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
 #define ODAM_MM16(accv, x, y) accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
 #if CG_STAMP
         unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
+        const unsigned long long st_loop0 = st_prev;
 #endif
         for (int kp = 0; 2 * kp < nk; ++kp) {
             CG_STAMP_AT(3);
@@ -523,14 +531,20 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         }
 #if CG_STAMP
         CG_STAMP_AT(3);
-        if (lane == 0) {
-            for (int i = 0; i < 4; i++) atomicAdd(&g_stamps[i], st_acc[i]);
-            atomicAdd(&g_stamps[4], (unsigned long long)nk);
-            atomicAdd(&g_stamps[5], 1ull);
-        }
+        const unsigned long long st_loop1 = __builtin_readcyclecounter();
+        auto stamps_out = [&](unsigned long long t_end) {      // at the very end of the kernel
+            if (lane == 0) {
+                for (int i = 0; i < 4; i++) atomicAdd(&g_stamps[i], st_acc[i]);
+                atomicAdd(&g_stamps[4], (unsigned long long)nk);
+                atomicAdd(&g_stamps[5], 1ull);
+                atomicAdd(&g_stamps[6], st_loop0 - st_entry);
+                atomicAdd(&g_stamps[7], t_end - st_loop1);
+            }
+        };
+        if constexpr (FUSE != 0) stamps_out(st_loop1);
 #endif
 #undef ODAM_MM16
-        __syncthreads();
+        if constexpr (FUSE != 0 || POOLABLE) __syncthreads();      // (the plain epilogue below has its own, behind its first residual requests)
         if constexpr (FUSE == 1) { fused_second(a, c16, smem, lds_base, m0, wave, lane); return; }
         if constexpr (FUSE == 2) { fused_chain(a, c16, smem, lds_base, m0, wave, lane); return; }
         if constexpr (FUSE == 3) { fused_second128(a, c16, smem, lds_base, m0, wave, lane); return; }
@@ -565,7 +579,16 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         }
         // epilogue of the 16x16 accumulators (lane: column l & 15, rows 4 (l >> 4) + r): scale / bias (+ residual) (ReLU), fp32
         // out; a row tile of 16 rows goes through a per-wave LDS slab (rows padded by 4 floats: the four row groups of a
-        // ds_write_b32 land on different banks) and leaves as 16-byte stores
+        // ds_write_b32 land on different banks) and leaves as 16-byte stores.
+        // Round 5: NO BRANCHES.  Residual rows and output rows go through buffer descriptors over the tile (base = the tile's
+        // first element: wave-uniform, per-lane byte offsets below 2^31 whatever the tensor's size); a lane whose row is past M
+        // or whose channels are past Cout gets an out-of-range offset -- the load returns zeros, the store is dropped.  With
+        // `if (m < M) load` every load and store sat in its own exec-masked block, and the compiler's wait insertion gives up
+        // across those: it waited vmcnt(0) at the first use of a residual row -- i.e. for the row tile it had just requested as
+        // well, and for every store issued so far (the .s of round 4: s_waitcnt vmcnt(0) at row tiles 0 and 2) -- so each wave
+        // sat through two full memory round trips per tile with nothing in flight.  Now the waits are counted (the residual of
+        // row tile i + 1 and the stores of row tile i - 1 stay in flight under row tile i), and the first two row tiles'
+        // residual rows are requested BEFORE the barrier that ends the main loop.  Same arithmetic, same order: bit-identical.
         {
             constexpr int WROWS = BM / WM, WCOLS = BN / WN, EP_LD = WCOLS + 4;
             static_assert(NW * 16 * EP_LD * 4 <= NST * STAGE, "epilogue slabs fit the ring");
@@ -574,21 +597,37 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             const int c4e = (lane % LPR) * 4;
             const int n = n0 + wn * WCOLS + c4e;
             const bool n_ok = n < a.Cout;
-            float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-            if (n_ok && a.scale) sc = *reinterpret_cast<const float4*>(a.scale + n);
-            if (n_ok && a.bias) bi = *reinterpret_cast<const float4*>(a.bias + n);
-            const float* resp = reinterpret_cast<const float*>(a.res);
-            float* outp = reinterpret_cast<float*>(a.C);
+            const int nc = n_ok ? n : 0;
+            float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + nc) : float4{1.f, 1.f, 1.f, 1.f};
+            float4 bi = a.bias ? *reinterpret_cast<const float4*>(a.bias + nc) : float4{0.f, 0.f, 0.f, 0.f};
+            if (!n_ok) { sc = float4{1.f, 1.f, 1.f, 1.f}; bi = float4{0.f, 0.f, 0.f, 0.f}; }
+            const size_t tile_off = ((size_t)m0 * a.ldc + n0) * sizeof(float);
+            // (no residual: a descriptor of zero records -- every load through it returns zeros)
+            const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<char*>(reinterpret_cast<const char*>(a.res ? a.res : a.C)) + tile_off, 0, a.res ? (int)OOB_VOFF : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C) + tile_off, 0, (int)OOB_VOFF, 0x00020000);
+            const int rows_left = a.M - m0;                       // rows of this tile that exist
+            const int row0 = wm * WROWS + lane / LPR;             // + mi * 16 + it * RPI
+            const unsigned col_b = (unsigned)(wn * WCOLS + c4e) * 4u;
+            auto voff = [&](int mi, int it) -> unsigned {
+                const int r = row0 + mi * 16 + it * RPI;
+                const unsigned ok = (unsigned)n_ok & (unsigned)(r < rows_left);      // (bitwise: a short-circuit && becomes a branch)
+                return ok ? (unsigned)r * (unsigned)a.ldc * 4u + col_b : OOB_VOFF;
+            };
             float4 rv[2][NIT];
             auto load_res = [&](int mi, float4 (&dst)[NIT]) {
 #pragma unroll
-                for (int it = 0; it < NIT; it++) {
-                    const int m = m0 + wm * WROWS + mi * 16 + it * RPI + lane / LPR;
-                    dst[it] = float4{0.f, 0.f, 0.f, 0.f};
-                    if (resp && n_ok && m < a.M) dst[it] = *reinterpret_cast<const float4*>(resp + (size_t)m * a.ldc + n);
-                }
+                for (int it = 0; it < NIT; it++)
+                    dst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, voff(mi, it), 0, 0));
             };
             load_res(0, rv[0]);
+            if (MI > 1) load_res(1, rv[1]);
+            __syncthreads();      // every wave is past its last fragment read: the ring is free for the slabs
+            const unsigned relu_m = a.relu ? 0xffffffffu : 0u;
+            auto act = [&](float v) {      // relu ? (v > 0 ? v : 0) : v, without a branch
+                const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
+                return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
+            };
 #pragma unroll
             for (int mi = 0; mi < MI; mi++) {
                 __builtin_amdgcn_wave_barrier();
@@ -596,27 +635,27 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
                 for (int j = 0; j < NJ; j++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) Ep[(4 * kq + r) * EP_LD + j * 16 + r16] = c16[mi][j][r];
-                if (mi + 1 < MI) load_res(mi + 1, rv[(mi + 1) & 1]);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
                 for (int it = 0; it < NIT; it++) {
                     const int row = it * RPI + lane / LPR;
-                    const int m = m0 + wm * WROWS + mi * 16 + row;
                     const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
                     const float4 rr = rv[mi & 1][it];
                     float4 o;
                     o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
                     o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-                    if (a.relu) {
-                        o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f;
-                        o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f;
-                    }
-                    if (n_ok && m < a.M) *reinterpret_cast<float4*>(outp + (size_t)m * a.ldc + n) = o;
+                    o.x = act(o.x); o.y = act(o.y); o.z = act(o.z); o.w = act(o.w);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, voff(mi, it), 0, 0);
                 }
+                if (mi + 2 < MI) load_res(mi + 2, rv[mi & 1]);      // into the registers this row tile has just released
             }
         }
+#if CG_STAMP
+        __builtin_amdgcn_sched_barrier(0);
+        stamps_out(__builtin_readcyclecounter());
+#endif
         return;
     } else if constexpr (PRE) {
         // Pre-split filters, software-pipelined across the barrier.  Tile kt is consumed from REGISTERS: its fragments were
@@ -955,7 +994,10 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         atomicAdd(&g_stamps[5], 1ull);
     }
 #endif
-    __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
+    // plain layers whose shape the branch-free epilogue takes: it issues its first residual requests, THEN the barrier
+    bool ep2 = false;
+    if constexpr (FUSE == 0) ep2 = !(POOLABLE && MODE == 0 && a.pool) && epilogue2_ok<BM, BN, WM, WN, BF16>(a);
+    if (!ep2) __syncthreads();   // the last stage is fully read before the epilogue reuses the ring
     if constexpr (FUSE == 1) {
         fused_second(a, acc, smem, lds_base, m0, wave, lane);
         return;
@@ -1004,7 +1046,8 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
     }
     static_assert(X16 || (WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>()),
                   "ring and epilogue staging fit the dynamic LDS");
-    epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
+    if (ep2) epilogue2<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, m0, n0, wm, wn, wave, lane);
+    else epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, big_lds_bytes<MODE, BN, NST, NTH>() / 4, m0, n0, wm, wn, wave, lane);
 }
 
 #define g_s1_window odam_cfg::get(odam_cfg::CG_S1)      // bf16 3x3 stride 1: window main loop (0: the generic tap gather)
@@ -1013,6 +1056,7 @@ template <int MODE, int BN, int NST, int NTH = 512>
 static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
     ConvGemmArgs a = a_in;
     a.s1_window = (MODE == 0 && NTH == 512) ? g_s1_window : 0;
+    a.stagger = odam_cfg::get(odam_cfg::CG_STAGGER);
     constexpr int bytes = big_lds_bytes<MODE, BN, NST, NTH>();
     static const bool attr_ok = [] {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;

@@ -25,10 +25,13 @@ constexpr int LDS_STRIDE = 36;  // floats per LDS row
 #ifndef CG_STAMP
 #define CG_STAMP 0
 #endif
+// CG_STAMP=2 (round 5): the LIGHT set for the 16x16x32 loop -- per pair only the wait (before the vmcnt -> behind the barrier: phases 1 + 0,
+// the products go to phase 2), per tile entry -> loop ([6]) and loop end -> last store issued ([7]); every sum leaves through atomics at the
+// very END of the kernel (round 4's set issued them before the epilogue, where they sit in front of the epilogue's counted waits).
 #if CG_STAMP
 static __device__ unsigned long long g_stamps[8];
-#define CG_STAMP_AT(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
-                            st_acc[i] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define CG_STAMP_AT(i) do { if (CG_STAMP == 1 || (i) != 2) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                            st_acc[(CG_STAMP == 2 && (i) == 3) ? 2 : (i)] += t_ - st_prev; st_prev = t_; __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define CG_STAMP_AT(i) do { } while (0)
 #endif
@@ -252,6 +255,110 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
                 if (n_ok && m < a.M) store1((size_t)m * a.ldc + n, v);
             }
         }
+    }
+}
+
+// ---- the same epilogue without branches (round 5) ----------------------------------------------------------------------------
+// epilogue() above guards every residual load and every store with `if (m < M && n_ok)`: each sits in its own exec-masked block,
+// and the compiler's wait insertion does not count across those -- it waits vmcnt(0) at the first use of a residual row, i.e. for
+// every load and store issued so far, the next row tile's residual included (the .s of the round-4 kernels).  Here residual and
+// output go through buffer descriptors over the TILE (wave-uniform base, per-lane byte offsets; a lane past M or past Cout gets an
+// out-of-range offset: the load returns zeros, the store is dropped), so the code is straight-line, the waits are counted, the
+// residual rows of row tile i + 1 and the stores of row tile i - 1 stay in flight under row tile i, and the first two row tiles'
+// residual rows are requested BEFORE the workgroup barrier that frees the staging buffers.  16 bytes per lane either way: four
+// fp32 channels or eight bf16 channels.  Same operations in the same order as epilogue(): bit-identical results.
+template <int BM, int BN, int WM, int WN, bool BF16>
+__device__ __forceinline__ bool epilogue2_ok(const ConvGemmArgs& a) {
+    constexpr int WCOLS = BN / WN, CPL = BF16 ? 8 : 4, LPR = WCOLS / CPL;
+    constexpr bool shape_ok = LPR >= 1 && LPR <= 32 && (64 % LPR) == 0 && 32 / (64 / LPR) <= 8;      // at most 2 x 8 residual registers-of-16-bytes per lane
+    if (!shape_ok) return false;
+    if (BF16) return !a.out_f32 && (a.Cout & 7) == 0 && (a.ldc & 7) == 0;
+    return (a.Cout & 3) == 0 && (a.ldc & 3) == 0;
+}
+template <int BM, int BN, int WM, int WN, int TM, int TN, bool BF16>
+__device__ __forceinline__ void epilogue2(const ConvGemmArgs& a, floatx16 (&acc)[TM][TN], float* smem, int m0, int n0, int wm, int wn,
+                                          int wave, int lane) {
+    constexpr int WROWS = BM / WM, WCOLS = BN / WN;
+    constexpr int CPL = BF16 ? 8 : 4, ESZ = BF16 ? 2 : 4;
+    constexpr int LPR = WCOLS / CPL, RPI = 64 / LPR, NIT = (32 / RPI) > 0 ? 32 / RPI : 1;
+    const int half = lane >> 5;
+    float* Ep = smem + wave * (32 * WCOLS);
+    const int c0 = (lane % LPR) * CPL;
+    const int n = n0 + wn * WCOLS + c0;
+    const bool n_ok = n < a.Cout;
+    const int nc = n_ok ? n : 0;
+    float sc[CPL], bi[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c += 4) {
+        const float4 s4 = a.scale ? *reinterpret_cast<const float4*>(a.scale + nc + c) : float4{1.f, 1.f, 1.f, 1.f};
+        const float4 b4 = a.bias ? *reinterpret_cast<const float4*>(a.bias + nc + c) : float4{0.f, 0.f, 0.f, 0.f};
+        sc[c] = n_ok ? s4.x : 1.f; sc[c + 1] = n_ok ? s4.y : 1.f; sc[c + 2] = n_ok ? s4.z : 1.f; sc[c + 3] = n_ok ? s4.w : 1.f;
+        bi[c] = n_ok ? b4.x : 0.f; bi[c + 1] = n_ok ? b4.y : 0.f; bi[c + 2] = n_ok ? b4.z : 0.f; bi[c + 3] = n_ok ? b4.w : 0.f;
+    }
+    const size_t tile_off = ((size_t)m0 * a.ldc + n0) * ESZ;
+    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(a.res ? a.res : a.C)) + tile_off, 0, a.res ? (int)OOB_VOFF : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C) + tile_off, 0, (int)OOB_VOFF, 0x00020000);
+    const int rows_left = a.M - m0;
+    const int row0 = wm * WROWS + lane / LPR;
+    const unsigned col_b = (unsigned)(wn * WCOLS + c0) * (unsigned)ESZ;
+    auto voff = [&](int i, int it) -> unsigned {
+        const int r = row0 + i * 32 + it * RPI;
+        const unsigned ok = (unsigned)n_ok & (unsigned)(r < rows_left);
+        return ok ? (unsigned)r * (unsigned)a.ldc * (unsigned)ESZ + col_b : OOB_VOFF;
+    };
+    u32x4 rv[2][NIT];
+    auto load_res = [&](int i, u32x4 (&dst)[NIT]) {
+#pragma unroll
+        for (int it = 0; it < NIT; it++) dst[it] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, voff(i, it), 0, 0);
+    };
+    load_res(0, rv[0]);
+    if (TM > 1) load_res(1, rv[1]);
+    __syncthreads();      // every wave is done with the staging buffers: they become the slabs
+    const unsigned relu_m = a.relu ? 0xffffffffu : 0u;
+    auto act = [&](float v) {      // relu ? (v > 0 ? v : 0) : v
+        const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
+        return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
+    };
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) Ep[((r & 3) + 8 * (r >> 2) + 4 * half) * WCOLS + j * 32 + (lane & 31)] = acc[i][j][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int row = it * RPI + lane / LPR;
+            const u32x4 rw = rv[i & 1][it];
+            if constexpr (BF16) {
+                const float4 v0 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c0]);
+                const float4 v1 = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c0 + 4]);
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                u32x4 ow;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float lo = v[2 * c] * sc[2 * c] + bi[2 * c], hi = v[2 * c + 1] * sc[2 * c + 1] + bi[2 * c + 1];
+                    lo += __builtin_bit_cast(float, rw[c] << 16);
+                    hi += __builtin_bit_cast(float, rw[c] & 0xffff0000u);
+                    lo = act(lo); hi = act(hi);
+                    ow[c] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(ow, out_rs, voff(i, it), 0, 0);
+            } else {
+                const float4 v = *reinterpret_cast<const float4*>(&Ep[row * WCOLS + c0]);
+                const float4 rr = __builtin_bit_cast(float4, rw);
+                float4 o;
+                o.x = v.x * sc[0] + bi[0]; o.y = v.y * sc[1] + bi[1]; o.z = v.z * sc[2] + bi[2]; o.w = v.w * sc[3] + bi[3];
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                o.x = act(o.x); o.y = act(o.y); o.z = act(o.z); o.w = act(o.w);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, voff(i, it), 0, 0);
+            }
+        }
+        if (i + 2 < TM) load_res(i + 2, rv[i & 1]);
     }
 }
 

@@ -330,7 +330,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_gemm_kernel(ConvGemmArgs a)
     }
 
     static_assert(WM * WN * 32 * (BN / WN) <= NST * (BM + BN) * LDS_LD, "epilogue staging fits the tile buffers");
-    epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, (int)sizeof(smem) / 4, m0, n0, wm, wn, wave, lane);
+    if (epilogue2_ok<BM, BN, WM, WN, BF16>(a)) epilogue2<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, m0, n0, wm, wn, wave, lane);      // (its own barrier: one more)
+    else epilogue<BM, BN, WM, WN, TM, TN, BF16>(a, acc, smem, (int)sizeof(smem) / 4, m0, n0, wm, wn, wave, lane);
 }
 
 #define g_big_mode odam_cfg::get(odam_cfg::CG_RING)      // 0 off, 1 auto, 2 whenever eligible

@@ -27,7 +27,7 @@ def use_native_collectives(device):
     Needs an initialised process group (a world of one included).  Returns the communicator's (world, rank)."""
     import ctypes
     from . import _lib
-    device = str(torch.device(device))
+    device = _dev_key(device)
     if device in _NATIVE:
         return _NATIVE[device][1:]
     rank, ws = dist.get_rank(), dist.get_world_size()
@@ -53,8 +53,27 @@ def close_native_collectives():
     _NATIVE.clear()
 
 
+def _dev_key(device):
+    """'cuda' / None -> the current device's full name ('cuda:0'); a torch.device or string otherwise"""
+    d = torch.device("cuda" if device is None else device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
 def _native(device):
-    return _NATIVE.get(str(torch.device(device))) if device is not None and str(device) != "cpu" else None
+    """The library's communicator for `device`, or None while native collectives are off.  Once use_native_collectives() has run,
+    the mode is process-wide: every collective of this module goes through the library's communicator, and a device without one is
+    an error -- never a silent fall-back to torch.distributed, which would leave this rank in a different collective than its
+    peers (a deadlock) and, under a gloo group, hand CUDA tensors to gloo."""
+    if not _NATIVE:
+        return None
+    key = _dev_key(device)
+    if key not in _NATIVE:
+        from . import _lib
+        raise _lib.OdamError(f"native collectives are on (use_native_collectives) but no communicator exists for {key}; "
+                             f"have {sorted(_NATIVE)}")
+    return _NATIVE[key]
 
 
 def world():
@@ -112,7 +131,7 @@ def allgather_detections(blk, cnt, n_frames, device=None, force=False):
     rank, ws = world()
     if ws == 1 and not (force and dist.is_available() and dist.is_initialized()):
         return blk, cnt
-    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    dev = device or ("cuda" if (dist.get_backend() == "nccl" or _NATIVE) else "cpu")
     per = -(-n_frames // ws)  # padded shard length so all_gather_into_tensor sees equal shapes
     W = MAX_DETS * DET_COLS
     nat = _native(dev)
@@ -166,7 +185,7 @@ def allgather_rows(local, n_total, owner_lists, device=None, force=False):
         out = np.zeros((n_total,) + local.shape[1:], np.float32)
         out[owner_lists[0]] = local
         return out
-    dev = device or ("cuda" if dist.get_backend() == "nccl" else "cpu")
+    dev = device or ("cuda" if (dist.get_backend() == "nccl" or _NATIVE) else "cpu")
     per = max(len(o) for o in owner_lists)
     nat = _native(dev)
     if nat is not None:

@@ -77,7 +77,7 @@ def sharded_optim(proc, tracks, device=None, force=False):
             "quadrics": quadrics, "params": rows[:, :9].copy(), "fitted": rows[:, 9] != 0}
 
 
-def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=0, device=None, force=False, stages=None):
+def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=0, device=None, force=False, stages=None, overlap=None):
     """The driver loop of run_processor.py:70-83 for one scene on the ranks of the current process group.
 
     proc      OdamProcess after init_sequence (its detector is used unless `detect` is given; its associator and fitter always)
@@ -85,6 +85,13 @@ def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=
               path); default: proc.detect_frames over frames[f0:f1]
     chunk     frames per all-gather (0 = the whole scene in one): association of a chunk starts when its detections arrive
     stages    optional dict that receives wall-clock seconds per stage (detect + gather, associate, fit 1, merge, fit 2)
+    overlap   detection + all-gather of chunk i + 1 run on a worker thread while this thread replays process_frame over chunk i
+              ("chunking lets association overlap detection"; src/processor.py:306-345 is the loop that is replicated).
+              None = on in a world of more than one rank with more than one chunk: there a rank's share of a chunk's detection is
+              1 / N of it while the replicated association is not, so the chain runs at max(associate, detect / N) instead of their
+              sum; on ONE GPU the association's short launches wait behind the detector's queued ones (profiles/
+              r4_experiments_not_kept.txt #12, #13) and the overlap returns nothing.  Only the worker issues collectives while it
+              runs, in chunk order on every rank; results are identical with and without (the same calls on the same data).
     Returns the second optim_process dict (what the reference pickles), identical on every rank; proc.tracks holds the
     unmerged tracks."""
     import time
@@ -95,14 +102,56 @@ def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=
         def detect(f0, f1):
             return [np.asarray(r, np.float64).reshape(-1, 79) for r in proc.detect_frames(list(frames[f0:f1]), list(frame_ids[f0:f1]))]
     t = {"detect_gather": 0.0, "associate": 0.0}
-    for c0, c1 in parallel.chunk_spans(n_frames, chunk or n_frames):
-        s0 = time.perf_counter()
-        rows = detect_gathered(detect, c0, c1, device, force)
-        s1 = time.perf_counter()
-        for i, r in enumerate(rows):
-            proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
-        t["detect_gather"] += s1 - s0
-        t["associate"] += time.perf_counter() - s1
+    spans = parallel.chunk_spans(n_frames, chunk or n_frames)
+    if overlap is None:
+        overlap = parallel.world()[1] > 1 and len(spans) > 1
+    if overlap and len(spans) > 1:
+        import queue
+        import threading
+        q = queue.Queue(maxsize=2)      # at most two chunks of detections ahead of the association loop
+
+        def produce():
+            try:
+                import torch
+                if device is not None and str(device) != "cpu" and torch.cuda.is_available():
+                    torch.cuda.set_device(torch.device(device))      # the device is per thread
+                for c0, c1 in spans:
+                    s0 = time.perf_counter()
+                    rows = detect_gathered(detect, c0, c1, device, force)
+                    q.put((c0, rows, time.perf_counter() - s0))
+                q.put(None)
+            except BaseException as e:      # noqa: BLE001 -- handed to the consumer, which re-raises it
+                q.put(e)
+
+        th = threading.Thread(target=produce, name="odam-detect", daemon=True)
+        th.start()
+        waited = 0.0
+        while True:
+            s0 = time.perf_counter()
+            item = q.get()
+            waited += time.perf_counter() - s0
+            if item is None:
+                break
+            if isinstance(item, BaseException):
+                raise item
+            c0, rows, dt_detect = item
+            s1 = time.perf_counter()
+            for i, r in enumerate(rows):
+                proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
+            t["associate"] += time.perf_counter() - s1
+            t["detect_gather"] += dt_detect
+        th.join()
+        t["overlapped"] = True
+        t["associate_waited_for_detections"] = waited      # what the association loop did NOT hide
+    else:
+        for c0, c1 in spans:
+            s0 = time.perf_counter()
+            rows = detect_gathered(detect, c0, c1, device, force)
+            s1 = time.perf_counter()
+            for i, r in enumerate(rows):
+                proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
+            t["detect_gather"] += s1 - s0
+            t["associate"] += time.perf_counter() - s1
     s0 = time.perf_counter()
     out = sharded_optim(proc, proc.tracks, device, force)
     s1 = time.perf_counter()

@@ -115,6 +115,8 @@ class OdamProcess:
         self.P_cws = []
         self.usable_frames = []
         self._sum_cache = []
+        self._win_checked = None
+        self._frame_token = None
         if getattr(self, "_win", None) is not None:
             self._win.reset()
 
@@ -186,6 +188,7 @@ class OdamProcess:
     def _windows(self):
         """the device mirror of self.tracks' observations, or None where it does not apply (a caller-supplied associator
         or fitter without the native entry points, shape codes in use, more tracks than the native store holds)"""
+        self._win_checked = None      # set again below only when the mirror was checked against self.tracks in THIS frame
         if not (getattr(self.associator, "native_windows", False) and self.no_code and hasattr(self._fitter(), "project_extents")):
             return None
         if getattr(self, "_win", None) is None:
@@ -201,7 +204,7 @@ class OdamProcess:
             return None
         if not w.in_step(self.tracks):                        # first use, or somebody edited self.tracks: rebuild the mirror
             w.load(self.tracks)
-        self._win_checked = len(self.usable_frames)           # _attach_to_tracks of this frame need not check again
+        self._win_checked = getattr(self, "_frame_token", None)   # _attach_to_tracks of this frame need not check again
         return w
 
     def _preprocess_tracks(self, tracks, T_wc, cam_azi, n_times=100, proj_px=None):
@@ -328,7 +331,8 @@ class OdamProcess:
         rows = self._track_rows(detections, T_wc, with_code=not self.no_code)
         win = getattr(self, "_win", None)
         # the device mirror matches the tracks as they stand: checked by _windows() in this very frame, or checked now
-        in_step = win is not None and (getattr(self, "_win_checked", -1) == len(self.usable_frames) or win.in_step(self.tracks))
+        tok = getattr(self, "_frame_token", None)
+        in_step = win is not None and ((tok is not None and getattr(self, "_win_checked", None) is tok) or win.in_step(self.tracks))
         ids, picked = [], []
         for det_id, track_id in enumerate(pred_match):
             if score_mat[track_id, det_id] < self.score_threshold:
@@ -347,6 +351,7 @@ class OdamProcess:
     def process_frame(self, rgb, frame_id, T_wc, detections=None):
         """`detections`: optional rows for this frame computed earlier by `detect_frames` (here or on another
         rank); None -> run the detector now, as the reference does."""
+        self._frame_token = object()      # one per call: what "_windows() checked the device mirror in this very frame" is keyed on
         self.usable_frames.append(frame_id)
         self.T_wcs.append(T_wc)
         self.P_cws.append(self.sequence_meta.K @ np.linalg.inv(T_wc)[:3, :])

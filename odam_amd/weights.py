@@ -173,7 +173,7 @@ def make_associator_state_dict(n_self=2, n_gnn=8, seed=0):
     configs/detr_scan_net.yaml: keypoint_encoder [78,256,256], 8 GNN layers, 2 self layers): random tensors.  They exercise
     the arithmetic, but every descriptor comes out nearly equal and the assignment is uniform.  The hand-written weights
     that make the same architecture associate by position and class (whole-chain fixture) are test scaffolding and live
-    in tests/scene_weights.py."""
+    in tools/scene_weights.py."""
     return _make_associator_state_dict(n_self, n_gnn, seed)
 
 

@@ -236,10 +236,15 @@ void oracle_sq_points(const float *p, float *out) {
  * Outputs: loss2d, loss (incl. prior), grad[9], ext[F][4], win[F][4] (winner point, -1 = none).
  * Direction order in the loss follows names = [x_min, x_max, y_min, y_max] (sq_libs.py:438).
  * ---------------------------------------------------------------------------------------- */
+/* Measurement hook (tests/golden/make_sq_divergence.py only): the search's results for every (view, direction) -- winner index,
+ * extent, and the winner's projected q_r, q_z -- supplied from outside (the reference's own torch run) instead of computed. */
+typedef struct { const int *win; const float *ext, *qr, *qz; } sq_search_t;
+
 static void sq_loss_grad_(const float *p, const sq_state_t *S, int F, const float *P,
                           const float *tgt, const float *mask, const float *prior_icov,
                           const float *s0, int optimise_shapes,
-                          float *loss2d_out, float *loss_out, float *grad, float *ext_out, int *win_out) {
+                          float *loss2d_out, float *loss_out, float *grad, float *ext_out, int *win_out,
+                          const sq_search_t *given) {
     int Pn = 1;
     while (Pn < F) Pn <<= 1;
     float (*contrib)[9] = (float (*)[9])calloc((size_t)Pn, sizeof(float[9]));   /* one row per view */
@@ -250,7 +255,7 @@ static void sq_loss_grad_(const float *p, const sq_state_t *S, int F, const floa
         const float *M = P + 12 * f;
         float best[4] = {1000000.0f, -1000000.0f, 1000000.0f, -1000000.0f};
         int bi[4] = {-1, -1, -1, -1};
-        for (int i = 0; i < SQ_N; i++) {
+        for (int i = 0; i < (given ? 0 : SQ_N); i++) {
             const float *w = S->pw[i];
             /* pixels = homog(pts) @ M^T, k-ordered   sq_libs.py:398 */
             float qx = fmaf(w[2], M[2], fmaf(w[1], M[1], w[0] * M[0])) + M[3];
@@ -268,8 +273,8 @@ static void sq_loss_grad_(const float *p, const sq_state_t *S, int F, const floa
         float dg[4][9];
         memset(dg, 0, sizeof(dg));
         for (int d = 0; d < 4; d++) {
-            float ext = best[d];
-            int wi = bi[d];
+            float ext = given ? given->ext[4 * f + d] : best[d];
+            int wi = given ? given->win[4 * f + d] : bi[d];
             if (ext_out) ext_out[4 * f + d] = ext;
             if (win_out) win_out[4 * f + d] = wi;
             float m = mask[4 * f + d];
@@ -285,6 +290,7 @@ static void sq_loss_grad_(const float *p, const sq_state_t *S, int F, const floa
             int r = (d < 2) ? 0 : 1;
             float qr = fmaf(w[2], M[4 * r + 2], fmaf(w[1], M[4 * r + 1], w[0] * M[4 * r])) + M[4 * r + 3];
             float qz = fmaf(w[2], M[10], fmaf(w[1], M[9], w[0] * M[8])) + M[11];
+            if (given) { qr = given->qr[4 * f + d]; qz = given->qz[4 * f + d]; }
             float den = fabsf(qz) + 1e-6f;
             float val = qr / den;
             float gq = g / den;                               /* d val / d q_r */
@@ -356,7 +362,51 @@ void oracle_sq_loss_grad(const float *p, int F, const float *P, const float *tgt
                          float *loss2d, float *loss, float *grad, float *ext, int *win) {
     sq_state_t *S = (sq_state_t *)malloc(sizeof(sq_state_t));
     sq_forward_points_(p, S);
-    sq_loss_grad_(p, S, F, P, tgt, mask, prior_icov, s0, optimise_shapes, loss2d, loss, grad, ext, win);
+    sq_loss_grad_(p, S, F, P, tgt, mask, prior_icov, s0, optimise_shapes, loss2d, loss, grad, ext, win, NULL);
+    free(S);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement hooks (tests/golden/make_sq_divergence.py: WHICH part of a step makes the free-running oracle leave the
+ * reference's trajectory).  The forward state of a step -- everything sq_loss_grad_ reads besides the parameters -- as one
+ * flat float array, so that it can be produced either here (oracle_sq_state) or by the reference's own torch operations:
+ *   [0] cos(angle) [1] sin(angle) [2..4] a [5..6] e [7..8] sigmoid(shapes)
+ *   then 8 arrays of 1000: cos(eta) sin(eta) cos(omega) sin(omega) f1 fz f2 fs2
+ *   then 3 arrays of 1000 x 3: raw (before the 1e-6 clamp), po (object frame), pw (world frame)
+ * oracle_sq_loss_grad_state evaluates the gradient from such a state; `win` non-null: with the search's results given as well.
+ * ---------------------------------------------------------------------------------------- */
+#define SQ_STATE_FLOATS (9 + 8 * SQ_N + 9 * SQ_N)
+int oracle_sq_state_floats(void) { return SQ_STATE_FLOATS; }
+
+static void state_pack_(const sq_state_t *S, float *o) {
+    o[0] = S->c; o[1] = S->s; memcpy(o + 2, S->a, 12); memcpy(o + 5, S->e, 8); memcpy(o + 7, S->sig, 8);
+    const float *arr[8] = {S->ce, S->se, S->cw, S->sw, S->f1, S->fz, S->f2, S->fs2};
+    for (int k = 0; k < 8; k++) memcpy(o + 9 + k * SQ_N, arr[k], SQ_N * 4);
+    memcpy(o + 9 + 8 * SQ_N, S->raw, SQ_N * 12);
+    memcpy(o + 9 + 11 * SQ_N, S->po, SQ_N * 12);
+    memcpy(o + 9 + 14 * SQ_N, S->pw, SQ_N * 12);
+}
+static void state_unpack_(const float *o, sq_state_t *S) {
+    S->c = o[0]; S->s = o[1]; memcpy(S->a, o + 2, 12); memcpy(S->e, o + 5, 8); memcpy(S->sig, o + 7, 8);
+    float *arr[8] = {S->ce, S->se, S->cw, S->sw, S->f1, S->fz, S->f2, S->fs2};
+    for (int k = 0; k < 8; k++) memcpy(arr[k], o + 9 + k * SQ_N, SQ_N * 4);
+    memcpy(S->raw, o + 9 + 8 * SQ_N, SQ_N * 12);
+    memcpy(S->po, o + 9 + 11 * SQ_N, SQ_N * 12);
+    memcpy(S->pw, o + 9 + 14 * SQ_N, SQ_N * 12);
+}
+void oracle_sq_state(const float *p, float *state_out) {
+    sq_state_t *S = (sq_state_t *)malloc(sizeof(sq_state_t));
+    sq_forward_points_(p, S);
+    state_pack_(S, state_out);
+    free(S);
+}
+void oracle_sq_loss_grad_state(const float *p, const float *state, int F, const float *P, const float *tgt, const float *mask,
+                               const float *prior_icov, const float *s0, int optimise_shapes, const int *win, const float *ext,
+                               const float *qr, const float *qz, float *loss2d, float *loss, float *grad, float *ext_out, int *win_out) {
+    sq_state_t *S = (sq_state_t *)malloc(sizeof(sq_state_t));
+    state_unpack_(state, S);
+    sq_search_t g = {win, ext, qr, qz};
+    sq_loss_grad_(p, S, F, P, tgt, mask, prior_icov, s0, optimise_shapes, loss2d, loss, grad, ext_out, win_out, win ? &g : NULL);
     free(S);
 }
 
@@ -405,7 +455,7 @@ void oracle_sq_fit(const float *p_init, int F, const float *P, const float *tgt,
     for (int it = 0; it < n_iters; it++) {
         float l2d, l;
         sq_forward_points_(p, S);
-        sq_loss_grad_(p, S, F, P, tgt, mask, prior_icov, s0, n_opt == 9, &l2d, &l, g, NULL, NULL);
+        sq_loss_grad_(p, S, F, P, tgt, mask, prior_icov, s0, n_opt == 9, &l2d, &l, g, NULL, NULL, NULL);
         oracle_adam_step(p, m, v, g, it + 1, n_opt, 0.01, 0.1);
         if (traj) memcpy(traj + 9 * it, p, sizeof(p));
         if (loss_log) loss_log[it] = l2d;

@@ -85,6 +85,7 @@ def main():
     import src.processor as ref_processor
     from odam_amd import weights, synth, transforms
     sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, os.path.join(REPO, "tools"))
     import scene_weights
     rm = patch_run_merge()
     ref_processor.merge_process = rm.merge_process

@@ -1,0 +1,256 @@
+"""WHICH part of a step makes a correct float32 implementation leave the reference's fit trajectory?  A substitution measurement
+over the 46 survey problems (tests/golden/sq_survey.npz).  Runs in the build container only (imports the reference and torch's CPU ops).
+
+The reference's step (likojack/ODAM src/super_quadric/sq_libs.py:455-472) has three parts that a restatement cannot copy bit for bit
+without knowing the arithmetic behind them:
+  A  transcendentals of the surface points (sq_libs.py:577-595, learnable_primitives/sampling.py:596-615): torch.cos / sin / exp / log
+     are MKL VML calls in this torch build (vsCos, vsSin, vsExp, vsLn: closed source), abs(x) ** e is Sleef_powf16_u10 for the vector
+     body and glibc powf for the scalar tail of 8 (probe: /tmp-free, see PROBE below); the oracle evaluates glibc's cosf / sinf / powf / expf / logf
+  B  the projection  homog(pts) @ Ms^T  (sq_libs.py:398): an MKL sgemm;   the oracle: one k-ordered fma chain per value
+  C  the gradient: autograd's reduction orders (sum over 1000 points, over F views) against the oracle's closed form + fixed tree
+The free-running fit is re-run with the oracle's A / B replaced by the reference's own torch operations, one after the other:
+  H0  oracle A, B, C                       (= oracle_sq_fit; what the GPU kernel reproduces bit for bit)
+  H1  torch  A, oracle B, C                (the step's points are the reference's, bit for bit)
+  H2  torch  A, B, oracle C                (extents, winners and the winners' projections are the reference's)
+  ref the reference itself
+and every run is compared with the reference's trajectory: t = first step after which the nine parameters differ in any bit,
+w = first step whose 4 F arg-extreme winners differ, e = final deviation (the survey's measure).  The cause of a problem's
+divergence is the first substitution that carries the run to the end within 1e-4 (A, then B; C if neither does).
+
+Writes tests/golden/sq_divergence.npz (per problem: t, w, e for H0 / H1 / H2) and prints the table.
+Run: python tests/golden/make_sq_divergence.py        (about 10 minutes on 7 processes)
+"""
+import ctypes
+import os
+import sys
+from multiprocessing import Pool
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+
+import numpy as np  # noqa: E402
+
+N = 1000
+
+
+def torch_state(p, et, om):
+    """the forward state of one step (layout of oracle_sq_state) computed by the SAME torch CPU operations the reference runs
+    (sq_libs.py:556-595, sampling.py:586-615), from float32 parameters p and the sampler's angles"""
+    import torch
+    t = torch.from_numpy(np.asarray(p, np.float32).copy())
+    angle = t[3]
+    cosz, sinz = torch.cos(angle), torch.sin(angle)
+    zeros = angle.detach() * 0
+    ones = zeros.detach() + 1
+    R = torch.stack([cosz, -sinz, zeros, sinz, cosz, zeros, zeros, zeros, ones], dim=0).reshape(3, 3)
+    a = (t[4:7] ** 2).unsqueeze(0).unsqueeze(0)
+    sig = torch.sigmoid(t[7:9])
+    e = (sig * (1.6 - 0.2) + 0.2).unsqueeze(0).unsqueeze(0)
+    etas = np.asarray(et, np.float32).copy()[None, None]; omegas = np.asarray(om, np.float32).copy()[None, None]
+    etas[etas == 0] += 1e-6; omegas[omegas == 0] += 1e-6
+    etas = a.new_tensor(etas); omegas = a.new_tensor(omegas)
+    a1, a2, a3 = (a[:, :, k].unsqueeze(-1) for k in range(3))
+    e1, e2 = e[:, :, 0].unsqueeze(-1), e[:, :, 1].unsqueeze(-1)
+    fexp = lambda x, q: torch.sign(x) * (torch.abs(x) ** q)
+    ce, se, cw, sw = torch.cos(etas), torch.sin(etas), torch.cos(omegas), torch.sin(omegas)
+    f1, fz, f2, fs2 = fexp(ce, e1), fexp(se, e1), fexp(cw, e2), fexp(sw, e2)
+    x = a1 * f1 * f2; y = a2 * f1 * fs2; z = a3 * fz
+    raw = torch.stack([x, y, z], -1)[0, 0]
+    c = lambda v: ((v > 0).float() * 2 - 1) * torch.max(torch.abs(v), v.new_tensor(1e-6))
+    po = torch.stack([c(x), c(y), c(z)], -1)[0, 0]
+    pw = po @ R.T
+    pw = pw + t[:3].unsqueeze(0)
+    o = np.zeros(9 + 17 * N, np.float32)
+    o[0], o[1] = cosz.item(), sinz.item()
+    o[2:5] = a[0, 0].numpy(); o[5:7] = e[0, 0].numpy(); o[7:9] = sig.numpy()
+    for k, v in enumerate((ce, se, cw, sw, f1, fz, f2, fs2)):
+        o[9 + k * N: 9 + (k + 1) * N] = v[0, 0].numpy()
+    o[9 + 8 * N: 9 + 11 * N] = raw.numpy().reshape(-1)
+    o[9 + 11 * N: 9 + 14 * N] = po.numpy().reshape(-1)
+    o[9 + 14 * N: 9 + 17 * N] = pw.numpy().reshape(-1)
+    return o, pw
+
+
+def torch_search(pw, Ms):
+    """sq_libs.py:395-414 with the reference's own operations: winners, extents and the winners' q_r, q_z per (view, direction)"""
+    import torch
+    import src.utils.geometry_utils as geo_utils
+    F = Ms.shape[0]
+    pts = pw.repeat(F, 1, 1)
+    q = geo_utils.get_homogeneous(pts) @ Ms.permute(0, 2, 1)      # the reference's own call (its helper keeps pts[0] only: a broadcast matmul)
+    valid = q[:, :, 2] > 0.5
+    pix = q[:, :, :2] / (torch.abs(q[:, :, 2:]) + 1e-6)
+    big = torch.ones_like(pix[:, :, 0]) * 1000000
+    res = [torch.min(torch.where(valid, pix[:, :, 0], big), dim=1), torch.max(torch.where(valid, pix[:, :, 0], -big), dim=1),
+           torch.min(torch.where(valid, pix[:, :, 1], big), dim=1), torch.max(torch.where(valid, pix[:, :, 1], -big), dim=1)]
+    win = torch.stack([r.indices for r in res], 1)
+    ext = torch.stack([r.values for r in res], 1)
+    any_valid = valid.any(1)
+    ar = torch.arange(F)
+    qr = torch.stack([q[ar, win[:, d], 0 if d < 2 else 1] for d in range(4)], 1)
+    qz = torch.stack([q[ar, win[:, d], 2] for d in range(4)], 1)
+    win = torch.where(any_valid[:, None], win, torch.full_like(win, -1))
+    return (np.ascontiguousarray(win.numpy().astype(np.int32)), np.ascontiguousarray(ext.numpy()),
+            np.ascontiguousarray(qr.numpy()), np.ascontiguousarray(qz.numpy()))
+
+
+def check_geo():
+    """the two helpers above restate the reference's tensor code: pin them against the reference itself once"""
+    import torch
+    import src.super_quadric.sq_libs as L
+    from odam_amd import synth
+    from conftest import Oracle
+    o = Oracle()
+    prob = synth.make_sq_problem(24, 311)
+    opt = L.SuperQuadricOptimizer(prob["translate"], prob["angle"], prob["dims"], prob["class_id"], "super_quadric", True)
+    from make_golden import params_of
+    p = params_of(opt.Q_init)
+    pts, _ = opt.Q_init.compute_ellipsoid_points(False)
+    sc = (opt.Q_init.scales ** 2).detach().numpy(); sh = L.squashing(opt.Q_init.shapes).detach().numpy()
+    et, om = o.sample(sc, sh)
+    st, pw = torch_state(p, et, om)
+    assert torch.equal(pw, pts.detach()), "torch_state does not reproduce compute_ellipsoid_points bit for bit"
+
+
+def _one(ci):
+    import torch
+    torch.set_num_threads(1)
+    import refenv
+    refenv.setup()
+    import src.super_quadric.sq_libs as L
+    from make_golden import params_of
+    from conftest import Oracle
+    from odam_amd import synth, sq
+    o = Oracle()
+    lib = o.lib
+    z = np.load(os.path.join(HERE, "sq_survey.npz"))
+    F, seed = int(z["views"][ci]), int(z["seeds"][ci])
+    prob = synth.make_sq_problem(F, seed)
+    if ci == 0:
+        check_geo()
+    # ---- the reference itself, recording the parameters after every step -----------------------------------------------------
+    opt = L.SuperQuadricOptimizer(np.asarray(prob["translate"], np.float32), np.float32(prob["angle"]), prob["dims"], prob["class_id"],
+                                  "super_quadric", True)
+    traj, before, grads = [], [], []
+    step0 = opt.optimizer.step
+    Q = opt.Q_init
+
+    def rec_step(*a, **k):
+        before.append(params_of(Q))
+        grads.append(np.concatenate([Q.translate.grad.numpy(), [Q.angle.grad.item()], Q.scales.grad.numpy(), Q.shapes.grad.numpy()]).astype(np.float32))
+        r = step0(*a, **k)
+        traj.append(params_of(Q))
+        return r
+    opt.optimizer.step = rec_step
+    opt.run(prob["bbox_lines"], None, prob["P"], 200)
+    ref = np.asarray(traj, np.float32); ref_before = np.asarray(before, np.float32); ref_g = np.asarray(grads, np.float32)
+    assert np.array_equal(ref[-1].view(np.uint32), z["final"][ci].view(np.uint32)), "the reference run is not the stored one"
+    # ---- the hybrids --------------------------------------------------------------------------------------------------------
+    p0 = z[f"c{ci}_p0"].astype(np.float32); cls = int(z[f"c{ci}_cls"])
+    P = np.ascontiguousarray(z[f"c{ci}_P"], np.float32); tgt = np.ascontiguousarray(z[f"c{ci}_tgt"], np.float32)
+    mask = np.ascontiguousarray(z[f"c{ci}_mask"], np.float32)
+    Ms = torch.from_numpy(P.reshape(-1, 3, 4).copy())
+    icov = np.ascontiguousarray(o.icov[cls].copy())
+    fp, ip = Oracle.fp, Oracle.ip
+    nst = lib.oracle_sq_state_floats()
+    s0 = p0[4:7].copy()
+
+    def forward(p, mode):
+        """state (+ search results) of one step at parameters p: mode 0 the oracle's, 1 torch's points, 2 torch's points and search"""
+        if mode == 0:
+            st = np.zeros(nst, np.float32)
+            lib.oracle_sq_state(p.ctypes.data_as(fp), st.ctypes.data_as(fp))
+            return st, None
+        e = (torch.sigmoid(torch.from_numpy(p[7:9].copy())) * (1.6 - 0.2) + 0.2).numpy()      # sq_libs.py:26-27, as the reference evaluates it
+        et, om = o.sample(np.ascontiguousarray((torch.from_numpy(p[4:7].copy()) ** 2).numpy()), np.ascontiguousarray(e))
+        st, pw = torch_state(p, et, om)
+        return st, (torch_search(pw, Ms) if mode == 2 else None)
+
+    def grad(p, st, srch):
+        g = np.zeros(9, np.float32); win = np.zeros((F, 4), np.int32); ext = np.zeros((F, 4), np.float32)
+        l2 = ctypes.c_float(); l = ctypes.c_float()
+        args = [p.ctypes.data_as(fp), st.ctypes.data_as(fp), F, P.ctypes.data_as(fp), tgt.ctypes.data_as(fp), mask.ctypes.data_as(fp),
+                icov.ctypes.data_as(fp), s0.ctypes.data_as(fp), 1]
+        args += [None] * 4 if srch is None else [srch[0].ctypes.data_as(ip), srch[1].ctypes.data_as(fp), srch[2].ctypes.data_as(fp), srch[3].ctypes.data_as(fp)]
+        args += [ctypes.byref(l2), ctypes.byref(l), g.ctypes.data_as(fp), ext.ctypes.data_as(fp), win.ctypes.data_as(ip)]
+        lib.oracle_sq_loss_grad_state(*args)
+        return g, win, ext
+
+    def run(mode):
+        p = p0.copy(); m = np.zeros(9, np.float32); v = np.zeros(9, np.float32)
+        out = np.zeros((200, 9), np.float32)
+        for it in range(200):
+            st, srch = forward(p, mode)
+            g, _, _ = grad(p, st, srch)
+            lib.oracle_adam_step(p.ctypes.data_as(fp), m.ctypes.data_as(fp), v.ctypes.data_as(fp), g.ctypes.data_as(fp), it + 1, 9,
+                                 ctypes.c_double(0.01), ctypes.c_double(0.1))
+            out[it] = p
+        return out
+    rel = lambda a, b: float(np.max(np.abs(a.astype(np.float64) - b) / np.maximum(np.abs(b.astype(np.float64)), 1e-3)))
+    same = lambda a, b: bool(np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32)))
+    res = {}
+    for mode in (0, 1, 2):
+        tr = run(mode)
+        if mode == 0:      # H0 is the oracle's own fit: same bits as oracle_sq_fit
+            fin, _, _ = o.fit(p0, P, tgt, mask, cls)
+            assert same(fin, tr[-1]), "H0 is not oracle_sq_fit"
+        diff = np.nonzero((tr.view(np.uint32) != ref.view(np.uint32)).any(1))[0]
+        res[mode] = (int(diff[0]) + 1 if len(diff) else 0, rel(tr[-1], ref[-1]))      # 1-based first step after which the parameters differ; 0 = never
+    # ---- what differs AT the first differing step of the oracle's own run (the state before it is the reference's, bit for bit) ----
+    cause = ""
+    t0 = res[0][0]
+    if t0:
+        p = ref_before[t0 - 1].copy()
+        st0, _ = forward(p, 0); st1, _ = forward(p, 1); st2, sr2 = forward(p, 2)
+        g0, w0, e0 = grad(p, st0, None); g1, w1, e1 = grad(p, st1, None); g2, _, _ = grad(p, st2, sr2)
+        if not same(g0, g1):
+            cause += "A"      # the transcendentals of the points (MKL VML / Sleef in the reference, glibc here) change the gradient's bits
+        if not same(g1, g2):
+            cause += "B"      # the projection (MKL sgemm against the k-ordered fma chain) does
+        if not same(g2, ref_g[t0 - 1]):
+            cause += "C"      # with the reference's own points, extents and winners: the gradient's summation order (autograd) does
+    # ---- teacher-forced rates along the reference's trajectory: how often does each part inject a last-bit difference? -----------
+    nA = nB = nC = nW = 0
+    for it in range(0, 200, 4):
+        p = ref_before[it].copy()
+        st0, _ = forward(p, 0); st2, sr2 = forward(p, 2)
+        g1, w1, e1 = grad(p, st2, None); g2, _, _ = grad(p, st2, sr2)
+        nA += not same(st0[9 + 14 * N:], st2[9 + 14 * N:])
+        nW += not np.array_equal(w1, sr2[0])
+        nB += not same(g1, g2)
+        nC += not same(g2, ref_g[it])
+    return ci, F, res, cause, (nA / 50.0, nW / 50.0, nB / 50.0, nC / 50.0)
+
+
+def main():
+    z = np.load(os.path.join(HERE, "sq_survey.npz"))
+    n = int(z["n_cases"])
+    order = sorted(range(n), key=lambda i: -int(z["views"][i]))
+    with Pool(7) as pool:
+        out = pool.map(_one, order, chunksize=1)
+    t = np.zeros((n, 3), np.int32); e = np.zeros((n, 3)); cause = [""] * n; rates = np.zeros((n, 4))
+    for ci, F, res, c, r in out:
+        for mode in (0, 1, 2):
+            t[ci, mode], e[ci, mode] = res[mode]
+        cause[ci] = c; rates[ci] = r
+    np.savez_compressed(os.path.join(HERE, "sq_divergence.npz"), first_param_step=t, final_dev=e, cause=np.array(cause), rates=rates,
+                        views=z["views"], modes=np.array(["H0 oracle", "H1 torch transcendentals", "H2 torch transcendentals + projection"]),
+                        rate_names=np.array(["points differ", "a winner differs (given the reference's points)",
+                                             "projection changes the gradient's bits", "summation order changes the gradient's bits"]))
+    print("# problem views | H0: first differing step, what differs there (A transcendentals, B projection, C summation order), final e"
+          " | H1 (reference's transcendentals): step, e | H2 (+ its projection): step, e | teacher-forced share of steps with a difference: points, winners, B, C")
+    for ci in range(n):
+        print("%2d %3d | %3d %-3s %.2e | %3d %.2e | %3d %.2e | %.2f %.2f %.2f %.2f" % (
+            ci, z["views"][ci], t[ci, 0], cause[ci] or "-", e[ci, 0], t[ci, 1], e[ci, 1], t[ci, 2], e[ci, 2], *rates[ci]))
+    for mode, name in enumerate(("H0", "H1", "H2")):
+        print("# %s: bit-identical to the reference through all 200 steps on %d of %d, final e <= 1e-4 on %d" % (
+            name, int((t[:, mode] == 0).sum()), n, int((e[:, mode] <= 1e-4).sum())))
+    for c in "ABC":
+        print("# %s among the differences at the first differing step: %d of %d problems" % (c, sum(c in x for x in cause), sum(bool(x) for x in cause)))
+
+
+if __name__ == "__main__":
+    main()

@@ -6,6 +6,7 @@ from PIL import Image
 from odam_amd import associator, detector, synth, transforms, weights
 from odam_amd.processor import OdamProcess
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import scene_weights
 DEV = "cuda:0"
 SEQ = dict(n=40, h=256, w=320, seed=11)

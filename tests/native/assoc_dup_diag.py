@@ -3,6 +3,7 @@ import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 from odam_amd import _lib, associator, weights
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import scene_weights
 DEV = "cuda:0"
 z = np.load(os.path.join(ROOT, "tests/golden/assoc.npz"))

@@ -6,6 +6,7 @@ from PIL import Image
 from odam_amd import associator, detector, synth, transforms, weights, merge
 from odam_amd.processor import OdamProcess
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import scene_weights
 from conftest import rel_err
 z = np.load(os.path.join(ROOT, "tests/golden/e2e.npz"))

@@ -3,6 +3,7 @@ through OdamProcess.process_frame with the scene association weights; cProfile +
 import os, sys, time, cProfile, pstats
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import scene_weights
 from odam_amd import associator, detector, sq, synth, weights
 from odam_amd.processor import OdamProcess, detection_array

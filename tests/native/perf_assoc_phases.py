@@ -2,6 +2,7 @@
 import os, sys, time
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 import scene_weights
 from odam_amd import associator, detector, sq, synth, weights, processor
 from odam_amd.processor import OdamProcess, detection_array

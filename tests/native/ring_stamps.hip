@@ -15,7 +15,7 @@
 #include <random>
 #include <vector>
 
-struct Shape { const char* name; int B, H, W, Cin, Cout, k, pad; };
+struct Shape { const char* name; int B, H, W, Cin, Cout, k, pad, res; };
 
 static unsigned short to_bf16(float v) { unsigned u; memcpy(&u, &v, 4); return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
 
@@ -25,7 +25,8 @@ int main(int argc, char** argv) {
     const Shape shapes[] = {{"l3.c2", 32, 50, 67, 256, 256, 3, 1}, {"l4.c2", 32, 25, 34, 512, 512, 3, 1},
                             {"l3.c1", 32, 50, 67, 1024, 256, 1, 0}, {"l4.c1", 32, 50, 67, 1024, 512, 1, 0},
                             {"l2.c2", 32, 100, 134, 128, 128, 3, 1}, {"l2.c1", 32, 100, 134, 512, 128, 1, 0},
-                            {"l1.c2", 32, 200, 267, 64, 64, 3, 1}, {"l3.c3", 32, 50, 67, 256, 1024, 1, 0}};
+                            {"l1.c2", 32, 200, 267, 64, 64, 3, 1}, {"l3.c3", 32, 50, 67, 256, 1024, 1, 0},
+                            {"l3.c3+res", 32, 50, 67, 256, 1024, 1, 0, 1}, {"l4.c3+res", 32, 25, 34, 512, 2048, 1, 0, 1}, {"l2.ds", 32, 100, 134, 256, 512, 1, 0, 0}};
     std::mt19937 rng(1);
     std::normal_distribution<float> nd(0.f, 1.f);
     for (const Shape& s : shapes) {
@@ -36,7 +37,8 @@ int main(int argc, char** argv) {
             for (int k = 0; k < K; k++) w[(size_t)n * Kpad + k] = nd(rng) / sqrtf((float)K);
         std::vector<unsigned short> w3((size_t)s.Cout * Kpad * 3);
         odam_cg::split3_filters(w.data(), s.Cout, Kpad, w3.data());
-        float *dx, *dw, *dy; void* dw3;
+        float *dx, *dw, *dy, *dres = nullptr; void* dw3;
+        if (s.res) { hipMalloc(&dres, (size_t)M * s.Cout * 4); hipMemset(dres, 0x3c, (size_t)M * s.Cout * 4); }
         hipMalloc(&dx, x.size() * 4); hipMalloc(&dw, w.size() * 4); hipMalloc(&dy, (size_t)M * s.Cout * 4); hipMalloc(&dw3, w3.size() * 2);
         if (bf) {
             std::vector<unsigned short> xb(x.size()), wb(w.size());
@@ -50,7 +52,7 @@ int main(int argc, char** argv) {
         }
         hipMemcpy(dw3, w3.data(), w3.size() * 2, hipMemcpyHostToDevice);
         odam_cg::ConvGemmArgs a{};
-        a.A = dx; a.Wt = dw; a.Wt3 = dw3; a.C = dy; a.B = s.B; a.H = s.H; a.W = s.W; a.Cin = s.Cin;
+        a.A = dx; a.Wt = dw; a.Wt3 = dw3; a.C = dy; a.res = dres; a.B = s.B; a.H = s.H; a.W = s.W; a.Cin = s.Cin;
         a.log2Cin = 31 - __builtin_clz(s.Cin); a.Ho = s.H; a.Wo = s.W; a.Cout = s.Cout; a.KH = a.KW = s.k; a.stride = 1; a.pad = s.pad;
         a.Kpad = Kpad; a.relu = 1; a.M = M; a.ldc = s.Cout; a.dtype = bf ? 1 : 0; a.k_order = (s.k > 1 && s.Cin % (bf ? 64 : 32) == 0) ? 1 : 0;
         if (bf) a.Wt3 = nullptr;
@@ -73,9 +75,11 @@ int main(int argc, char** argv) {
         const double tiles = (double)z[4];   // wave-k-tiles
         printf("  | per wave and k-tile: barrier %6.0f  vmcnt %6.0f  first half %6.0f  rest %6.0f  (sum %6.0f cycles; %llu waves)",
                z[0] / tiles, z[1] / tiles, z[2] / tiles, z[3] / tiles, (z[0] + z[1] + z[2] + z[3]) / tiles, z[5]);
+        if (z[6] || z[7]) printf("  | per wave and tile: entry -> loop %6.0f  loop %7.0f  loop end -> last store issued %6.0f cycles", (double)z[6] / z[5],
+                                 (double)(z[0] + z[1] + z[2] + z[3]) / z[5], (double)z[7] / z[5]);
 #endif
         printf("\n");
-        hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dw3);
+        hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dw3); if (dres) hipFree(dres);
     }
     return 0;
 }

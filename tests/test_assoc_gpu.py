@@ -171,6 +171,42 @@ def test_lost_persistent_launch_is_rerun_and_not_sticky(golden):
     a.close()
 
 
+def test_row_partitioned_kernel_checks_its_placement(golden):
+    """ADVICE (round 4): gnn_rowpart_kernel exchanges its row-wise stages inside one XCD and is right only if the 32 workgroups of a
+    group run behind one L2.  Every launch now compares the hardware XCC ids inside each group: (1) on this box the check passes on
+    every launch (no lost launch over 40 frames: the mapping the kernel was built on holds here); (2) a forced mismatch abandons the
+    launch, the frame is re-run through the launch sequence with the same result, and after three in a row the handle stays on the
+    launch sequence."""
+    from odam_amd import _lib, associator, weights
+    z = golden("assoc.npz")
+    cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
+    a = associator.Associator(cfg, max_tracks=64, device=DEV)
+    a.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0))
+    assert _lib.config()["assoc.persist"] == 2
+    L, h = _lib.lib(), a._handle()
+    tr, de, Zr = z["c0_tracks"], z["c0_det"], z["c0_Z"]
+    T, n = Zr.shape[0] - 1, Zr.shape[1] - 1
+    data = {"tracks": torch.from_numpy(tr), "detections": torch.from_numpy(de), "valid_list": [(T, n)]}
+    good = a(data, 0.1, eval_only=True)
+    for _ in range(40):
+        again = a(data, 0.1, eval_only=True)
+    assert a.lost_launches == 0, "a group of the row-partitioned kernel straddles XCDs on this box"
+    assert np.array_equal(again["pred"][0][0].cpu().numpy(), good["pred"][0][0].cpu().numpy())
+    seq = a.assignment(torch.from_numpy(tr), torch.from_numpy(de), T, n, sequence=True).cpu().numpy()
+    _lib.check(L.odam_assoc_debug_misplace(h, 1), "misplace")
+    on = ctypes.c_int()
+    for k in range(3):
+        out = a(data, 0.1, eval_only=True)
+        assert a.lost_launches == k + 1
+        assert np.array_equal(out["pred"][0][0].cpu().numpy(), seq)
+        assert np.array_equal(out["matches"][0], good["matches"][0])
+    _lib.check(L.odam_assoc_info(h, ctypes.byref(on), None, None), "info")
+    assert on.value == 0 and getattr(a, "persistent_given_up", False)      # three in a row: the launch sequence from here on
+    out = a(data, 0.1, eval_only=True)
+    assert a.lost_launches == 3 and np.array_equal(out["pred"][0][0].cpu().numpy(), seq)
+    a.close()
+
+
 def test_workspace_growth_respects_native_limit(golden):
     """growth past max_tracks builds a larger handle (capped at the native 1024); more tracks than that is a clear error and
     leaves the old handle usable"""

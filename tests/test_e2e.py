@@ -48,6 +48,9 @@ def test_whole_pipeline_matches_the_reference_run(golden, measured):
     from conftest import rel_err
     from test_sq_gpu import check_against_spread
     import e2e_lib
+    import os, sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
     import scene_weights
     z = golden("e2e.npz")
     seq = synth.make_sequence(**SEQ)
@@ -62,7 +65,7 @@ def test_whole_pipeline_matches_the_reference_run(golden, measured):
     # Association, frame by frame: our assignment matrix against the reference's own (e2e.npz Z<i>) in every probability,
     # and the decisions taken from it -- Hungarian matches, the 0.1 match threshold, the 0.8 score threshold on matches
     # and on the dustbin row -- against the decisions the reference's matrix gives.  Our own matrix drives the loop.
-    # (The association weights were re-tuned for this: tests/scene_weights.py explains how round 2's first set left
+    # (The association weights were re-tuned for this: tools/scene_weights.py explains how round 2's first set left
     # every frame's matching on an ulp-level tie; with the present set the smallest decision margin of the reference run is
     # 2.3e-4 in probability.)
     plain = net.assignment

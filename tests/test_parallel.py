@@ -122,7 +122,7 @@ def test_allgather_gloo_world_of_8():
     assert len(res) == 8 and all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
 
 
-def _chain(z, oracle, chunk):
+def _chain(z, oracle, chunk, overlap=None):
     """odam_amd.pipeline.run_scene over the canned-detection sequence of tests/golden/process_tracks.npz with the oracle-backed
     test doubles (tests only): returns everything a rank ends up holding"""
     import sys
@@ -144,7 +144,8 @@ def _chain(z, oracle, chunk):
         calls.append((f0, f1))
         return [np.asarray(z[f"det{ids[f]}"], np.float64).reshape(-1, 79) for f in range(f0, f1)]
     stages = {}
-    out = pipeline.run_scene(proc, len(ids), ids, z["scene_T_wcs"], detect=detect, chunk=chunk, device="cpu", stages=stages)
+    out = pipeline.run_scene(proc, len(ids), ids, z["scene_T_wcs"], detect=detect, chunk=chunk, device="cpu", stages=stages, overlap=overlap)
+    assert bool(stages.get("overlapped", False)) == (bool(chunk) and chunk < len(ids) and (overlap is True or (overlap is None and dist.is_initialized() and dist.get_world_size() > 1)))
     first = stages["first_pass"]
     cat = lambda ts: np.concatenate([np.asarray(t).reshape(-1, 82) for t in ts])
     return {"tracks": cat(proc.tracks), "lens": np.array([len(t) for t in proc.tracks]), "calls": np.array(calls),
@@ -162,6 +163,18 @@ def _worker_chain(rank, ws, port, chunk, q):
     res = _chain(np.load(os.path.join(GOLDEN, "process_tracks.npz")), Oracle(), chunk)
     q.put((rank, res))
     dist.destroy_process_group()
+
+
+def test_run_scene_association_overlapped_with_detection_is_the_same_chain(oracle, golden):
+    """pipeline.run_scene(overlap=True): detection + gather of chunk i + 1 on a worker thread under the association of chunk i
+    (src/processor.py:306-345 is the loop that runs meanwhile) returns what the serial chain returns, bit for bit, and asks the
+    detector for the same spans in the same order."""
+    z = golden("process_tracks.npz")
+    serial = _chain(z, oracle, 16, overlap=False)
+    over = _chain(z, oracle, 16, overlap=True)
+    for k in serial:
+        assert serial[k].shape == over[k].shape, k
+        assert np.array_equal(np.ascontiguousarray(serial[k]).view(np.uint8), np.ascontiguousarray(over[k]).view(np.uint8)), k
 
 
 @pytest.mark.parametrize("chunk", [0, 16])
