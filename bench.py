@@ -58,6 +58,7 @@ def parity_block():
         with open(os.path.join(REPO, "tests", "golden", "sq_survey_table.txt")) as f:
             tail = [l[1:].strip() for l in f.read().splitlines() if l.startswith("#")][1:]
         out["sq_end_state_survey"] = tail
+        out["sq_first_divergence"] = [l for l in tail if l.startswith(("first divergence", "with the reference's OWN"))] or None
         out["sq_end_state_note"] = ("free-running 200-step fits of 46 problems against the reference's own fits: NOT all within 1e-4 -- the fit "
                                     "is a chain of arg-extreme decisions and the reference itself moves by more than 1e-4 under 1-2 ulp nudges "
                                     "of its input (s) and across ATen's own CPU dispatch levels; the gate is e <= max(1e-4, 3 s) per problem "

@@ -444,6 +444,17 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             }
         };
         dma_tile(0, 0); dma_tile(1, 1);
+#if CG_HACK      // timing experiments only (tests/native/ring_stamps.hip -DCG_HACK=1 / 3): results are WRONG.  1: no epilogue at all (the main loop's own
+                 // time); 3: no epilogue, but its memory traffic -- one 16-byte residual load and one 16-byte store per lane and fourth block, the
+                 // tile's own rows -- issued INSIDE the main loop: what a tile costs if the previous tile's epilogue rode under its products
+        const size_t hk_off = ((size_t)m0 * a.ldc + n0) * sizeof(float);
+        const __amdgpu_buffer_rsrc_t hk_res = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(a.res ? a.res : a.C)) + hk_off, 0, a.res ? (int)OOB_VOFF : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t hk_out = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.C) + hk_off, 0, (int)OOB_VOFF, 0x00020000);
+        u32x4 hk_l[8] = {};
+        constexpr int HK_LPR = (BN / WN) / 4, HK_RPI = 64 / HK_LPR;
+        const int hk_row0 = wm * (BM / WM) + lane / HK_LPR;
+        const unsigned hk_col = (unsigned)(wn * (BN / WN) + (lane % HK_LPR) * 4) * 4u;
+#endif
 #define ODAM_MM16(accv, x, y) accv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
 #if CG_STAMP
         unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = __builtin_readcyclecounter();
@@ -525,6 +536,16 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
                     const int part = dpart < 2 * A_LD ? (dpart >> 1) : A_LD + (dpart - 2 * A_LD) % B3_HI;
                     dma_part16(2 * kp + 2 + half_, (s0 ^ 2) + half_, part);
                 }
+#if CG_HACK & 2
+                if (b % 4 == 0) {
+                    const int step = kp * (NBLK / 4) + b / 4;      // 32 steps = the tile's 32 KB per wave, both ways
+                    const int r = hk_row0 + (step >> 3) * 16 + (step & 7) * HK_RPI;
+                    const unsigned vo = (step < (BM / WM / 16) * (16 / HK_RPI) && m0 + r < a.M) ? (unsigned)r * (unsigned)a.ldc * 4u + hk_col : OOB_VOFF;
+                    asm volatile("" :: "v"(hk_l[(b / 4) % 8]));      // the load of the pair before is consumed here
+                    __builtin_amdgcn_raw_buffer_store_b128(hk_l[(b / 4) % 8], hk_out, vo, 0, 0);
+                    hk_l[(b / 4) % 8] = __builtin_amdgcn_raw_buffer_load_b128(hk_res, vo, 0, 0);
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);      // (without the fence: +2 % time; static priority for waves 4-7: no change)
                 if (b == NBLK / 2 - 1) CG_STAMP_AT(2);
             }
@@ -532,8 +553,8 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
 #if CG_STAMP
         CG_STAMP_AT(3);
         const unsigned long long st_loop1 = __builtin_readcyclecounter();
-        auto stamps_out = [&](unsigned long long t_end) {      // at the very end of the kernel
-            if (lane == 0) {
+        auto stamps_out = [&](unsigned long long t_end) {      // at the very end of the kernel; one workgroup in 64 reports (2 M atomics on eight
+            if (lane == 0 && (blockIdx.x & 63) == 0) {         // words would take longer than the layer: the round-5 stamps of every wave did)
                 for (int i = 0; i < 4; i++) atomicAdd(&g_stamps[i], st_acc[i]);
                 atomicAdd(&g_stamps[4], (unsigned long long)nk);
                 atomicAdd(&g_stamps[5], 1ull);
@@ -544,6 +565,19 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         if constexpr (FUSE != 0) stamps_out(st_loop1);
 #endif
 #undef ODAM_MM16
+#if CG_HACK
+        if constexpr (FUSE == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; i++)
+#pragma unroll
+                for (int j = 0; j < NJ; j++) asm volatile("" :: "v"(c16[i][j]));
+#if CG_HACK & 2
+#pragma unroll
+            for (int i = 0; i < 8; i++) asm volatile("" :: "v"(hk_l[i]));
+#endif
+            return;
+        }
+#endif
         if constexpr (FUSE != 0 || POOLABLE) __syncthreads();      // (the plain epilogue below has its own, behind its first residual requests)
         if constexpr (FUSE == 1) { fused_second(a, c16, smem, lds_base, m0, wave, lane); return; }
         if constexpr (FUSE == 2) { fused_chain(a, c16, smem, lds_base, m0, wave, lane); return; }

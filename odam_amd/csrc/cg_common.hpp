@@ -42,6 +42,9 @@ static __device__ unsigned long long g_tail_stamps[8];
 #else
 #define CG_TSTAMP(i) do { } while (0)
 #endif
+#ifndef CG_HACK
+#define CG_HACK 0      // timing experiments of the 16x16x32 loop (cg_big.hpp); 0 in every product build
+#endif
 #ifndef CG_ABLATE
 #define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores, 16 no first-tile load
 #endif

@@ -5,7 +5,7 @@ The reference's step (likojack/ODAM src/super_quadric/sq_libs.py:455-472) has th
 without knowing the arithmetic behind them:
   A  transcendentals of the surface points (sq_libs.py:577-595, learnable_primitives/sampling.py:596-615): torch.cos / sin / exp / log
      are MKL VML calls in this torch build (vsCos, vsSin, vsExp, vsLn: closed source), abs(x) ** e is Sleef_powf16_u10 for the vector
-     body and glibc powf for the scalar tail of 8 (probe: /tmp-free, see PROBE below); the oracle evaluates glibc's cosf / sinf / powf / expf / logf
+     body and glibc powf for the scalar tail of 8 (tests/golden/probe_torch_math.py); the oracle evaluates glibc's cosf / sinf / powf / expf / logf
   B  the projection  homog(pts) @ Ms^T  (sq_libs.py:398): an MKL sgemm;   the oracle: one k-ordered fma chain per value
   C  the gradient: autograd's reduction orders (sum over 1000 points, over F views) against the oracle's closed form + fixed tree
 The free-running fit is re-run with the oracle's A / B replaced by the reference's own torch operations, one after the other:

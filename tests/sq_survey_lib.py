@@ -63,14 +63,35 @@ def check(rows):
     assert sum(r["e"] <= 1e-4 for r in rows) >= 8          # tracked to the last step on these
 
 
-def table(rows):
+def divergence_lines(div):
+    """summary lines of tests/golden/sq_divergence.npz (make_sq_divergence.py): what makes the free-running oracle leave the reference's
+    trajectory, measured by substituting the reference's own torch operations for the oracle's, part by part"""
+    t, e, cause = div["first_param_step"], div["final_dev"], [str(c) for c in div["cause"]]
+    n = len(cause)
+    has = lambda c: sum(c in x for x in cause)
+    return ["first divergence (first step after which the nine parameters differ from the reference's in any bit: step %d ... %d, median %d): "
+            "A = the points' transcendentals (torch.cos / sin / exp / log are MKL VML calls in this torch build -- closed source --, abs(x) ** e "
+            "is Sleef_powf16_u10 + glibc powf for the scalar tail; the oracle: glibc) change the gradient's bits there in %d of %d problems, "
+            "B = the projection (MKL sgemm vs the oracle's k-ordered fma chain) in %d, C = autograd's summation order in %d" % (
+                t[:, 0].min(), t[:, 0].max(), int(np.median(t[:, 0])), has("A"), n, has("B"), has("C")),
+            "with the reference's OWN transcendentals in the oracle (H1): bit-identical through 200 steps on %d of %d, e <= 1e-4 on %d; with "
+            "its projection too (H2): e <= 1e-4 on %d (the oracle alone, H0: %d) -- B is exact already, A and C each suffice to move the last "
+            "bits at the first step, and A is not restatable" % (int((t[:, 1] == 0).sum()), n, int((e[:, 1] <= 1e-4).sum()),
+                                                                  int((e[:, 2] <= 1e-4).sum()), int((e[:, 0] <= 1e-4).sum()))]
+
+
+def table(rows, div=None):
     have_d = bool(rows and rows[0].get("d"))
     out = ["# problem views | e (ours vs reference)  s (reference vs its own ulp-nudged runs, max of 10)  rank | loss: eL sL jitter | box IoU: ours, reference's worst nudge"
-           + (" | d: the reference re-run on ATen's scalar (default) CPU kernels vs the stored (AVX-512) run" if have_d else "")]
+           + (" | d: the reference re-run on ATen's scalar (default) CPU kernels vs the stored (AVX-512) run" if have_d else "")
+           + (" | first divergence: step, cause (A transcendentals: MKL VML / Sleef, B projection: MKL sgemm, C autograd summation order), "
+              "e with the reference's own transcendentals" if div is not None else "")]
     for r in rows:
         out.append("%2d %3d | %.2e %.2e %.1f | %.2e %.2e %.2e | %.4f %.4f" % (r["i"], r["views"], r["e"], r["s"], r["rank"], r["eL"], r["sL"],
                                                                            r["fl"], r["iou"], r["siou"])
-                   + (" | %.2e" % r["d"]["default"] if have_d else ""))
+                   + (" | %.2e" % r["d"]["default"] if have_d else "")
+                   + (" | %3d %-3s %.2e" % (div["first_param_step"][r["i"], 0], str(div["cause"][r["i"]]) or "-", div["final_dev"][r["i"], 1])
+                      if div is not None else ""))
     n = len(rows)
     out.append("# e <= 1e-4: %d of %d; e <= max(1e-4, s): %d; reference spread s > 1e-4: %d; mean rank %.2f" % (
         sum(r["e"] <= 1e-4 for r in rows), n, sum(r["e"] <= max(1e-4, r["s"] * (1 + 1e-3)) for r in rows),
@@ -80,4 +101,6 @@ def table(rows):
                    "scalar kernels within 1e-4 on %d of %d (max %.2e), AVX2 identical on %d of %d -- ours within 1e-4 on %d of %d" % (
                        sum(r["d"]["default"] <= 1e-4 for r in rows), n, max(r["d"]["default"] for r in rows),
                        sum(r["d"]["avx2"] == 0 for r in rows), n, sum(r["e"] <= 1e-4 for r in rows), n))
+    if div is not None:
+        out += ["# " + l for l in divergence_lines(div)]
     return "\n".join(out) + "\n"
