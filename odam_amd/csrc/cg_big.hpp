@@ -106,10 +106,6 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
 #if CG_STAMP
     const unsigned long long st_entry = __builtin_readcyclecounter();      // g_stamps[6]: entry -> main loop, [7]: main loop's end -> last store issued
 #endif
-    if (a.stagger > 0 && bid < 256 && ((bid >> 3) & 1)) {      // cg.stagger: every other CU of an XCD starts its first tile late
-        const unsigned long long t0 = __builtin_readcyclecounter(), dt = (unsigned long long)a.stagger << 10;
-        while (__builtin_readcyclecounter() - t0 < dt) __builtin_amdgcn_s_sleep(32);
-    }
     {
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
@@ -626,6 +622,10 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         {
             constexpr int WROWS = BM / WM, WCOLS = BN / WN, EP_LD = WCOLS + 4;
             static_assert(NW * 16 * EP_LD * 4 <= NST * STAGE, "epilogue slabs fit the ring");
+            // (opaque copy of the thread id: nothing of the epilogue's lane arithmetic is computed ahead of the K loop and carried through it)
+            int tid_e = tid;
+            asm volatile("" : "+v"(tid_e));
+            const int lane = tid_e & 63, wave = tid_e >> 6, wm = wave / WN, wn = wave % WN, r16 = lane & 15, kq = lane >> 4;
             float* Ep = smem + wave * (16 * EP_LD);
             constexpr int LPR = WCOLS / 4, RPI = 64 / LPR, NIT = 16 / RPI;
             const int c4e = (lane % LPR) * 4;
@@ -1090,7 +1090,6 @@ template <int MODE, int BN, int NST, int NTH = 512>
 static int launch_big(const ConvGemmArgs& a_in, hipStream_t stream) {
     ConvGemmArgs a = a_in;
     a.s1_window = (MODE == 0 && NTH == 512) ? g_s1_window : 0;
-    a.stagger = odam_cfg::get(odam_cfg::CG_STAGGER);
     constexpr int bytes = big_lds_bytes<MODE, BN, NST, NTH>();
     static const bool attr_ok = [] {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, BN, NST, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;

@@ -284,6 +284,8 @@ __device__ __forceinline__ void epilogue2(const ConvGemmArgs& a, floatx16 (&acc)
     constexpr int WROWS = BM / WM, WCOLS = BN / WN;
     constexpr int CPL = BF16 ? 8 : 4, ESZ = BF16 ? 2 : 4;
     constexpr int LPR = WCOLS / CPL, RPI = 64 / LPR, NIT = (32 / RPI) > 0 ? 32 / RPI : 1;
+    // (opaque copies: nothing of the epilogue's lane arithmetic is to be computed ahead of the K loop and carried through it)
+    asm volatile("" : "+v"(lane), "+v"(wave), "+v"(wm), "+v"(wn));
     const int half = lane >> 5;
     float* Ep = smem + wave * (32 * WCOLS);
     const int c0 = (lane % LPR) * CPL;

@@ -12,7 +12,6 @@ static int launch_fused_bf16_as(const ConvGemmArgs& a, hipStream_t stream) {
     if (!attr_ok) return odam_fail(2, "conv_gemm: cannot raise the dynamic LDS limit");
     ConvGemmArgs b = a;
     b.s1_window = g_s1_window;
-    b.stagger = odam_cfg::get(odam_cfg::CG_STAGGER);
     hipLaunchKernelGGL((conv_gemm_big_kernel<0, P, 4, 512, FUSE>), dim3((a.M + 255) / 256), dim3(512), FUSE_LDS_BYTES, stream, b);
     ODAM_HIP(hipGetLastError());
     return 0;

@@ -4,9 +4,7 @@
 namespace odam_cg {
 
 template <int MODE>
-static int launch_big_fused_as(const ConvGemmArgs& a_in, hipStream_t stream) {
-    ConvGemmArgs a = a_in;
-    a.stagger = odam_cfg::get(odam_cfg::CG_STAGGER);
+static int launch_big_fused_as(const ConvGemmArgs& a, hipStream_t stream) {
     static const bool attr_ok = [] {
         return hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, 64, 4, 512, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&
                hipFuncSetAttribute((const void*)conv_gemm_big_kernel<MODE, 64, 4, 512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, FUSE_LDS_BYTES) == hipSuccess &&

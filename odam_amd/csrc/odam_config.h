@@ -36,8 +36,6 @@ enum Key {
     ASSOC_SK_FAST,  // Sinkhorn on one wavefront (<= 128 rows, <= 32 columns; assoc.hip sinkhorn_wave_kernel): 1 (default) scaling factors absorbed
                     // into the potentials every 10 iterations, restarting with 1 and then in log space if a factor leaves its range;
                     // 2 / 3 = start at that rung (tests); 0 = the sixteen-wave log-space kernel
-    CG_STAGGER,     // experiment: ring-kernel workgroups of the first round on every other compute unit start `value` x 1024 shader cycles late
-                    // (tile phases of neighbouring CUs then alternate: one multiplies while the other streams its epilogue).  Default 0
     N_KEYS
 };
 int get(Key k);

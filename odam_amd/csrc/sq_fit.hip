@@ -109,13 +109,20 @@ struct Lds {
     float* tth;     // [2][TABN] theta, curve point x, y of every dyadic parameter position
     float* tcx;
     float* tcy;
+    float* tct;     // [2][TABN] the per-entry factors of phase C at every dyadic position (entry_factors: cos, sin, signed powers of the
+    float* tst;     //           zero-nudged angle), so that a buffer slot filled from the table needs no transcendental of its own
+    float* tfc;
+    float* tfs;
+    float* tfx;     // [TABN]    curve 0: fexp(cos theta, e1) of the un-nudged angle (the CDF term's factor, sampling.cpp:141-146)
+    float* rtab;    // [2][512]  split ratio dA / (dA + dB) of every dyadic node (heap order: node i of depth d, position j = 2^d - 1 + j)
+    int* bufq;      // [2][BUFP] dyadic position that filled a buffer slot, -1: an arc deeper than the table did
     float* vgrad;   // [pn][9]
     float* lterm;   // [views][4], only when the loss is logged
 };
 
 __host__ __device__ inline size_t lds_words(int rows, int loss_rows) {
     return 12 * 6 + 8 + 8 + 16 + 144 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
-           (size_t)rows * 9 + (size_t)loss_rows * 4;
+           4 * 2 * 520 + 520 + 2 * 512 + 2 * BUFP + (size_t)rows * 9 + (size_t)loss_rows * 4;
 }
 
 __device__ inline Lds carve(float* base, int pn) {
@@ -144,6 +151,13 @@ __device__ inline Lds carve(float* base, int pn) {
     L.tth = w; w += 2 * 520;
     L.tcx = w; w += 2 * 520;
     L.tcy = w; w += 2 * 520;
+    L.tct = w; w += 2 * 520;
+    L.tst = w; w += 2 * 520;
+    L.tfc = w; w += 2 * 520;
+    L.tfs = w; w += 2 * 520;
+    L.tfx = w; w += 520;
+    L.rtab = w; w += 2 * 512;
+    L.bufq = (int*)w; w += 2 * BUFP;
     L.vgrad = w; w += (size_t)pn * 9;
     L.lterm = w;
     return L;
@@ -242,7 +256,15 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
 #else
 #define STAMP(k) do { } while (0)
 #endif
+    const int tid_k = tid;
     for (int it = 0; it <= A.n_iters; ++it) {
+        // Lane constants are re-derived from an opaque copy of the thread id in every step: left to itself the compiler computes every
+        // lane-dependent invariant of the step body ONCE, before this loop (per-level lane masks, table addresses, ...), and then keeps
+        // them in scratch -- stored once, reloaded every step by 1024 threads of up to 240 workgroups in lock step.
+        int tid_i = tid_k;
+        asm volatile("" : "+v"(tid_i));
+        const int tid = tid_i, lane = tid & 63;
+        const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
         // ---------------- A: shape scalars ------------------------------------------------------
         if (tid == 0) L.shape[0] = cosf_(L.p[3]);
         else if (tid == 1) L.shape[1] = sinf_(L.p[3]);
@@ -254,10 +276,8 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         }
         __syncthreads();
         STAMP(0);
-        const Shape S_ = load_shape(L.shape);
-        float p[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) p[k] = L.p[k];
+        // (the derived shape and the parameters are read from LDS where a phase needs them -- broadcast reads -- instead of sitting in 18
+        //  registers from here to the end of the step: those were spilled around every phase that inlines a transcendental)
 
         // ---------------- B: arc subdivision ------------------------------------------------------
         // curve 0: eta  (a1, a3, e1) from +pi/2 to -pi/2;  curve 1: omega (a1, a2, e2) from +pi to -pi.
@@ -271,7 +291,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         static_assert(TABN == 513 && NT >= 64, "table pass layout");
         for (int w = tid; w < 2 * (TABN - 1); w += NT) {
             const int c = w / (TABN - 1), q = w - c * (TABN - 1);
-            const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
+            const float a1 = L.shape[2], a2 = c ? L.shape[3] : L.shape[4], e = L.shape[5 + c];
             const float ta = c ? PI_F : PI_F / 2;
             float lo = ta, hi = -ta, th;
             if (q == 0) th = lo;
@@ -284,66 +304,162 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                     if (q < mq) { hq = mq; hi = th; } else { lq = mq; lo = th; }
                 }
             }
-            float cx, cy;
-            xy(th, a1, a2, e, cx, cy);
+            // xy(th, a1, a2, e) with its parts kept: the same cosine, sine and powers are the per-entry factors of phase C for a buffer
+            // slot that this position fills (entry_factors: sgn(x) |x|^e of the ZERO-NUDGED angle).  The one position with theta == 0 (the
+            // midpoint of either curve) takes its factors from 1e-6 and its curve point in closed form -- cos 0 = 1, sin 0 = 0, and
+            // powf_pos(1, e) = 1, powf_pos(0, e) = 0 exactly (glibc's table has the entry {1, 0}) -- so no lane evaluates anything twice
+            const bool z0 = th == 0.0f;
+            const float thf = z0 ? 1e-6f : th;
             const int t = c * TABN + q;
-            L.tth[t] = th; L.tcx[t] = cx; L.tcy[t] = cy;
-            if (q == 0) { L.tth[t + TABN - 1] = -ta; L.tcx[t + TABN - 1] = cx; L.tcy[t + TABN - 1] = -cy; }
+            // one transcendental at a time, every result stored as soon as it exists (the four inlined routines interleaved keep ~40 more
+            // registers alive than the 128 a 1024-thread workgroup has: their spill traffic of 16 partner workgroups meets in one XCD's L2)
+            L.tth[t] = th;
+            const float ect = cosf_(thf);
+            L.tct[t] = ect;
+            __builtin_amdgcn_sched_barrier(0);
+            const float pc = powf_pos(absf(ect), e);
+            const float fxc = z0 ? 1.0f : __builtin_copysignf(pc, ect);      // fexp(cos th)
+            L.tfc[t] = sgnf(ect) * pc;
+            L.tcx[t] = a1 * fxc;
+            if (c == 0) L.tfx[q] = fxc;
+            __builtin_amdgcn_sched_barrier(0);
+            const float est = sinf_(thf);
+            L.tst[t] = est;
+            __builtin_amdgcn_sched_barrier(0);
+            const float ps = powf_pos(absf(est), e);
+            const float fxs = z0 ? 0.0f : __builtin_copysignf(ps, est);      // fexp(sin th)
+            L.tfs[t] = sgnf(est) * ps;
+            L.tcy[t] = a2 * fxs;
+            if (q == 0) {      // the far end (theta = -ta): cosf_ is even, sinf_ and the signed powers are odd, exactly (read back: no register kept for it)
+                const int t1 = t + TABN - 1;
+                L.tth[t1] = -ta; L.tcx[t1] = L.tcx[t]; L.tcy[t1] = -L.tcy[t];
+                L.tct[t1] = L.tct[t]; L.tst[t1] = -L.tst[t]; L.tfc[t1] = L.tfc[t]; L.tfs[t1] = -L.tfs[t];
+                if (c == 0) L.tfx[TABN - 1] = L.tfx[0];
+            }
         }
-        if (tid < 6) L.cnt[tid] = (tid < 2) ? 1 : 0;
-        if (tid < 2) {   // roots: the whole parameter range, 199 interior slots starting at 1
-            QArc* root = &L.q[(tid * 2 + 0) * QCAP];
-            root->qa = 0; root->qb = TABN - 1; root->a.n = BUF - 2; root->a.off = 1;
+        if (tid < 6) L.cnt[tid] = 0;
+        if (tid < 2) {   // end points of the two buffers
             const float ta = tid ? PI_F : PI_F / 2;
             L.buf[tid * BUFP] = ta;
             L.buf[tid * BUFP + BUF - 1] = -ta;
+            L.bufq[tid * BUFP] = 0;
+            L.bufq[tid * BUFP + BUF - 1] = TABN - 1;
         }
         __syncthreads();
         STAMP(1);
+        // B2a: the split ratio dA / (dA + dB) of EVERY dyadic node down to depth 8 (2 x 511 of them, one per thread): it depends on the
+        // three table points only, not on how many slots reach the node (arc_split: the first three statements).
+        for (int w = tid; w < 2 * 511; w += NT) {
+            const int c = w / 511, i = w - c * 511;
+            const int d = 31 - __builtin_clz(i + 1), j = i + 1 - (1 << d);
+            const int qa = j << (9 - d), qb = qa + (1 << (9 - d)), qm = (qa + qb) >> 1;
+            const int t0 = c * TABN;
+            const float dA = dist(L.tcx[t0 + qa], L.tcy[t0 + qa], L.tcx[t0 + qm], L.tcy[t0 + qm]);
+            const float dB = dist(L.tcx[t0 + qm], L.tcy[t0 + qm], L.tcx[t0 + qb], L.tcy[t0 + qb]);
+            L.rtab[c * 512 + i] = dA / (dA + dB);
+        }
+        __syncthreads();
 #ifndef SQ_ABLATE_B
-        // B2: one wavefront per curve walks its levels with wave-level synchronisation only (no workgroup barrier
-        // per level: a level is ~200 nodes at most, 4 passes of 64 lanes); the other wavefronts wait at the
-        // barrier below.
+        // B2b: slot counts down the dyadic tree.  Round 4 walked the levels with a queue in LDS (a node's record, its table points, an
+        // atomic per child: four dependent LDS round trips per level, 6.9 us per step).  The tree has a FIXED shape: node j of depth d
+        // covers table positions [j 2^(9-d), (j + 1) 2^(9-d)], so lane j of one wavefront per curve owns node j of every depth d <= 6,
+        // hands (n, offset) to its children in lanes 2 j, 2 j + 1 with ONE shuffle per level, and walks depths 7 and 8 -- the four
+        // grandchildren of its depth-6 node -- alone.  Per node: nA = round(ratio (n - 1)), the slot nA + offset receives the node's
+        // midpoint theta, children (nA, offset) and (n - nA - 1, offset + nA + 1): arc_split's arithmetic on the same values, so the
+        // buffers come out bit for bit as before.  Arcs that still hold slots below depth 8 (strongly unbalanced curves) go to the
+        // queue and the level loop of round 4 (on-the-fly midpoints), which runs only then.
         if (wid < 2) {
             const int c = wid;
             const int t0 = c * TABN;
+            QArc* q0 = &L.q[(c * 2 + 0) * QCAP];
+            // every ratio and midpoint theta this lane can need, requested up front: node (d, lane) for d <= 6, its two depth-7 and four
+            // depth-8 descendants (one LDS round trip instead of one per level)
+            float rr[7], tt[7];
+#pragma unroll
+            for (int d = 0; d <= 6; d++) {
+                const int j = (lane < (1 << d)) ? lane : 0;
+                rr[d] = L.rtab[c * 512 + (1 << d) - 1 + j];
+                tt[d] = L.tth[t0 + (j << (9 - d)) + (1 << (8 - d))];
+            }
+            auto visit = [&](float r, float th, int qm, int n, int off, int& nl, int& ol, int& nr, int& orr) {
+                // a node holding n slots from offset off: fills its slot, returns the children's (n, offset); n <= 0: nothing
+                nl = 0; nr = 0; ol = off; orr = off;
+                if (n <= 0) return;
+                const int nA = (int)__builtin_roundf(r * (float)(n - 1));
+                L.buf[c * BUFP + nA + off] = th;
+                L.bufq[c * BUFP + nA + off] = qm;
+                nl = nA; ol = off; nr = n - nA - 1; orr = off + nA + 1;
+            };
+            int n = (lane == 0) ? BUF - 2 : 0, off = 1;
+#pragma unroll
+            for (int d = 0; d <= 6; d++) {
+                int nl, ol, nr, orr;
+                visit(rr[d], tt[d], (lane << (9 - d)) + (1 << (8 - d)), (lane < (1 << d)) ? n : 0, off, nl, ol, nr, orr);
+                if (d < 6) {      // children 2 j, 2 j + 1 read their parent's results from lane j: one shuffle (n, offset <= 200: a byte each)
+                    const int pk = __shfl(nl | (ol << 8) | (nr << 16) | (orr << 24), lane >> 1);
+                    n = ((lane & 1) ? (pk >> 16) : pk) & 0xff;
+                    off = ((lane & 1) ? (pk >> 24) : (pk >> 8)) & 0xff;
+                } else {          // depths 7 and 8 of this lane's depth-6 node, in the lane (their ratios and thetas: a second round trip)
+                    float r7[2], t7[2], r8[4], t8[4];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        r7[h] = L.rtab[c * 512 + 127 + 2 * lane + h];
+                        t7[h] = L.tth[t0 + ((2 * lane + h) << 2) + 2];
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        r8[g] = L.rtab[c * 512 + 255 + 4 * lane + g];
+                        t8[g] = L.tth[t0 + ((4 * lane + g) << 1) + 1];
+                    }
+                    int n7[2] = {nl, nr}, o7[2] = {ol, orr};
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        int n8l, o8l, n8r, o8r;
+                        visit(r7[h], t7[h], ((2 * lane + h) << 2) + 2, n7[h], o7[h], n8l, o8l, n8r, o8r);
+                        int n8[2] = {n8l, n8r}, o8[2] = {o8l, o8r};
+#pragma unroll
+                        for (int g = 0; g < 2; g++) {
+                            int n9l, o9l, n9r, o9r;
+                            const int j8 = 4 * lane + 2 * h + g;
+                            visit(r8[2 * h + g], t8[2 * h + g], (j8 << 1) + 1, n8[g], o8[g], n9l, o9l, n9r, o9r);
+                            // depth 9: intervals of length 1, no midpoint in the table -- what is left goes to the queue
+                            const int nn[2] = {n9l, n9r}, oo[2] = {o9l, o9r};
+#pragma unroll
+                            for (int k = 0; k < 2; k++) {
+                                if (nn[k] > 0) {
+                                    const int qa = 2 * j8 + k, qb = qa + 1;
+                                    QArc o;
+                                    o.a.ax = L.tcx[t0 + qa]; o.a.ay = L.tcy[t0 + qa]; o.a.ta = L.tth[t0 + qa];
+                                    o.a.bx = L.tcx[t0 + qb]; o.a.by = L.tcy[t0 + qb]; o.a.tb = L.tth[t0 + qb];
+                                    o.a.n = nn[k]; o.a.off = oo[k]; o.qa = -1; o.qb = -1;
+                                    q0[atomicAdd(&L.cnt[0 * 2 + c], 1)] = o;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            // the arcs below the table, level by level as in round 4 (no arc: the loop ends at once)
             for (int lvl = 0; lvl < BUF; ++lvl) {
                 const int cur = lvl % 3, nxt = (lvl + 1) % 3, clr = (lvl + 2) % 3;
-                const int n = L.cnt[cur * 2 + c];
-                if (n == 0) break;
+                const int nq = L.cnt[cur * 2 + c];
+                if (nq == 0) break;
                 if (lane == 0) L.cnt[clr * 2 + c] = 0;
-                for (int i = lane; i < n; i += 64) {
+                for (int i = lane; i < nq; i += 64) {
                     QArc nd = L.q[(c * 2 + (lvl & 1)) * QCAP + i];
                     Arc lf, rt;
                     float th;
-                    int slot, qm = -1;
-                    if (nd.qa >= 0) {   // table-backed: end points and midpoint come from B1
-                        qm = (nd.qa + nd.qb) >> 1;
-                        nd.a.ax = L.tcx[t0 + nd.qa]; nd.a.ay = L.tcy[t0 + nd.qa]; nd.a.ta = L.tth[t0 + nd.qa];
-                        nd.a.bx = L.tcx[t0 + nd.qb]; nd.a.by = L.tcy[t0 + nd.qb]; nd.a.tb = L.tth[t0 + nd.qb];
-                        th = L.tth[t0 + qm];
-                        slot = arc_split(nd.a, th, L.tcx[t0 + qm], L.tcy[t0 + qm], lf, rt);
-                    } else {
-                        const float a1 = S_.a[0], a2 = c ? S_.a[1] : S_.a[2], e = S_.e[c];
-                        slot = arc_step(nd.a, a1, a2, e, th, lf, rt);
-                    }
+                    const float a1 = L.shape[2], a2 = c ? L.shape[3] : L.shape[4], e = L.shape[5 + c];
+                    const int slot = arc_step(nd.a, a1, a2, e, th, lf, rt);
                     L.buf[c * BUFP + slot] = th;
+                    L.bufq[c * BUFP + slot] = -1;
                     QArc* qn = &L.q[(c * 2 + ((lvl + 1) & 1)) * QCAP];
-                    if (lf.n > 0) {
-                        QArc o; o.a = lf;
-                        const bool tab = (qm >= 0) && (qm - nd.qa >= 2);
-                        o.qa = tab ? nd.qa : -1; o.qb = tab ? qm : -1;
-                        qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = o;
-                    }
-                    if (rt.n > 0) {
-                        QArc o; o.a = rt;
-                        const bool tab = (qm >= 0) && (nd.qb - qm >= 2);
-                        o.qa = tab ? qm : -1; o.qb = tab ? nd.qb : -1;
-                        qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = o;
-                    }
+                    if (lf.n > 0) { QArc o; o.a = lf; o.qa = -1; o.qb = -1; qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = o; }
+                    if (rt.n > 0) { QArc o; o.a = rt; o.qa = -1; o.qb = -1; qn[atomicAdd(&L.cnt[nxt * 2 + c], 1)] = o; }
                 }
-                // LDS operations of one wavefront complete in order; the fences keep the compiler from moving
-                // the next level's reads above this level's writes
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -358,11 +474,16 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             const int grp = w >> 8, k = w & 255;
             if (k >= BUF) continue;
             if (grp == 0) {
-                if (k >= 1) L.term[k] = (S_.a[0] + S_.a[1]) * fexp(cosf_(L.buf[k]), S_.e[0]);
+                if (k >= 1) {
+                    const int q = L.bufq[k];
+                    L.term[k] = (L.shape[2] + L.shape[3]) * (q >= 0 ? L.tfx[q] : fexp(cosf_(L.buf[k]), L.shape[5]));
+                }
             } else {
                 const int c = grp - 1;
+                const int q = L.bufq[c * BUFP + k];
                 float ct, st, fc, fs;
-                entry_factors(L.buf[c * BUFP + k], S_.e[c], ct, st, fc, fs);
+                if (q >= 0) { ct = L.tct[c * TABN + q]; st = L.tst[c * TABN + q]; fc = L.tfc[c * TABN + q]; fs = L.tfs[c * TABN + q]; }
+                else entry_factors(L.buf[c * BUFP + k], L.shape[5 + c], ct, st, fc, fs);
                 L.fac[(4 * c + 0) * BUFP + k] = ct; L.fac[(4 * c + 1) * BUFP + k] = st;
                 L.fac[(4 * c + 2) * BUFP + k] = fc; L.fac[(4 * c + 3) * BUFP + k] = fs;
             }
@@ -400,6 +521,11 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
 
         STAMP(3);
         // ---------------- D: inverse-CDF lookup + surface points --------------------------------
+        {
+        const Shape S_ = load_shape(L.shape);
+        float p[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) p[k] = L.p[k];
         for (int i = tid; i < N_PTS; i += NT) {
             const float r = A.draws[i];
             int lo = 0, hi = BUF;  // std::lower_bound
@@ -414,6 +540,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             L.pwx[i] = pw[0]; L.pwy[i] = pw[1]; L.pwz[i] = pw[2];
             L.ie[i] = (unsigned short)ke;
             L.io[i] = (unsigned short)ko;
+        }
         }
         __syncthreads();
 
@@ -435,6 +562,10 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
         // those same lanes and is added in the order (d0 + d1) + (d2 + d3).
         // views f = res, res + keff, res + 2 keff, ... (cnt of them); row m of L.vgrad receives view res + keff * m
         auto views = [&](int res, int cnt) {
+        const Shape S_ = load_shape(L.shape);
+        float p[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) p[k] = L.p[k];
         for (int v0 = 0; v0 < cnt; v0 += NT / S) {
             const int mrow = v0 + tid / S;
             const int f = res + keff * mrow;
@@ -654,7 +785,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             float g = (F > 0) ? L.xroot[tid] : 0.0f;
             if (use_prior && tid >= 4 && tid < 7) {
                 float gs[3];
-                prior_term(L.icov, L.s0, p, gs);
+                prior_term(L.icov, L.s0, L.p, gs);
                 g += gs[tid - 4];
             }
             if (tid < n_opt) {

@@ -3,7 +3,7 @@ import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo"); sys.path.insert(0, ROOT)
 import numpy as np, torch
 from odam_amd import _lib
-_lib.LIB_PATH = os.path.join(ROOT, "tests/native/_abl/libstamps.so")
+_lib.LIB_PATH = os.path.join(ROOT, sys.argv[1] if len(sys.argv) > 1 else "tests/native/_abl/libstamps.so")
 from odam_amd import sq, synth
 f = sq.SqFitter("cuda:0", 200)
 names = ["A shape", "B1 table", "B2 levels", "C cdf", "D points", "E exchange", "F tree/adam", "E own views"]
