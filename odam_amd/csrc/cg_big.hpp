@@ -46,7 +46,7 @@ namespace odam_cg {
 constexpr int big_bm(int BN, int NTH) { return (NTH == 1024 && BN == 64) ? 512 : 256; }
 constexpr int big_wm(int MODE, int BN, int NTH) {
     return NTH == 1024 ? (BN == 64 ? 16 : 4)      // bf16, 256 columns: sixteen waves of 64 x 64
-         : MODE >= 3 ? (BN == 256 ? 4 : 8) : (BN == 256 ? 2 : (BN == 128 ? 4 : 8));
+         : MODE >= 3 ? (BN == 256 ? ((MODE == 4 && CG_X16_WM8) ? 8 : 4) : 8) : (BN == 256 ? 2 : (BN == 128 ? 4 : 8));
 }
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
@@ -55,7 +55,7 @@ constexpr int big_lds_bytes() {
     const int ring = NST * (MODE >= 3 ? bm * 64 + 96 * BN : (bm + BN) * 64);
     const int wm = big_wm(MODE, BN, NTH);
     const int wn = NTH / 64 / wm;
-    const int slab = MODE == 4 ? (NTH / 64) * 16 * (BN / wn + 4) * 4 : (NTH / 64) * 32 * (BN / wn) * 4;      // the 16x16x32 loop's epilogue: 16-row slabs, rows padded by 4
+    const int slab = MODE == 4 ? (NTH / 64) * 16 * ((BN / wn > 128 ? 128 : BN / wn) + 4) * 4 : (NTH / 64) * 32 * (BN / wn) * 4;      // the 16x16x32 loop's epilogue: 16-row slabs, rows padded by 4
     const int s1 = (MODE == 0 && NTH == 512) ? (BN == 256 ? 2 : (BN == 128 ? 3 : 4)) * (384 * 64 + 3 * BN * 64) : 0;   // the 3x3 stride-1 window ring (bf16)
     const int m = ring > slab ? ring : slab;
     return m > s1 ? m : s1;
@@ -499,25 +499,54 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
                     o.l.z = pk(ul[0], ul[1]); o.l.w = pk(ul[2], ul[3]);
                 }
             };
+            // The filter fragments of a GROUP of four column tiles stay in registers while the wave's row tiles pass under them (column group
+            // outer, row tile inner; every split row fragment is kept for the later groups): 2 MI + 3 NJ LDS fragment reads per pair and
+            // wave instead of 2 MI + 3 MI NJ (the 256-column tiles: 32 instead of 104).  Round 4 re-read the filter fragments of every block
+            // from LDS to save vector issue; the light stamps of round 5 say the loop is short of ISSUE slots altogether (two waves x (176 split
+            // instructions + 104 LDS reads + 10 DMA issues) per pair against the 50 % of the cycles the matrix instruction leaves), and LDS
+            // reads are the part that can go: same box, layer3 3x3 659 -> 616 us, reduce 355 -> 332, expand + residual 422 -> 405, forward of
+            // 32 frames 31.5 -> 30.9 ms (profiles/r5_ring_breg.txt).  The six products of a block and their order on every accumulator are
+            // unchanged: bit-identical outputs.  (CG_X16_BREG = 0 builds round 4's order: tests/native/ring_stamps.hip A/B.)
+            constexpr bool BREG = CG_X16_BREG != 0;
+            constexpr int NG = NJ / 4;
+            Ops A4[BREG ? MI : 1], Bg[BREG ? 4 : 1];
             read_a(0);
+            if constexpr (BREG) {
 #pragma unroll
-            for (int j = 0; j < BD; j++) read_b(j % NJ, B2[j]);
-            half_split(ar0, A2[0], 0); half_split(ar1, A2[0], 1);
+                for (int j = 0; j < 4; j++) read_b(j, Bg[j]);
+                half_split(ar0, A4[0], 0); half_split(ar1, A4[0], 1);
+            } else {
+#pragma unroll
+                for (int j = 0; j < BD; j++) read_b(j % NJ, B2[j]);
+                half_split(ar0, A2[0], 0); half_split(ar1, A2[0], 1);
+            }
             int dpart = 0;
 #pragma unroll
             for (int b = 0; b < NBLK; b++) {
-                const int mi = b / NJ, nj = b % NJ;
-                const Ops& oa = A2[mi & 1];
-                const Ops& ob = B2[b % (BD + 1)];
+                const int grp = b / (4 * MI);      // (BREG) column group, row tile, column tile of block b
+                const int mi = BREG ? (b / 4) % MI : b / NJ, nj = BREG ? 4 * grp + b % 4 : b % NJ;
+                const Ops& oa = BREG ? A4[BREG ? mi : 0] : A2[mi & 1];
+                const Ops& ob = BREG ? Bg[BREG ? b % 4 : 0] : B2[b % (BD + 1)];
                 // smallest products first, as MODE 3
                 ODAM_MM16(c16[mi][nj], oa.l, ob.h); ODAM_MM16(c16[mi][nj], oa.m, ob.m); ODAM_MM16(c16[mi][nj], oa.h, ob.l);
                 ODAM_MM16(c16[mi][nj], oa.m, ob.h); ODAM_MM16(c16[mi][nj], oa.h, ob.m);
                 ODAM_MM16(c16[mi][nj], oa.h, ob.h);
+                if constexpr (BREG) {
+                    const int j = b % 4;
+                    if (grp == 0 && mi + 1 < MI) {      // first column group: the next row tile is read and split under this one's four blocks
+                        if (j == 0) read_a(mi + 1);
+                        if (j == 2) half_split(ar0, A4[BREG ? mi + 1 : 0], 0);
+                        if (j == 3) half_split(ar1, A4[BREG ? mi + 1 : 0], 1);
+                    }
+                    if (mi == MI - 1 && grp + 1 < NG)   // a group's last row tile: column tile j's registers are free, the next group's tile j moves in
+                        read_b(4 * (grp + 1) + j, Bg[BREG ? j : 0]);
+                } else {
                 if (b + BD < NBLK) read_b((b + BD) % NJ, B2[(b + BD) % (BD + 1)]);
                 if (mi + 1 < MI) {
                     if (nj == 1) read_a(mi + 1);
                     if (nj == 3) half_split(ar0, A2[(mi + 1) & 1], 0);
                     if (nj == (NJ > 5 ? 5 : 3)) half_split(ar1, A2[(mi + 1) & 1], 1);
+                }
                 }
 #pragma unroll
                 for (; dpart < ((b + 1) * NDMA + NBLK - 1) / NBLK; dpart++) {
@@ -620,21 +649,27 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         // row tile i + 1 and the stores of row tile i - 1 stay in flight under row tile i), and the first two row tiles'
         // residual rows are requested BEFORE the barrier that ends the main loop.  Same arithmetic, same order: bit-identical.
         {
-            constexpr int WROWS = BM / WM, WCOLS = BN / WN, EP_LD = WCOLS + 4;
+            // A wave's tile leaves in UNITS of 16 rows x UC columns (UC = its width, at most 128): unit u = row tile u / NH, column half u % NH.
+            constexpr int WROWS = BM / WM, WCOLS = BN / WN, UC = WCOLS > 128 ? 128 : WCOLS, NH = WCOLS / UC, NU = MI * NH, EP_LD = UC + 4;
             static_assert(NW * 16 * EP_LD * 4 <= NST * STAGE, "epilogue slabs fit the ring");
             // (opaque copy of the thread id: nothing of the epilogue's lane arithmetic is computed ahead of the K loop and carried through it)
             int tid_e = tid;
             asm volatile("" : "+v"(tid_e));
             const int lane = tid_e & 63, wave = tid_e >> 6, wm = wave / WN, wn = wave % WN, r16 = lane & 15, kq = lane >> 4;
             float* Ep = smem + wave * (16 * EP_LD);
-            constexpr int LPR = WCOLS / 4, RPI = 64 / LPR, NIT = 16 / RPI;
+            constexpr int LPR = UC / 4, RPI = 64 / LPR, NIT = 16 / RPI;
             const int c4e = (lane % LPR) * 4;
             const int n = n0 + wn * WCOLS + c4e;
-            const bool n_ok = n < a.Cout;
-            const int nc = n_ok ? n : 0;
-            float4 sc = a.scale ? *reinterpret_cast<const float4*>(a.scale + nc) : float4{1.f, 1.f, 1.f, 1.f};
-            float4 bi = a.bias ? *reinterpret_cast<const float4*>(a.bias + nc) : float4{0.f, 0.f, 0.f, 0.f};
-            if (!n_ok) { sc = float4{1.f, 1.f, 1.f, 1.f}; bi = float4{0.f, 0.f, 0.f, 0.f}; }
+            bool n_ok[NH];
+            float4 sc[NH], bi[NH];
+#pragma unroll
+            for (int h = 0; h < NH; h++) {
+                n_ok[h] = n + h * UC < a.Cout;
+                const int nc = n_ok[h] ? n + h * UC : 0;
+                sc[h] = a.scale ? *reinterpret_cast<const float4*>(a.scale + nc) : float4{1.f, 1.f, 1.f, 1.f};
+                bi[h] = a.bias ? *reinterpret_cast<const float4*>(a.bias + nc) : float4{0.f, 0.f, 0.f, 0.f};
+                if (!n_ok[h]) { sc[h] = float4{1.f, 1.f, 1.f, 1.f}; bi[h] = float4{0.f, 0.f, 0.f, 0.f}; }
+            }
             const size_t tile_off = ((size_t)m0 * a.ldc + n0) * sizeof(float);
             // (no residual: a descriptor of zero records -- every load through it returns zeros)
             const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(
@@ -643,19 +678,19 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             const int rows_left = a.M - m0;                       // rows of this tile that exist
             const int row0 = wm * WROWS + lane / LPR;             // + mi * 16 + it * RPI
             const unsigned col_b = (unsigned)(wn * WCOLS + c4e) * 4u;
-            auto voff = [&](int mi, int it) -> unsigned {
-                const int r = row0 + mi * 16 + it * RPI;
-                const unsigned ok = (unsigned)n_ok & (unsigned)(r < rows_left);      // (bitwise: a short-circuit && becomes a branch)
-                return ok ? (unsigned)r * (unsigned)a.ldc * 4u + col_b : OOB_VOFF;
+            auto voff = [&](int u, int it) -> unsigned {
+                const int r = row0 + (u / NH) * 16 + it * RPI;
+                const unsigned ok = (unsigned)n_ok[u % NH] & (unsigned)(r < rows_left);      // (bitwise: a short-circuit && becomes a branch)
+                return ok ? (unsigned)r * (unsigned)a.ldc * 4u + col_b + (unsigned)((u % NH) * UC * 4) : OOB_VOFF;
             };
             float4 rv[2][NIT];
-            auto load_res = [&](int mi, float4 (&dst)[NIT]) {
+            auto load_res = [&](int u, float4 (&dst)[NIT]) {
 #pragma unroll
                 for (int it = 0; it < NIT; it++)
-                    dst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, voff(mi, it), 0, 0));
+                    dst[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, voff(u, it), 0, 0));
             };
             load_res(0, rv[0]);
-            if (MI > 1) load_res(1, rv[1]);
+            if (NU > 1) load_res(1, rv[1]);
             __syncthreads();      // every wave is past its last fragment read: the ring is free for the slabs
             const unsigned relu_m = a.relu ? 0xffffffffu : 0u;
             auto act = [&](float v) {      // relu ? (v > 0 ? v : 0) : v, without a branch
@@ -663,12 +698,13 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
                 return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
             };
 #pragma unroll
-            for (int mi = 0; mi < MI; mi++) {
+            for (int u = 0; u < NU; u++) {
+                const int mi = u / NH, h = u % NH;
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = 0; j < NJ; j++)
+                for (int j = 0; j < UC / 16; j++)
 #pragma unroll
-                    for (int r = 0; r < 4; r++) Ep[(4 * kq + r) * EP_LD + j * 16 + r16] = c16[mi][j][r];
+                    for (int r = 0; r < 4; r++) Ep[(4 * kq + r) * EP_LD + j * 16 + r16] = c16[mi][h * (UC / 16) + j][r];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -676,14 +712,14 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
                 for (int it = 0; it < NIT; it++) {
                     const int row = it * RPI + lane / LPR;
                     const float4 v = *reinterpret_cast<const float4*>(&Ep[row * EP_LD + c4e]);
-                    const float4 rr = rv[mi & 1][it];
+                    const float4 rr = rv[u & 1][it];
                     float4 o;
-                    o.x = v.x * sc.x + bi.x; o.y = v.y * sc.y + bi.y; o.z = v.z * sc.z + bi.z; o.w = v.w * sc.w + bi.w;
+                    o.x = v.x * sc[h].x + bi[h].x; o.y = v.y * sc[h].y + bi[h].y; o.z = v.z * sc[h].z + bi[h].z; o.w = v.w * sc[h].w + bi[h].w;
                     o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
                     o.x = act(o.x); o.y = act(o.y); o.z = act(o.z); o.w = act(o.w);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, voff(mi, it), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, voff(u, it), 0, 0);
                 }
-                if (mi + 2 < MI) load_res(mi + 2, rv[mi & 1]);      // into the registers this row tile has just released
+                if (u + 2 < NU) load_res(u + 2, rv[u & 1]);      // into the registers this unit has just released
             }
         }
 #if CG_STAMP

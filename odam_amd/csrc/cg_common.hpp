@@ -42,6 +42,12 @@ static __device__ unsigned long long g_tail_stamps[8];
 #else
 #define CG_TSTAMP(i) do { } while (0)
 #endif
+#ifndef CG_X16_BREG
+#define CG_X16_BREG 1      // the 16x16x32 loop (cg_big.hpp): filter fragments of a column group stay in registers; 0 = round 4's block order (A/B builds)
+#endif
+#ifndef CG_X16_WM8
+#define CG_X16_WM8 0       // experiment: the 256-column 16x16x32 tiles as eight waves of 32 x 256 (half the activation splits per wave, every filter fragment read by every wave)
+#endif
 #ifndef CG_HACK
 #define CG_HACK 0      // timing experiments of the 16x16x32 loop (cg_big.hpp); 0 in every product build
 #endif
