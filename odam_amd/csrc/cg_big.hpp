@@ -507,6 +507,10 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             // reads are the part that can go: same box, layer3 3x3 659 -> 616 us, reduce 355 -> 332, expand + residual 422 -> 405, forward of
             // 32 frames 31.5 -> 30.9 ms (profiles/r5_ring_breg.txt).  The six products of a block and their order on every accumulator are
             // unchanged: bit-identical outputs.  (CG_X16_BREG = 0 builds round 4's order: tests/native/ring_stamps.hip A/B.)
+            // With the filter reads that cheap, the 256-column tile runs as eight waves of 32 x 256 (big_wm, CG_X16_WM8) instead of 4 x 2
+            // waves of 64 x 128: no activation row is split by two waves (88 instead of 176 split instructions per pair and wave) and every
+            // wave reads all sixteen column tiles once per pair (52 fragment reads instead of 32): 3x3 layers 604 -> 588 us, reduce 330 ->
+            // 321, expand + residual 401 -> 392, forward of 32 frames 30.26 -> 29.92 ms, bit-identical (profiles/r5_ring_wm8.txt).
             constexpr bool BREG = CG_X16_BREG != 0;
             constexpr int NG = NJ / 4;
             Ops A4[BREG ? MI : 1], Bg[BREG ? 4 : 1];

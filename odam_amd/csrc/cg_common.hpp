@@ -46,7 +46,7 @@ static __device__ unsigned long long g_tail_stamps[8];
 #define CG_X16_BREG 1      // the 16x16x32 loop (cg_big.hpp): filter fragments of a column group stay in registers; 0 = round 4's block order (A/B builds)
 #endif
 #ifndef CG_X16_WM8
-#define CG_X16_WM8 0       // experiment: the 256-column 16x16x32 tiles as eight waves of 32 x 256 (half the activation splits per wave, every filter fragment read by every wave)
+#define CG_X16_WM8 1       // the 256-column 16x16x32 tiles as eight waves of 32 x 256 (no activation row is split by two waves; every wave reads every filter fragment); 0 = 4 x 2 waves of 64 x 128 (A/B builds)
 #endif
 #ifndef CG_HACK
 #define CG_HACK 0      // timing experiments of the 16x16x32 loop (cg_big.hpp); 0 in every product build
