@@ -47,7 +47,7 @@ int odam_sq_destroy(odam_sq_ctx* ctx);
 
 /*
  * Fits n_obj super-quadrics, n_iters Adam steps each, entirely on device: one 1024-thread workgroup per object,
- * or -- when the grid would leave most CUs idle -- up to sixteen per object that split the views of the per-view
+ * or -- when the grid would leave most CUs idle -- up to thirty-two per object that split the views of the per-view
  * extent search by residue class and exchange one sub-tree root each per step (results are bit-identical either way).
  *   init_params  [dev] [n_obj][9]   translate[3], angle, scales[3] (= sqrt(dims/2)), shapes[2]
  *   class_id     [dev] [n_obj]      0..7 selects the scale prior row; < 0 = no prior (prior=False)

@@ -15,7 +15,7 @@ const Entry TABLE[N_KEYS] = {
     {"cg.ring", 1, 0, 2},        {"cg.f32", 2, 0, 2},         {"cg.fuse", 2, 0, 2},       {"cg.fuse_bf16", 2, 0, 2},
     {"cg.s1", 1, 0, 1},          {"cg.ut", 1, 0, 1},          {"cg.tiles", 31, 0, 31},      {"cg.force", 0, 0, 3},
     {"cg.presplit", 1, 0, 1},    {"cg.mfma16", 3, 0, 3},      {"att.x3", 1, 0, 1},         {"att.bf16_mfma", 1, 0, 1}, {"stem.rows", 1, 0, 1},
-    {"assoc.persist", 2, 0, 2},  {"sq.split", 16, 1, 16},     {"sq.split_wait", 3000, 0, 100000000}, {"sq.lanes", 0, 0, 64},
+    {"assoc.persist", 2, 0, 2},  {"sq.split", 32, 1, 32},     {"sq.split_wait", 3000, 0, 100000000}, {"sq.lanes", 0, 0, 64},
     {"stem.pool", 1, 0, 1},
     {"cg.pin", 0, 0, 1},
     {"cg.small_x3", 1, 0, 1},

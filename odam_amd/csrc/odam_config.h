@@ -24,7 +24,7 @@ enum Key {
     ASSOC_PERSIST,  // association: matching GNN as one persistent launch where the residency gate allows: 2 (default) rows dealt to the XCDs, one
                     // device-wide barrier per layer and XCD-local ones for the rest (gnn_rowpart_kernel); 1 five device-wide barriers per layer
                     // (gnn_persistent_kernel; bit-identical); 0 the launch sequence
-    SQ_SPLIT,       // super-quadric fit: workgroups per object at most (default 16)
+    SQ_SPLIT,       // super-quadric fit: workgroups per object at most (default 32)
     SQ_SPLIT_WAIT,  // ... bounded wait for a partner's rows, 100 MHz ticks (default 3000; 0 = never wait)
     SQ_LANES,       // ... lanes per view in the extent search (default 0 = chosen by the cost model)
     STEM_POOL,      // conv1's 3x3 / stride 2 max-pool on the tile of the row-convolution stem (fp32 split mode, sixteen-wave tiles): default 1

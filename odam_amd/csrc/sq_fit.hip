@@ -94,8 +94,8 @@ struct Lds {
     float* shape;   // [12]  c, s, a0..2, e0..1, sig0..1
     float* misc;    // [8]   cdf sum, dirsum[4]
     int* cnt;       // [8]   3 x 2 level counters
-    int* xready;    // [16]  view split: partner rows arrived this step
-    float* xroot;   // [16][9] sub-tree roots of the residue classes
+    int* xready;    // [32]  view split: partner rows arrived this step
+    float* xroot;   // [32][9] sub-tree roots of the residue classes
     float* pwx;     // [1024] x3
     float* pwy;
     float* pwz;
@@ -121,7 +121,7 @@ struct Lds {
 };
 
 __host__ __device__ inline size_t lds_words(int rows, int loss_rows) {
-    return 12 * 6 + 8 + 8 + 16 + 144 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
+    return 12 * 6 + 8 + 8 + 32 + 288 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
            4 * 2 * 520 + 520 + 2 * 512 + 2 * BUFP + (size_t)rows * 9 + (size_t)loss_rows * 4;
 }
 
@@ -136,8 +136,8 @@ __device__ inline Lds carve(float* base, int pn) {
     L.shape = w; w += 12;
     L.misc = w; w += 8;
     L.cnt = (int*)w; w += 8;
-    L.xready = (int*)w; w += 16;
-    L.xroot = w; w += 144;
+    L.xready = (int*)w; w += 32;
+    L.xroot = w; w += 288;
     L.pwx = w; w += 1024;
     L.pwy = w; w += 1024;
     L.pwz = w; w += 1024;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
     if (wj >= keff) return;
     const int fs = (F + keff - 1) / keff;           // views per slice
     const bool lead = (wj == 0);                    // writes the object's outputs
-    int absent = 0;                                 // bit jj: partner jj missed a deadline once -> no more waiting for it
+    unsigned absent = 0;                              // bit jj: partner jj missed a deadline once -> no more waiting for it
 
     if (tid < 9) {
         L.p[tid] = A.init_params[(size_t)obj * 9 + tid];
@@ -577,20 +577,51 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             float bv0 = 1000000.0f, bv1 = -1000000.0f, bv2 = 1000000.0f, bv3 = -1000000.0f;
             int bi0 = NONE, bi1 = NONE, bi2 = NONE, bi3 = NONE;
             if (vf) {
-                for (int i = sub; i < N_PTS; i += S) {
-                    const float wx = L.pwx[i], wy = L.pwy[i], wz = L.pwz[i];
-                    const float qz = proj_row(wx, wy, wz, Mv[8], Mv[9], Mv[10], Mv[11]);
-                    if (qz > 0.5f) {
+                // Phase E is bound by vector ISSUE (16 waves x ceil(1000 / S) points x ~55 instructions on one CU), so the scan is written for few
+                // instructions per point: no branch around the projection (a point behind the camera gets NaN coordinates, every comparison below
+                // is then false), and the two IEEE divisions by the same denominator share their reciprocal.  div2 is the compiler's own fp32
+                // division sequence (v_rcp + one Newton step, quotient + two residual corrections, all fused) WITHOUT v_div_scale / v_div_fixup:
+                // those rescale operands whose quotient or residuals would leave the normal range, i.e. never for a depth in [0.5, 2^100) and a
+                // numerator that is 0 or >= 2^-100 in magnitude -- there every intermediate of the plain sequence is the scaled sequence's times
+                // a power of two, so the result is the correctly rounded quotient, bit for bit.  The smallest |numerator| the lane saw is kept
+                // (one v_min3); a view in which it ever falls below 2^-100 (or is exactly zero: never measured) is scanned again with the
+                // compiler's division.
+                auto scan = [&](auto exact) {
+                    float mn = 3.0e38f;
+                    bv0 = 1000000.0f; bv1 = -1000000.0f; bv2 = 1000000.0f; bv3 = -1000000.0f;
+                    bi0 = NONE; bi1 = NONE; bi2 = NONE; bi3 = NONE;
+#pragma unroll 2
+                    for (int i = sub; i < N_PTS; i += S) {
+                        const float wx = L.pwx[i], wy = L.pwy[i], wz = L.pwz[i];
+                        const float qz = proj_row(wx, wy, wz, Mv[8], Mv[9], Mv[10], Mv[11]);
                         const float qx = proj_row(wx, wy, wz, Mv[0], Mv[1], Mv[2], Mv[3]);
                         const float qy = proj_row(wx, wy, wz, Mv[4], Mv[5], Mv[6], Mv[7]);
                         const float den = absf(qz) + 1e-6f;
-                        const float u = qx / den, v = qy / den;
+                        float u, v;
+                        if constexpr (decltype(exact)::value) {
+                            u = qx / den; v = qy / den;
+                        } else {
+                            float r = __builtin_amdgcn_rcpf(den);
+                            r = __builtin_fmaf(__builtin_fmaf(-den, r, 1.0f), r, r);
+                            float a = qx * r, b = qy * r;
+                            a = __builtin_fmaf(__builtin_fmaf(-den, a, qx), r, a);
+                            b = __builtin_fmaf(__builtin_fmaf(-den, b, qy), r, b);
+                            u = __builtin_fmaf(__builtin_fmaf(-den, a, qx), r, a);
+                            v = __builtin_fmaf(__builtin_fmaf(-den, b, qy), r, b);
+                            mn = __builtin_fminf(mn, __builtin_fminf(absf(qx), absf(qy)));
+                        }
+                        const bool front = qz > 0.5f;
+                        u = front ? u : __builtin_nanf("");
+                        v = front ? v : __builtin_nanf("");
                         if (u < bv0) { bv0 = u; bi0 = i; }
                         if (u > bv1) { bv1 = u; bi1 = i; }
                         if (v < bv2) { bv2 = v; bi2 = i; }
                         if (v > bv3) { bv3 = v; bi3 = i; }
                     }
-                }
+                    return mn;
+                };
+                const float mn = scan(std::false_type{});
+                if (__builtin_expect(mn < 0x1p-100f, 0)) scan(std::true_type{});
             }
             for (int sft = S >> 1; sft >= 1; sft >>= 1) {
                 merge_min(bv0, bi0, __shfl_xor(bv0, sft), __shfl_xor(bi0, sft));
@@ -695,7 +726,9 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             unsigned long long* xq = A.xroots + slot * (size_t)(A.split * 9);
             float* xl = want_loss ? A.xloss + slot * (size_t)A.max_views * 4 : nullptr;
             const unsigned long long tag = (unsigned long long)(it + 1) << 32;
-            if (wid == wj) {
+            // wavefront w looks after residue classes w and w + 16 (a split of up to 32): its own class is published, a partner's collected
+            for (int jj = wid; jj < keff; jj += NT / 64) {
+            if (jj == wj) {
                 // (the partners of an object share an XCD -- see the workgroup-id mapping above --, so the root only has to reach that XCD's
                 //  L2: a workgroup-scope store, read back below by loads that miss the vector L1 (sc0 sc1); tests/native/xcd_barrier_probe.hip)
                 if (lane < 9)
@@ -711,8 +744,7 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                     if (lane == 0)
                         __hip_atomic_store(&A.done[obj * A.split + wj], (unsigned)(it + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
                 }
-            } else if (wid < keff) {
-                const int jj = wid;
+            } else {
                 unsigned long long v = 0;
                 bool ok = lane >= 9;
                 auto peek = [&](const unsigned long long* q) {
@@ -758,10 +790,11 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
                 if (ready && lane < 9) L.xroot[jj * 9 + lane] = __uint_as_float((unsigned)(v & 0xffffffffull));
                 if (lane == 0) L.xready[jj] = ready;
             }
+            }
             __syncthreads();
             for (int jj = 0; jj < keff; jj++) {
                 if (jj == wj || L.xready[jj]) continue;      // uniform: read from LDS after the barrier
-                absent |= 1 << jj;                           // no more waiting for this partner
+                absent |= 1u << jj;                          // no more waiting for this partner
                 slice_root(jj);
             }
         }
@@ -919,7 +952,7 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     A.n_obj = n_obj; A.split = 1; A.split_min_views = 64; A.max_views = max_views; A.split_wait_ticks = (unsigned)wait_env;
     int grid = n_obj;
     const int n_pad = (n_obj + 7) / 8 * 8;
-    int k = split_env < 1 ? 1 : (split_env > 16 ? 16 : split_env);
+    int k = split_env < 1 ? 1 : (split_env > 32 ? 32 : split_env);
     while (k > 1 && n_pad * k > ctx->n_cu) k >>= 1;
     if (k > 1 && A.n_iters > 0 && max_views >= A.split_min_views) {
         const size_t roots = (size_t)A.n_iters * n_obj * k * 9;                 // 64-bit words: one tagged root per workgroup and step

@@ -215,7 +215,7 @@ def test_more_views_than_one_workgroup_holds(fitter, oracle):
 
 
 def test_view_split_is_bit_identical_on_every_path():
-    """The fit of one object split over 2 / 4 / 16 workgroups -- including the fallback where a workgroup never waits
+    """The fit of one object split over 2 / 4 / 16 / 32 workgroups -- including the fallback where a workgroup never waits
     for its partners and recomputes their slices (ODAM_SQ_SPLIT_WAIT=0) -- gives the bits of the unsplit kernel
     (parameters, losses and surface points of 14 objects with 10..300 views).  The switches are read once per
     process, hence one subprocess per setting."""
@@ -226,7 +226,8 @@ def test_view_split_is_bit_identical_on_every_path():
     digests = {}
     for name, env in (("off", {"ODAM_SQ_SPLIT": "1"}), ("two", {"ODAM_SQ_SPLIT": "2"}), ("four", {"ODAM_SQ_SPLIT": "4"}),
                       ("sixteen", {"ODAM_SQ_SPLIT": "16"}), ("four, no waiting", {"ODAM_SQ_SPLIT": "4", "ODAM_SQ_SPLIT_WAIT": "0"}),
-                      ("sixteen, no waiting", {"ODAM_SQ_SPLIT": "16", "ODAM_SQ_SPLIT_WAIT": "0"})):
+                      ("sixteen, no waiting", {"ODAM_SQ_SPLIT": "16", "ODAM_SQ_SPLIT_WAIT": "0"}),
+                      ("thirty-two", {"ODAM_SQ_SPLIT": "32"}), ("thirty-two, no waiting", {"ODAM_SQ_SPLIT": "32", "ODAM_SQ_SPLIT_WAIT": "0"})):
         out = subprocess.run([sys.executable, script], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         digests[name] = [l for l in out.stdout.splitlines() if l.startswith("digest")][0]
