@@ -214,7 +214,9 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
     const bool use_prior = (cls >= 0) && (A.prior_icov != nullptr);
     const int n_opt = (A.representation == ODAM_SQ_SUPER_QUADRIC) ? 9 : 7;
     const bool want_loss = (A.loss_log != nullptr);
-    const int keff = (A.split > 1 && F >= A.split_min_views) ? A.split : 1;
+    // (more than 16 workgroups only where they still get eight views each: at 128 views 32 workgroups lose to the exchange what the scan gains,
+    //  at 298 they are 3.4 us per step ahead -- profiles/r5_sq8_stamps.txt)
+    const int keff = (A.split > 1 && F >= A.split_min_views) ? ((A.split > 16 && F < 8 * A.split) ? 16 : A.split) : 1;
     if (wj >= keff) return;
     const int fs = (F + keff - 1) / keff;           // views per slice
     const bool lead = (wj == 0);                    // writes the object's outputs
