@@ -13,6 +13,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/r5_bench_prof -o t --
 cp $O/r5_bench_prof/t_kernel_stats.csv $O/r5_bench_steps1_kernel_stats.csv 2>/dev/null
 rm -rf $O/r5_bench_prof
 cd $R
-python3 tests/native/perf_sq_stamps.py 2>&1 | grep -v amdgpu > $O/r5_sq_phase_stamps.txt
+bash tests/native/sq_stamps.sh > $O/r5_sq_phase_stamps.txt 2>&1      # (builds the stamped library from this tree first: a stale one measures another kernel)
 python3 bench.py --steps 3 --warmup 1 > $O/r5_bench_line.json 2> $O/r5_bench_line.err
 tail -c 600 $O/r5_bench_line.json
