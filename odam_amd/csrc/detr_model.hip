@@ -779,7 +779,23 @@ extern "C" int odam_op_conv2d_nhwc(const float* x, const float* w_packed, const 
     c.w = const_cast<float*>(w_packed); c.scale = const_cast<float*>(scale); c.bias = const_cast<float*>(bias);
     c.Cin = Cin; c.Cout = Cout; c.KH = KH; c.KW = KW; c.stride = stride; c.pad = pad; c.Kpad = Kpad;
     c.k_order = k_order;
-    return run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream);
+    // Split contraction mode: a model keeps its filters pre-split into three bf16 planes (upload_w3); this op-level entry builds them for the
+    // one call (download, split on the host, upload), so that the op tests drive the SAME kernels a forward does -- the 16x16x32 loop with its
+    // ragged last row tile and ragged last columns -- and not only the layer shapes a DETR happens to have.
+    unsigned short* d3 = nullptr;
+    if (odam_cg::f32_mode() == 2 && Kpad % 16 == 0 && (long)Cout * Kpad * 6 < 0x7fffffffL) {
+        std::vector<float> hw((size_t)Cout * Kpad);
+        ODAM_HIP(hipStreamSynchronize((hipStream_t)stream));
+        ODAM_HIP(hipMemcpy(hw.data(), w_packed, hw.size() * sizeof(float), hipMemcpyDeviceToHost));
+        std::vector<unsigned short> h3(hw.size() * 3);
+        odam_cg::split3_filters(hw.data(), Cout, Kpad, h3.data());
+        ODAM_HIP(hipMalloc(&d3, h3.size() * 2));
+        if (hipMemcpy(d3, h3.data(), h3.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d3); return odam_fail(1, "odam_op_conv2d_nhwc: upload of the split filters failed"); }
+        c.w3 = d3;
+    }
+    const int rc = run_conv(c, x, B, H, W, residual, relu != 0, y, 0, (hipStream_t)stream);
+    if (d3) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(d3); }
+    return rc;
 }
 
 extern "C" int odam_op_conv2d_nhwc_bf16(const void* x, const void* w_packed, const float* scale, const float* bias,

@@ -53,6 +53,8 @@ def _pack(w, epc=4, k_order=0):
     (2, 12, 12, 32, 32, 7, 1, 3, False, False),     # 49 taps: register-staged gather with Cin >= 32
     (3, 9, 9, 16, 32, 3, 1, 1, True, False),        # Cin < k-tile: two taps inside one k-tile
     (2, 31, 29, 64, 256, 3, 2, 1, False, True),     # stride 2 + residual, N = 256
+    (3, 25, 34, 256, 400, 1, 1, 0, True, True),     # N = 400: the second 256-column tile ends inside its second 128-column half (ring kernel, cg.ring=2)
+    (2, 23, 31, 128, 644, 1, 1, 0, False, True),    # N = 644: three column tiles, the last one 132 columns wide
 ])
 def test_conv_gemm_vs_torch(B, H, W, Cin, Cout, k, s, p, relu, res):
     from odam_amd import _lib
@@ -565,9 +567,10 @@ def _bf16_check(out, ref_b, ref_f, measured, tag, ref_b2=None):
       * kernel vs (b) stays inside that same noise level (max within 2x of (b) vs fp32);
       * class labels equal (b)'s wherever (b)'s decision is clear of the noise (top-2 logit gap above twice the largest
         logit deviation between (b) and fp32), and on at least 93 % of all queries (ties at the noise level included);
-      * with ref_b2 = (b) evaluated on an input nudged by one bf16 ulp in 0.1 % of its pixels (a second faithful evaluation that
-        rounds independently): the kernel disagrees with (b) no more than (b) disagrees with ITSELF -- labels within 3 % of the
-        200 queries (1.5 sigma of that count), every output's rms deviation within 1.5x.  tests/golden/c4_margins.txt
+      * with ref_b2 = (b) evaluated three more times on inputs nudged by one bf16 ulp in 0.1 % of the pixels (faithful evaluations that
+        round independently): the kernel disagrees with (b) no more than (b) disagrees with ITSELF -- labels within 3 % of the 200
+        queries of the mean self-agreement (measured 0.955 against 0.967), every output's rms deviation within 1.5x of the nudged
+        oracle's (measured 0.76 ... 0.89x: the kernel tracks the oracle more closely than the oracle tracks its nudged self).  tests/golden/c4_margins.txt
         (probe_c4_margins.py) is why the gate is relative: on the best linear class heads there are for this network two faithful
         bf16 evaluations agree on 96-99.5 % of the labels, so a fixed '>= 0.99' would test the weights' margins, not the kernels."""
     def rms(a, b):
@@ -594,15 +597,19 @@ def _bf16_check(out, ref_b, ref_f, measured, tag, ref_b2=None):
     assert decisive.float().mean().item() >= 0.2, "fixture without decisive logits"      # measured: 1.0 at 192x256, 0.26 at full size
     assert torch.equal(lab[decisive], lab_b[decisive])
     assert (lab == lab_b).float().mean().item() >= 0.93      # all queries, ties at the bf16 noise level included (measured 0.965 ... 1.0)
-    if ref_b2 is not None:
-        self_agree = (ref_b2["pred_logits"].argmax(-1) == lab_b).float().mean().item()
+    if ref_b2 is not None:      # a list of nudged evaluations: one alone is a noisy yardstick (label agreement 0.945 ... 0.975 over nudge seeds)
+        agree = [(r["pred_logits"].argmax(-1) == lab_b).float().mean().item() for r in ref_b2]
+        self_agree = sum(agree) / len(agree)
         measured(f"detr_bf16.{tag}.label_agreement_oracle_vs_nudged_self", self_agree)
+        measured(f"detr_bf16.{tag}.label_agreement_oracle_vs_nudged_self_min", min(agree))
         measured(f"detr_bf16.{tag}.label_agreement_gpu_vs_oracle", (lab == lab_b).float().mean().item())
-        assert (lab == lab_b).float().mean().item() >= self_agree - 0.03, ((lab == lab_b).float().mean().item(), self_agree)
+        assert (lab == lab_b).float().mean().item() >= self_agree - 0.03, ((lab == lab_b).float().mean().item(), agree)
         for k in KEYS:
-            r_self, r_gpu = rms(ref_b2[k], ref_b[k]), rms(out[k].cpu(), ref_b[k])
+            r_self = sum(rms(r[k], ref_b[k]) for r in ref_b2) / len(ref_b2)
+            r_gpu = rms(out[k].cpu(), ref_b[k])
             measured(f"detr_bf16.{tag}.{k}.oracle_vs_nudged_self_rms", r_self)
-            assert r_gpu <= 1.5 * r_self + 1e-4, (k, r_gpu, r_self)
+            measured(f"detr_bf16.{tag}.{k}.gpu_over_nudged_self_rms", r_gpu / max(r_self, 1e-12))
+            assert r_gpu <= 1.5 * r_self + 1e-4, (k, r_gpu, r_self)      # measured: 0.76 ... 0.89 -- the kernel tracks the oracle more closely than the oracle tracks its nudged self
 
 
 @pytest.mark.parametrize("ring", [1, 2])      # 2: every eligible layer on the 256-row ring kernel (3x3 stride 1: the window main loop)
@@ -708,8 +715,10 @@ def test_bf16_r101_full_size_vs_bf16_faithful_oracle(measured):
     torch.set_num_threads(8)
     ref_b = O.detr_forward_bf16(sd, img.cpu(), blocks=(3, 4, 23, 3))
     ref_f = O.detr_forward(sd, img.cpu(), blocks=(3, 4, 23, 3))
-    nudge = torch.rand(img.shape, generator=torch.Generator().manual_seed(1)) < 1e-3      # a second, independently rounding evaluation of the oracle
-    ref_b2 = O.detr_forward_bf16(sd, torch.where(nudge, img.cpu() * (1 + 2.0 ** -7), img.cpu()), blocks=(3, 4, 23, 3))
+    ref_b2 = []      # three more, independently rounding evaluations of the oracle: one bf16 ulp on 0.1 % of the pixels
+    for seed in (1, 2, 3):
+        nudge = torch.rand(img.shape, generator=torch.Generator().manual_seed(seed)) < 1e-3
+        ref_b2.append(O.detr_forward_bf16(sd, torch.where(nudge, img.cpu() * (1 + 2.0 ** -7), img.cpu()), blocks=(3, 4, 23, 3)))
     out = det(img)
     _bf16_check(out, ref_b, ref_f, measured, "full", ref_b2)
     det.close()
