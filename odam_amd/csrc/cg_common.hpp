@@ -48,9 +48,6 @@ static __device__ unsigned long long g_tail_stamps[8];
 #ifndef CG_X16_WM8
 #define CG_X16_WM8 1       // the 256-column 16x16x32 tiles as eight waves of 32 x 256 (no activation row is split by two waves; every wave reads every filter fragment); 0 = 4 x 2 waves of 64 x 128 (A/B builds)
 #endif
-#ifndef CG_TAIL_STAGGER
-#define CG_TAIL_STAGGER 1   // fused bottleneck tails (cg_tails_f32.hpp): the two waves of a SIMD take the filter groups in opposite phase; 0 = lock step (A/B builds)
-#endif
 #ifndef CG_HACK
 #define CG_HACK 0      // timing experiments of the 16x16x32 loop (cg_big.hpp); 0 in every product build
 #endif

@@ -560,24 +560,23 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
     const char* lds_c = reinterpret_cast<const char*>(smem);
     const int b_off = l32 * 32 + ((half ^ ((l32 >> 3) & 1)) * 16);
 #define ODAM_MM2(accv, x, y) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
-    // The two waves of a SIMD (w and w + 4) take the groups in OPPOSITE phase (CG_TAIL_STAGGER, round 5): in the interval that belongs to filter
-    // group g the early wave multiplies group g and then does its row pass (slab, scale, residual, store), the late wave first does the row pass of
-    // group g - 1 and then multiplies group g.  In lock step (round 2-4) both waves wanted the matrix pipe for the same 6,144 cycles and then
-    // both left it idle for their row passes; now one wave's row pass runs under the other's products.  Same arithmetic per element, same
-    // filter-buffer discipline (one barrier per group, group g + 1's filters requested inside interval g): bit-identical.
-    // (every lane-dependent constant of an interval is derived from an opaque copy of the lane id INSIDE the interval: carried through the group
-    //  loop they are hoisted ahead of it and spilled -- 23 registers in the first version of this loop)
-    floatx16 acc2[2];
-    auto products = [&](int g, int ln) {
-        const int half_ = ln >> 5, l32_ = ln & 31;
-        const char* wf = lds_c + SLABS + (g & 1) * GB + l32_ * 32 + ((half_ ^ ((l32_ >> 3) & 1)) * 16);
+#pragma unroll 1
+    for (int g = 0; g < NG; g++) {
+        // group g's filters were issued at the top of group g - 1; exactly 8 stores + 8 residual loads (buffer instructions, never
+        // branched around) are younger -- those may stay in flight
+        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        __syncthreads();
+        if (g + 1 < NG) dma_group(g + 1);
+        const char* wf = lds_c + SLABS + (g & 1) * GB;
+        floatx16 acc2[2];
 #pragma unroll
         for (int jb = 0; jb < 2; jb++) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc2[jb][r] = 0.0f;
 #pragma unroll
             for (int s_ = 0; s_ < KS; s_++) {
-                const char* bp = wf + (s_ * 3) * 2048 + jb * 1024;
+                const char* bp = wf + (s_ * 3) * 2048 + jb * 1024 + b_off;
                 const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 2048),
                             bl = *reinterpret_cast<const uint4*>(bp + 4096);
                 ODAM_MM2(acc2[jb], al[s_], bh); ODAM_MM2(acc2[jb], am[s_], bm); ODAM_MM2(acc2[jb], ah[s_], bl);
@@ -585,79 +584,29 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
                 ODAM_MM2(acc2[jb], ah[s_], bh);
             }
         }
-    };
-    auto row_offsets = [&](int ln, unsigned (&ro)[8]) {
-#pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int m = m_base + it * 4 + (ln >> 4);
-            ro[it] = m < a.M ? (unsigned)((size_t)m * a.F_ldc * 4 + (ln & 15) * 16) : OOB_VOFF;
-        }
-    };
-    auto load_res2 = [&](int g, const unsigned (&ro)[8]) {
-#pragma unroll
-        for (int it = 0; it < 8; it++)
-            rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, ro[it] == OOB_VOFF ? OOB_VOFF : ro[it] + (unsigned)(g * 256), 0, 0));
-    };
-    auto row_pass = [&](int g, int ln, const unsigned (&ro)[8]) {
-        const int half_ = ln >> 5, l32_ = ln & 31, c4_ = ln & 15;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int jb = 0; jb < 2; jb++)
 #pragma unroll
             for (int r = 0; r < 16; r++)
-                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half_, jb * 32 + l32_)] = acc2[jb][r];
+                slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
         wave_sync();
-        const int n = g * 64 + c4_ * 4;
+        const int n = g * 64 + c4 * 4;
         float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
         if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
         if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
-            const int row = it * 4 + (ln >> 4);
-            const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4_ ^ (row & 15)) << 2)]);
+            const int row = it * 4 + (lane >> 4);
+            const int m = m_base + row;
+            const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
             float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
                         v.w * sc.w + bi.w + rv[it].w};
             if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, ro[it] == OOB_VOFF ? OOB_VOFF : ro[it] + (unsigned)(g * 256), 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0);
         }
+        if (g + 1 < NG) load_res(g + 1);
         __builtin_amdgcn_wave_barrier();
-    };
-    const bool late = CG_TAIL_STAGGER && wave_u >= 4;
-    if (!late) {
-#pragma unroll 1
-        for (int g = 0; g <= (CG_TAIL_STAGGER ? NG : NG - 1); g++) {
-            // group g's filters were issued at the top of group g - 1; exactly 8 stores + 8 residual loads (buffer instructions, never
-            // branched around) are younger -- those may stay in flight
-            if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            __syncthreads();
-            if (g == NG) break;                              // (the late waves' last row pass: this wave only keeps the barrier count)
-            if (g + 1 < NG) dma_group(g + 1);
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            products(g, ln);
-            unsigned ro[8];
-            row_offsets(ln, ro);
-            row_pass(g, ln, ro);
-            if (g + 1 < NG) load_res2(g + 1, ro);
-        }
-    } else {
-#pragma unroll 1
-        for (int g = 0; g <= NG; g++) {
-            // this wave's pieces of group g's filters were issued in interval g - 1 AFTER its row pass: only the 8 residual loads of group g
-            // are younger (interval 0 issues them before the loop: nothing younger at g = 1)
-            if (g <= 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            __syncthreads();
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            unsigned ro[8];
-            row_offsets(ln, ro);
-            if (g > 0) row_pass(g - 1, ln, ro);
-            if (g + 1 < NG) dma_group(g + 1);
-            if (g > 0 && g < NG) load_res2(g, ro);
-            if (g < NG) products(g, ln);
-        }
     }
 #undef ODAM_MM2
 }
