@@ -440,7 +440,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             }
         };
         dma_tile(0, 0); dma_tile(1, 1);
-#if CG_HACK      // timing experiments only (tests/native/ring_stamps.hip -DCG_HACK=1 / 3): results are WRONG.  1: no epilogue at all (the main loop's own
+#if CG_HACK & 3  // timing experiments only (tests/native/ring_stamps.hip -DCG_HACK=1 / 3): results are WRONG.  1: no epilogue at all (the main loop's own
                  // time); 3: no epilogue, but its memory traffic -- one 16-byte residual load and one 16-byte store per lane and fourth block, the
                  // tile's own rows -- issued INSIDE the main loop: what a tile costs if the previous tile's epilogue rode under its products
         const size_t hk_off = ((size_t)m0 * a.ldc + n0) * sizeof(float);
@@ -594,7 +594,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         if constexpr (FUSE != 0) stamps_out(st_loop1);
 #endif
 #undef ODAM_MM16
-#if CG_HACK
+#if CG_HACK & 3
         if constexpr (FUSE == 0) {
 #pragma unroll
             for (int i = 0; i < MI; i++)

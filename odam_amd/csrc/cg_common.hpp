@@ -49,7 +49,7 @@ static __device__ unsigned long long g_tail_stamps[8];
 #define CG_X16_WM8 1       // the 256-column 16x16x32 tiles as eight waves of 32 x 256 (no activation row is split by two waves; every wave reads every filter fragment); 0 = 4 x 2 waves of 64 x 128 (A/B builds)
 #endif
 #ifndef CG_HACK
-#define CG_HACK 0      // timing experiments of the 16x16x32 loop (cg_big.hpp); 0 in every product build
+#define CG_HACK 0      // timing experiments (WRONG results; 0 in every product build): bits 1, 2 = the 16x16x32 loop's epilogue (cg_big.hpp); layer2's fused tail (cg_tails_f32.hpp): 4 = without its residual loads and stores, 8 = without its products
 #endif
 #ifndef CG_ABLATE
 #define CG_ABLATE 0   // timing experiments only (tests/native/perf_conv_ablate.py): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no output stores, 16 no first-tile load

@@ -564,7 +564,7 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
     for (int g = 0; g < NG; g++) {
         // group g's filters were issued at the top of group g - 1; exactly 8 stores + 8 residual loads (buffer instructions, never
         // branched around) are younger -- those may stay in flight
-        if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (g == 0 || (CG_HACK & 4)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         __syncthreads();
         if (g + 1 < NG) dma_group(g + 1);
@@ -575,7 +575,7 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
 #pragma unroll
             for (int r = 0; r < 16; r++) acc2[jb][r] = 0.0f;
 #pragma unroll
-            for (int s_ = 0; s_ < KS; s_++) {
+            for (int s_ = 0; s_ < ((CG_HACK & 8) ? 0 : KS); s_++) {      // (CG_HACK & 8: timing build without the expand products)
                 const char* bp = wf + (s_ * 3) * 2048 + jb * 1024 + b_off;
                 const uint4 bh = *reinterpret_cast<const uint4*>(bp), bm = *reinterpret_cast<const uint4*>(bp + 2048),
                             bl = *reinterpret_cast<const uint4*>(bp + 4096);
@@ -603,9 +603,15 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
             float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
                         v.w * sc.w + bi.w + rv[it].w};
             if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+#if CG_HACK & 4      // timing build without the tail's memory traffic: the value is consumed, nothing is stored, no residual row is requested
+            asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+#else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0);
+#endif
         }
+#if !(CG_HACK & 4)
         if (g + 1 < NG) load_res(g + 1);
+#endif
         __builtin_amdgcn_wave_barrier();
     }
 #undef ODAM_MM2
