@@ -567,10 +567,11 @@ def _bf16_check(out, ref_b, ref_f, measured, tag, ref_b2=None):
       * kernel vs (b) stays inside that same noise level (max within 2x of (b) vs fp32);
       * class labels equal (b)'s wherever (b)'s decision is clear of the noise (top-2 logit gap above twice the largest
         logit deviation between (b) and fp32), and on at least 93 % of all queries (ties at the noise level included);
-      * with ref_b2 = (b) evaluated three more times on inputs nudged by one bf16 ulp in 0.1 % of the pixels (faithful evaluations that
+      * with ref_b2 = (b) evaluated three more times on inputs nudged by one bf16 ulp in 1 % of the pixels (faithful evaluations that
         round independently): the kernel disagrees with (b) no more than (b) disagrees with ITSELF -- labels within 3 % of the 200
-        queries of the mean self-agreement (measured 0.955 against 0.967), every output's rms deviation within 1.5x of the nudged
-        oracle's (measured 0.76 ... 0.89x: the kernel tracks the oracle more closely than the oracle tracks its nudged self).  tests/golden/c4_margins.txt
+        queries of the mean self-agreement (measured: kernel 0.955; nudged oracle 0.945 ... 0.975, mean 0.958 at 1 % of the pixels,
+        0.977 at 0.1 %), every output's rms deviation within 1.5x of the nudged oracle's (measured 0.76 ... 0.91x even against the
+        0.1 % nudge: the kernel tracks the oracle more closely than the oracle tracks its nudged self).  tests/golden/c4_margins.txt
         (probe_c4_margins.py) is why the gate is relative: on the best linear class heads there are for this network two faithful
         bf16 evaluations agree on 96-99.5 % of the labels, so a fixed '>= 0.99' would test the weights' margins, not the kernels."""
     def rms(a, b):
@@ -715,9 +716,9 @@ def test_bf16_r101_full_size_vs_bf16_faithful_oracle(measured):
     torch.set_num_threads(8)
     ref_b = O.detr_forward_bf16(sd, img.cpu(), blocks=(3, 4, 23, 3))
     ref_f = O.detr_forward(sd, img.cpu(), blocks=(3, 4, 23, 3))
-    ref_b2 = []      # three more, independently rounding evaluations of the oracle: one bf16 ulp on 0.1 % of the pixels
-    for seed in (1, 2, 3):
-        nudge = torch.rand(img.shape, generator=torch.Generator().manual_seed(seed)) < 1e-3
+    ref_b2 = []      # three more, independently rounding evaluations of the oracle: one bf16 ulp on 1 % of the pixels (the kernel's own
+    for seed in (1, 2, 3):      # deviations -- one-ulp ties of the fp32 summation order -- start in every layer, in 3e-4 ... 5e-3 of the elements)
+        nudge = torch.rand(img.shape, generator=torch.Generator().manual_seed(seed)) < 1e-2
         ref_b2.append(O.detr_forward_bf16(sd, torch.where(nudge, img.cpu() * (1 + 2.0 ** -7), img.cpu()), blocks=(3, 4, 23, 3)))
     out = det(img)
     _bf16_check(out, ref_b, ref_f, measured, "full", ref_b2)
