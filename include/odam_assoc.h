@@ -110,6 +110,15 @@ int odam_assoc_stage_stamps(odam_assoc* m, int enable, unsigned long long* out, 
  * 1 the descriptors [(T+30), 256], 2 the score matrix [T, 32] (synchronises the device) */
 int odam_assoc_debug_read(odam_assoc* m, int which, float* out, long long n);
 
+/* hungarian_matching (src/models/associator.py:19-35) on the device, stream-ordered: the assignment scipy.optimize.linear_sum_assignment
+ * returns for the cost matrix 1 - scores (its shortest-augmenting-path solver restated with its tie order, binary64 duals), scores = exp(Z)
+ * when log_domain != 0 (Z = the log assignment of odam_assoc_forward without its dustbin row / column: n_tracks x n_det, row stride ldz) or
+ * Z itself; match_out [n_det] (device or pinned host) receives the track index of every detection whose matched score exceeds threshold,
+ * -1 otherwise; *status (device or pinned host) 0, or 1 for an infeasible matrix.  Up to 32 x 128 after the solver's transposition
+ * (min(n_tracks, n_det) <= 32, max <= 128), ODAM_E_LIMIT (3) beyond: the caller then solves on the host. */
+int odam_assoc_hungarian(const float* Z, int n_tracks, int n_det, int ldz, double threshold, int log_domain, int* match_out, int* status,
+                         void* stream);
+
 /* log_optimal_transport alone: scores [dev][m, n] with row stride lds, alpha = bin_score */
 int odam_assoc_sinkhorn(const float* scores, int lds, int m, int n, float alpha, int iters, float* Z_out, void* stream);
 

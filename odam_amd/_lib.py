@@ -50,6 +50,13 @@ def config():
     return {k: int(v.rstrip("*")) for k, v in (kv.split("=") for kv in buf.value.decode().split())}
 
 
+def get_config(key):
+    """one switch of the table (a single cheap call: used per frame by the associator)"""
+    v = ctypes.c_int(0)
+    check(lib().odam_config_get(key.encode(), ctypes.byref(v)), f"odam_config_get({key})")
+    return v.value
+
+
 def set_config(key, value):
     check(lib().odam_config_set(key.encode(), ctypes.c_int(int(value))), f"odam_config_set({key})")
 

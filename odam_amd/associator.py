@@ -3,8 +3,11 @@
     out = associator(data, match_threshold, eval_only=True)
     out["matches"][0]  -> track id per detection (-1 = new track)      (hungarian_matching, :19-35)
     out["pred"][0][0]  -> log assignment [(T+1), (n_det+1)] tensor      (log_optimal_transport, :283-298)
-The network forward and the 100 Sinkhorn iterations run in the gfx950 library (include/odam_assoc.h); the
-Hungarian assignment stays on the host with scipy, exactly as the reference does."""
+The network forward and the 100 Sinkhorn iterations run in the gfx950 library (include/odam_assoc.h).  The Hungarian step is scipy's on
+the host, exactly as the reference does (odam_config assoc.hungarian = 0, the default), or the library's (assoc.hungarian = 1:
+odam_assoc_hungarian restates scipy's shortest-augmenting-path solver with its tie order on one wavefront, launched behind the Sinkhorn
+loop; same matching on every fixture and on matrices full of ties -- tests/test_assoc_gpu.py -- but 0.01 ms per frame slower, because the
+host has to wait for the device either way)."""
 import ctypes
 import math
 
@@ -234,7 +237,7 @@ class Associator:
         never all become resident (the bounded wait would abandon every launch and re-run it through the sequence)."""
         _lib.check(_lib.lib().odam_assoc_set_persistent(self._handle(), ctypes.c_int(1 if on else 0)), "odam_assoc_set_persistent")
 
-    def assignment(self, tracks, detections, n_tracks, n_det, sequence=False):
+    def assignment(self, tracks, detections, n_tracks, n_det, sequence=False, threshold=None):
         """tracks [T,79,100], detections [1,79,30] or [79,30] (any device) -> Z [(T+1),(n_det+1)] device tensor.
         Stream-ordered; sequence=True takes the launch-sequence path (no device-wide barrier).
 
@@ -263,11 +266,21 @@ class Associator:
         with torch.cuda.device(dev):
             _lib.check(fn(self._handle(), _lib.ptr(tr), ctypes.c_int(n_tracks), _lib.ptr(de), ctypes.c_int(n_det), _lib.ptr(Z),
                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), what)
-        if _pinned:
+            self._match = None
+            if threshold is not None and _lib.get_config("assoc.hungarian") and min(n_tracks, n_det) <= 32 and max(n_tracks, n_det) <= 128:
+                # the Hungarian step behind the Sinkhorn loop on the same stream: match [n_det] + status into pinned memory next to Z
+                if getattr(self, "_pin_match", None) is None:
+                    self._pin_match = torch.empty(32, dtype=torch.int32).pin_memory()
+                _lib.check(L.odam_assoc_hungarian(_lib.ptr(Z), ctypes.c_int(n_tracks), ctypes.c_int(n_det), ctypes.c_int(n_det + 1),
+                                                  ctypes.c_double(float(threshold)), ctypes.c_int(1), _lib.ptr(self._pin_match),
+                                                  ctypes.c_void_p(self._pin_match.data_ptr() + 4 * 31),
+                                                  ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "odam_assoc_hungarian")
+                self._match = (self._pin_match, n_det)
+        if _pinned or self._match is not None:
             torch.cuda.current_stream(dev).synchronize()
         return Z
 
-    def assignment_checked(self, tracks, detections, n_tracks, n_det):
+    def assignment_checked(self, tracks, detections, n_tracks, n_det, threshold=None):
         """assignment() + synchronisation + the lost-launch check: if the persistent matching kernel could not get all its
         workgroups resident within the barrier bound (a foreign kernel held the CUs), this frame is run again through the
         launch sequence in the same process and counted in self.lost_launches.  The reference cannot fail this way
@@ -275,7 +288,7 @@ class Associator:
         kernels then read them from, and write Z to, pinned memory: no copy commands), on the device otherwise."""
         self._pin_mode = True
         try:
-            Z = self.assignment(tracks, detections, n_tracks, n_det)
+            Z = self.assignment(tracks, detections, n_tracks, n_det, threshold=threshold)
             torch.cuda.current_stream(self.device).synchronize()
             n = ctypes.c_uint(0)
             _lib.check(_lib.lib().odam_assoc_lost_launches(self._handle(), ctypes.byref(n)), "odam_assoc_lost_launches")
@@ -283,7 +296,7 @@ class Associator:
                 self._lost_seen = n.value
                 self.lost_launches += 1
                 self._lost_in_a_row = getattr(self, "_lost_in_a_row", 0) + 1
-                Z = self.assignment(tracks, detections, n_tracks, n_det, sequence=True)
+                Z = self.assignment(tracks, detections, n_tracks, n_det, sequence=True, threshold=threshold)
                 torch.cuda.current_stream(self.device).synchronize()
                 if self._lost_in_a_row >= 3:
                     # three abandoned launches in a row are not a busy device but a condition that will not pass (the row-partitioned
@@ -304,9 +317,14 @@ class Associator:
         n_tracks, n_det = valid[0]
         # ONE download of the log assignment: both consumers -- the Hungarian step here and process_frame's score matrix
         # (processor.py:337-339: predictions['pred'][0][0].cpu().exp()) -- read it on the host
-        Z = self.assignment_checked(in_data["tracks"], in_data["detections"][0], n_tracks, n_det).cpu()
+        self._match = None      # (set by assignment() when the Hungarian step ran on the device behind it)
+        Z = self.assignment_checked(in_data["tracks"], in_data["detections"][0], n_tracks, n_det, threshold=threshold).cpu()
         pred = [Z[None]]
-        match = [hungarian_matching(Z[:-1, :-1].exp(), threshold)]
+        m = getattr(self, "_match", None)
+        if m is not None and int(m[0][31]) == 0:      # solved on the device behind the Sinkhorn loop (status word 0)
+            match = [m[0][:n_det].numpy().astype(np.float64)]
+        else:
+            match = [hungarian_matching(Z[:-1, :-1].exp(), threshold)]
         return {"pred": pred, "loss": 0, "matches": match}
 
     forward = __call__

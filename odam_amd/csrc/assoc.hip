@@ -1591,3 +1591,156 @@ extern "C" int odam_assoc_sinkhorn(const float* scores, int lds_, int m_, int n_
     }
     return launch_sinkhorn(scores, lds_, m_, n_, n_, alpha, iters, Z_out, nullptr, (hipStream_t)stream);
 }
+
+// ---- the Hungarian step (src/models/associator.py:19-35) on the device ------------------------------------------------------------
+// hungarian_matching() hands 1 - exp(Z[:-1, :-1]) to scipy.optimize.linear_sum_assignment and keeps the pairs whose score exceeds the
+// threshold.  scipy's solver is the shortest-augmenting-path algorithm for the rectangular problem (Crouse 2016; scipy/optimize/
+// rectangular_lsap, version 1.6 on -- a published algorithm with a fixed, sequential tie order: columns are scanned in the order of a
+// "remaining" list that starts reversed and shrinks by swap-removal, among equal reduced costs the LAST unassigned column of that scan wins,
+// else the first one).  One wavefront restates it: lanes own columns (two per lane: up to 128), the scan over the remaining columns is one
+// lexicographic reduction on (reduced cost, assigned?, position in the list), duals and costs in binary64 in scipy's order of operations.
+// The result is the same matching whenever the scores are the same floats; the scores themselves are exp() of the device here and torch's
+// CPU exp on the host path (one ulp apart at most: a pair changes only on an exact tie or a score within an ulp of the threshold).
+namespace {
+constexpr int HG_MAXR = 32, HG_MAXC = 128;
+// what lane (l ^ (1 << BIT)) holds, on DPP / v_permlane*_swap (sk_wave.h): bit moves, any payload
+template <int BIT> __device__ __forceinline__ unsigned hg_xor(unsigned v) { return __builtin_bit_cast(unsigned, sk_xor<BIT>(__builtin_bit_cast(float, v))); }
+struct HgKey { double c; unsigned t; };      // reduced cost; tail = not-free << 19 | tie key << 12 | column << 5 | row of the column (if assigned)
+template <int BIT> __device__ __forceinline__ void hg_step(HgKey& b) {
+    const unsigned long long cb = __builtin_bit_cast(unsigned long long, b.c);
+    const unsigned lo = hg_xor<BIT>((unsigned)cb), hi = hg_xor<BIT>((unsigned)(cb >> 32)), ot = hg_xor<BIT>(b.t);
+    const double oc = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    if (oc < b.c || (oc == b.c && ot < b.t)) { b.c = oc; b.t = ot; }
+}
+__global__ __launch_bounds__(64) void hungarian_wave_kernel(const float* __restrict__ Z, int T, int n_det, int ldz, double thr, int log_domain,
+                                                            int* __restrict__ match_out, int* __restrict__ status) {
+    __shared__ double cost[HG_MAXR * HG_MAXC];
+    __shared__ float sc_[HG_MAXR * HG_MAXC];
+    __shared__ double u[HG_MAXR], spc_l[HG_MAXC];
+    __shared__ int col4row[HG_MAXR], row4col[HG_MAXC], path_l[HG_MAXC], remaining[HG_MAXC];
+    __shared__ unsigned char SR[HG_MAXR];
+    const int lane = threadIdx.x;
+    // ONE wavefront: its LDS operations execute in program order, so a wave-level fence (no s_barrier) orders a lane's write before the others' reads
+    auto sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const bool tr = n_det < T;                       // scipy transposes a tall matrix
+    const int nr = tr ? n_det : T, nc = tr ? T : n_det;
+    // Z may live in pinned HOST memory (the Sinkhorn kernel writes it there): every element is requested once, the requests of a batch of
+    // eight in flight together, and kept in LDS as the score (the threshold test at the end reads it again)
+    const int total = T * n_det;
+    for (int base = 0; base < total; base += 64 * 8) {
+        float z[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = base + k * 64 + lane;
+            const int r = idx / n_det, c = idx - r * n_det;
+            z[k] = idx < total ? Z[(size_t)r * ldz + c] : 0.0f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int idx = base + k * 64 + lane;
+            if (idx < total) {
+                const int r = idx / n_det, c = idx - r * n_det;
+                const float s = log_domain ? expf(z[k]) : z[k];
+                const int i = tr ? c : r, j = tr ? r : c;
+                sc_[i * HG_MAXC + j] = s;
+                cost[i * HG_MAXC + j] = (double)(1.0f - s);      // numpy: float32 (1 - scores), widened by the solver
+            }
+        }
+    }
+    // a lane keeps the state of its two columns (lane, lane + 64) in registers; rows, the scan list and what lane 0's augmentation walks are in LDS
+    const int jc[2] = {lane, lane + 64};
+    const bool has[2] = {jc[0] < nc, jc[1] < nc};
+    double vv[2] = {0.0, 0.0}, spc[2];
+    int r4c[2] = {-1, -1}, pth[2] = {-1, -1}, pos[2];
+    bool SC[2];
+    for (int j = lane; j < nc; j += 64) row4col[j] = -1;
+    if (lane < nr) { u[lane] = 0.0; col4row[lane] = -1; }
+    sync();
+    const double INF = __builtin_huge_val();
+    for (int cur = 0; cur < nr; cur++) {
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            if (has[q]) { remaining[nc - 1 - jc[q]] = jc[q]; r4c[q] = row4col[jc[q]]; }      // list position it holds column nc - it - 1
+            pos[q] = nc - 1 - jc[q]; spc[q] = INF; SC[q] = !has[q];
+        }
+        if (lane < nr) SR[lane] = 0;
+        sync();
+        double minVal = 0.0;
+        int i = cur, num_remaining = nc, sink = -1;
+        while (sink == -1) {
+            if (lane == 0) SR[i] = 1;
+            const double ui = u[i];
+            HgKey best{INF, 0xffffffffu};
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (SC[q]) continue;
+                const double r = minVal + cost[i * HG_MAXC + jc[q]] - ui - vv[q];
+                if (r < spc[q]) { pth[q] = i; spc[q] = r; }
+                const bool free_ = r4c[q] == -1;
+                // among equal reduced costs: the LAST free column of the scan (largest list position), else the first assigned one
+                const unsigned t = (free_ ? 0u : 1u << 19) | (unsigned)(free_ ? 127 - pos[q] : pos[q]) << 12 | (unsigned)jc[q] << 5 | (unsigned)(free_ ? 0 : r4c[q]);
+                if (spc[q] < best.c || (spc[q] == best.c && t < best.t)) { best.c = spc[q]; best.t = t; }
+            }
+            hg_step<0>(best); hg_step<1>(best); hg_step<2>(best); hg_step<3>(best); hg_step<4>(best); hg_step<5>(best);
+            minVal = best.c;
+            if (!(minVal < INF)) { if (lane == 0) *status = 1; return; }      // infeasible, or NaN scores (scipy raises)
+            const int j = (best.t >> 5) & 127, kk = (best.t >> 12) & 127;
+            const bool jfree = !(best.t >> 19);
+            const int idx = jfree ? 127 - kk : kk;                             // the winner's position in the list
+            if (jfree) sink = j; else i = best.t & 31;
+            const int last = remaining[num_remaining - 1];
+            sync();
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (jc[q] == j) { SC[q] = true; remaining[idx] = last; }
+                if (jc[q] == last) pos[q] = idx;
+            }
+            num_remaining--;
+            sync();
+        }
+        // what the dual update of the rows and lane 0's augmentation read by column index
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (has[q]) { spc_l[jc[q]] = spc[q]; path_l[jc[q]] = pth[q]; if (SC[q]) vv[q] -= minVal - spc[q]; }
+        sync();
+        if (lane < nr && SR[lane] && lane != cur) u[lane] += minVal - spc_l[col4row[lane]];
+        if (lane == 0) u[cur] += minVal;
+        sync();
+        if (lane == 0) {
+            int j = sink;
+            while (true) {
+                const int ii = path_l[j];
+                row4col[j] = ii;
+                const int t = col4row[ii]; col4row[ii] = j; j = t;
+                if (ii == cur) break;
+            }
+        }
+        sync();
+    }
+    for (int c = lane; c < n_det; c += 64) match_out[c] = -1;
+    sync();
+    if (lane < nr) {
+        const int jcol = col4row[lane];
+        if (jcol >= 0) {
+            const int r = tr ? jcol : lane, c = tr ? lane : jcol;
+            if ((double)sc_[lane * HG_MAXC + jcol] > thr) match_out[c] = r;
+        }
+    }
+    if (lane == 0) *status = 0;
+}
+}  // namespace
+
+extern "C" int odam_assoc_hungarian(const float* Z, int n_tracks, int n_det, int ldz, double threshold, int log_domain, int* match_out,
+                                    int* status, void* stream) {
+    if (!Z || !match_out || !status || n_tracks < 0 || n_det < 0 || ldz < n_det)
+        return odam_fail(1, "odam_assoc_hungarian: bad argument");
+    const int nr = n_det < n_tracks ? n_det : n_tracks, nc = n_det < n_tracks ? n_tracks : n_det;
+    if (nr > HG_MAXR || nc > HG_MAXC) return odam_fail(3, "odam_assoc_hungarian: more than 32 x 128 (the caller solves it on the host)");      // (3 = ODAM_E_LIMIT of odam_sq.h)
+    hipLaunchKernelGGL(hungarian_wave_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, Z, n_tracks, n_det, ldz, threshold, log_domain, match_out, status);
+    ODAM_HIP(hipGetLastError());
+    return 0;
+}

@@ -36,6 +36,9 @@ enum Key {
     ASSOC_SK_FAST,  // Sinkhorn on one wavefront (<= 128 rows, <= 32 columns; assoc.hip sinkhorn_wave_kernel): 1 (default) scaling factors absorbed
                     // into the potentials every 10 iterations, restarting with 1 and then in log space if a factor leaves its range;
                     // 2 / 3 = start at that rung (tests); 0 = the sixteen-wave log-space kernel
+    ASSOC_HUNGARIAN,  // the Hungarian step of the association (associator.py:19-35): 1 on the device behind the Sinkhorn loop (odam_assoc_hungarian: scipy's
+                    // solver restated on one wavefront), 0 (default) scipy on the host as the reference does -- measured 0.01 ms per frame FASTER than the
+                    // device form (the host waits for the device either way).  Read by the HOST side (odam_amd/associator.py), the library only keeps it
     N_KEYS
 };
 int get(Key k);

@@ -14,7 +14,7 @@ many = associator.Associator(cfg, max_tracks=64, device=DEV); many.load_state_di
 del os.environ["ODAM_ASSOC_PERSIST"]
 orig = one.assignment
 log = []
-def both(tracks, detections, n_tracks, n_det):
+def both(tracks, detections, n_tracks, n_det, **kw):
     Za = orig(tracks, detections, n_tracks, n_det)
     Zb = many.assignment(tracks, detections, n_tracks, n_det)
     Zc = orig(tracks, detections, n_tracks, n_det)

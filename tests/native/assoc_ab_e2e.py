@@ -27,7 +27,7 @@ def dump(h, which, rows, cols):
     _lib.check(_lib.lib().odam_assoc_debug_read(h, which, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_longlong(buf.size)), "dbg")
     return buf
 shown = [0]
-def both(tracks, detections, n_tracks, n_det):
+def both(tracks, detections, n_tracks, n_det, **kw):
     a = orig(tracks, detections, n_tracks, n_det).cpu().numpy()
     da = [dump(one._handle(), 0, n_tracks + 30, 512), dump(one._handle(), 1, n_tracks + 30, 256), dump(one._handle(), 2, n_tracks, 32)]
     b = many.assignment(tracks, detections, n_tracks, n_det).cpu().numpy()

@@ -9,6 +9,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_sinkhorn_kernel_vs_reference(golden):
@@ -447,3 +448,65 @@ def test_row_partitioned_matching_kernel_equals_the_device_wide_one(golden):
     finally:
         _lib.set_config("assoc.persist", 2)
         a.close()
+
+
+def _hungarian_device(scores_or_Z, thr, log_domain):
+    """odam_assoc_hungarian on a [T, n] float32 matrix -> match [n] (float64, as hungarian_matching returns), status"""
+    from odam_amd import _lib
+    M = torch.as_tensor(scores_or_Z, dtype=torch.float32).contiguous().to(DEV)
+    T, n = M.shape
+    out = torch.full((32,), -7, dtype=torch.int32, device=DEV)
+    _lib.check(_lib.lib().odam_assoc_hungarian(_lib.ptr(M), ctypes.c_int(T), ctypes.c_int(n), ctypes.c_int(n), ctypes.c_double(thr),
+                                               ctypes.c_int(log_domain), _lib.ptr(out), ctypes.c_void_p(out.data_ptr() + 4 * 31),
+                                               ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "odam_assoc_hungarian")
+    torch.cuda.synchronize()
+    o = out.cpu().numpy()
+    return o[:n].astype(np.float64), int(o[31])
+
+
+def test_hungarian_on_the_device_equals_scipy():
+    """odam_assoc_hungarian (scipy's rectangular shortest-augmenting-path solver restated on one wavefront, associator.py:19-35) against
+    hungarian_matching = scipy.optimize.linear_sum_assignment on the same float32 scores: random matrices wide, tall and square up to
+    30 detections x 128 tracks, matrices FULL of exact ties (constants, few distinct values, duplicated rows and columns: scipy's tie order
+    is part of the result), and every log-assignment matrix of the two reference-run fixtures (there through the device's own exp)."""
+    from odam_amd.associator import hungarian_matching
+    rng = np.random.default_rng(5)
+    cases = []
+    for T, n in ((5, 3), (3, 5), (30, 30), (42, 17), (17, 30), (100, 30), (128, 30), (1, 1), (1, 30), (60, 1), (31, 2), (2, 31)):
+        for rep in range(3):
+            cases.append(rng.random((T, n), dtype=np.float32))
+    for T, n in ((6, 6), (9, 4), (4, 9), (40, 30), (30, 12)):
+        cases.append(np.full((T, n), 0.5, np.float32))                                   # scipy: the identity on a constant matrix
+        cases.append((rng.integers(0, 3, (T, n)) / 4).astype(np.float32))                # three distinct values
+        cases.append((rng.integers(0, 8, (T, n)) / 8).astype(np.float32))
+        a = rng.random((T, n), dtype=np.float32); a[1::2] = a[0::2][:len(a[1::2])]       # duplicated rows
+        cases.append(a)
+        b = rng.random((T, n), dtype=np.float32); b[:, 1::2] = b[:, 0::2][:, :b[:, 1::2].shape[1]]      # duplicated columns
+        cases.append(b)
+    for thr in (0.0, 0.2, 0.6):
+        for sc in cases:
+            want = hungarian_matching(torch.from_numpy(sc), thr)
+            got, st = _hungarian_device(sc, thr, 0)
+            assert st == 0 and np.array_equal(got, want), (sc.shape, thr, got, want)
+    n_fix = 0
+    for name in ("e2e.npz", "process_tracks_net.npz"):
+        z = np.load(os.path.join(GOLD, name), allow_pickle=True)
+        for k in [k for k in z.files if k.startswith("Z") and k[1:].isdigit()]:
+            Z = torch.from_numpy(z[k].astype(np.float32))
+            if Z.shape[0] < 2 or Z.shape[1] < 2:
+                continue
+            for thr in (0.1, 0.2):
+                want = hungarian_matching(Z[:-1, :-1].exp(), thr)
+                got, st = _hungarian_device(Z[:-1, :-1].contiguous(), thr, 1)
+                assert st == 0 and np.array_equal(got, want), (name, k, thr)
+                n_fix += 1
+    assert n_fix >= 100
+    # beyond 32 x 128 the entry refuses (the host then solves it), and an all-NaN matrix (an abandoned persistent launch) is reported as infeasible
+    from odam_amd import _lib
+    big = torch.rand(40, 33, device=DEV)
+    out = torch.zeros(64, dtype=torch.int32, device=DEV)
+    assert _lib.lib().odam_assoc_hungarian(_lib.ptr(big), 40, 33, 33, ctypes.c_double(0.1), 0, _lib.ptr(out), ctypes.c_void_p(out.data_ptr() + 4 * 63),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 3
+    _, st = _hungarian_device(np.full((4, 3), np.nan, np.float32), 0.1, 0)
+    assert st == 1
+

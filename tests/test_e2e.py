@@ -41,7 +41,17 @@ def _key(t):
     return tuple(map(tuple, np.asarray(t)[:, :2]))
 
 
-def test_whole_pipeline_matches_the_reference_run(golden, measured):
+@pytest.fixture(params=[1, 0], ids=["hungarian on the device", "hungarian by scipy"])
+def hungarian_mode(request):
+    """the whole-chain test runs with the Hungarian step on the device (odam_assoc_hungarian) and on the host (scipy, the library's default)"""
+    from odam_amd import _lib
+    old = _lib.get_config("assoc.hungarian")
+    _lib.set_config("assoc.hungarian", request.param)
+    yield request.param
+    _lib.set_config("assoc.hungarian", old)
+
+
+def test_whole_pipeline_matches_the_reference_run(golden, measured, hungarian_mode):
     from PIL import Image
     from odam_amd import associator, detector, synth, transforms, weights
     from odam_amd.processor import OdamProcess
@@ -71,9 +81,9 @@ def test_whole_pipeline_matches_the_reference_run(golden, measured):
     plain = net.assignment
     dP, same = [], []
 
-    def checked(tracks, detections, n_tracks, n_det):
+    def checked(tracks, detections, n_tracks, n_det, **kw):
         Zr = z[f"Z{len(dP)}"]
-        Zt = plain(tracks, detections, n_tracks, n_det)
+        Zt = plain(tracks, detections, n_tracks, n_det, **kw)
         Z = Zt.cpu().numpy()
         assert Z.shape == Zr.shape, (len(dP), Z.shape, Zr.shape)
         P, Pr = np.exp(Z), np.exp(Zr)
