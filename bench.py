@@ -361,8 +361,9 @@ def main():
                                       "measured": "QK^T + PV flops of the fused attention kernel / its launch durations "
                                                   "(HIP events, one forward alone on one stream)"}
     if mine:
-        # the fit kernel alone: one more pass over this rank's objects with an event pair around the launch
-        rec = {}
+        # the fit kernel alone: three more passes over this rank's objects with an event pair around the launch, the median taken (round 5: a
+        # single pass read 8.7 ms on one box and 9.9 on the next; tests/native/perf_sq_fit30.py, seven passes, reads 8.4 on both)
+        rec = {"ev": []}
         orig_fit = fitter.fit
 
         def timed_fit(*a, **k):
@@ -370,16 +371,17 @@ def main():
             e0.record()
             out = orig_fit(*a, **k)
             e1.record()
-            rec["ev"], rec["views"] = (e0, e1), [int(v) for v in a[2]]
+            rec["ev"].append((e0, e1)); rec["views"] = [int(v) for v in a[2]]
             return out
 
         fitter.fit = timed_fit
-        multi_view.optim_process([tracks[i] for i in mine], frame_ids, scene["T_wcs"], scene["P_cws"], synth.IMG_H,
-                                 synth.IMG_W, K, "super_quadric", True, 200, 10, fitter=fitter)
+        for _ in range(3):
+            multi_view.optim_process([tracks[i] for i in mine], frame_ids, scene["T_wcs"], scene["P_cws"], synth.IMG_H,
+                                     synth.IMG_W, K, "super_quadric", True, 200, 10, fitter=fitter)
         fitter.fit = orig_fit
         torch.cuda.synchronize()
-        if "ev" in rec:
-            sq_ms = rec["ev"][0].elapsed_time(rec["ev"][1])
+        if rec["ev"]:
+            sq_ms = sorted(a_.elapsed_time(b_) for a_, b_ in rec["ev"])[len(rec["ev"]) // 2]
             views = rec["views"]
             alg = sum(12000 + 80 * v + 40 for v in views) * 200.0   # streaming-formulation bytes per object-step
             vu = pmc.get("sq_fit", {}).get("valu_util")
