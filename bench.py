@@ -11,8 +11,12 @@ One "step" = one pass of the hot path over one scene:
 value = frames of the WHOLE scene x steps / wall time (max over ranks).  Strong scaling: the scene is fixed.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N --steps K --warmup W          # no WORLD_SIZE in the environment: this process starts the N ranks itself
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          # ... or an external launcher does (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)
+
+Rank set-up is the reference's env-driven pattern (src/utils/misc.py:390-412: RANK / WORLD_SIZE / LOCAL_RANK -> set_device ->
+init_process_group('nccl')); `launch_ranks` below supplies that environment when nobody else has.
 """
 import argparse
 import json
@@ -29,7 +33,6 @@ sys.path.insert(0, REPO)
 from odam_amd import detector as det_mod, multi_view, parallel, sq, synth, transforms, weights  # noqa: E402
 from odam_amd.processor import detection_array  # noqa: E402
 
-FLOPS_PER_FRAME_R50 = 163.1e9   # SURVEY.md section 2.2 / BASELINE.md (2 x MAC, 800x1066 input)
 PEAK_FP32_MFMA = 157.3e12       # MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
 PEAK_HBM = 8.0e12                # MI355X_MICROARCH.md, HBM3E
 PEAK_BF16_MFMA = 2.5e15          # MI355X_MICROARCH.md, dense v_mfma_f32_32x32x16_bf16
@@ -89,6 +92,49 @@ def build_frames(f0, f1, device, seed=0):
     return torch.from_numpy(out).to(device)
 
 
+def launch_ranks(n, argv, one_device):
+    """`python bench.py --gpus N` from a plain shell: start N fresh rank processes of this same command line, one per GPU, with the
+    environment an external launcher would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT; the pattern the
+    reference reads in src/utils/misc.py:390-412), wait for all of them, pass rank 0's stdout (the JSON line) through and return
+    non-zero if any rank did.  This parent has imported torch and nothing else: it makes no HIP call (device_count() does not
+    initialise the GPU), so the children are ordinary child processes of a process that never touched the device -- never an exec
+    from one that has.  Fewer than N visible devices is refused unless --one-device lets the ranks share device 0."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n and not one_device:
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible GPUs, this machine shows {have}; refusing to report a run of fewer ranks "
+                         f"as n_gpus={n} (use --one-device to let {n} ranks share one GPU for a functional check)\n")
+        return 2
+    with socket.socket() as s:      # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ODAM_BENCH_LAUNCHER="bench.py")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, min(16, (os.cpu_count() or 16) // n))))
+        # ranks other than 0 print nothing on stdout by contract; whatever a library writes there goes to stderr, so stdout is the line alone
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.remove(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with code {code}; stopping the other ranks\n")
+                for o in alive:      # exactly the children this process started, by handle
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,9 +169,15 @@ def main():
                     "detection + gather of chunk i + 1 (pipeline.run_scene overlap; auto = on for more than one rank and more than one chunk)")
     ap.add_argument("--dump-chain", default="", help="every rank r writes tracks, fits and merge result of the --full-chain block to <path>.r<r>.npz")
     ap.add_argument("--only-chain", action="store_true", help="run nothing but the --full-chain block (tests)")
+    ap.add_argument("--no-pin", action="store_true", help="leave odam_config cg.pin at 0 (kernel choice by problem size: a rank's result then "
+                    "depends on its shard size at the 1e-5 level and an N-rank line is not bit-comparable with the one-rank line)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.one_device))
     ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={ws}: the line would report a rank count nobody asked for")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.one_device:
@@ -141,8 +193,23 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=ws)
     device = f"cuda:{local_rank}"
+    from odam_amd import _lib
+    if not args.no_pin:
+        # every size-dependent kernel choice as for a device-filling problem: a frame's result is then the same bits
+        # whatever shard or ragged batch it arrives in, so the N-rank lines of a scaling run and the one-rank line compute the same thing
+        _lib.set_config("cg.pin", 1)
+    native = None
     if args.native_collectives and (ws > 1 or args.force_collectives):
-        parallel.use_native_collectives(device)
+        native = parallel.use_native_collectives(device)
+    # who carries the collectives of this line, and over how many ranks (None: a world of one without a process group)
+    if ws > 1 or args.force_collectives:
+        collectives = {"backend": ("rccl (odam_comm.h communicator)" if native else
+                                   {"nccl": "rccl (torch.distributed nccl)"}.get(args.backend, args.backend)),
+                       "world": int(native[0]) if native else torch.distributed.get_world_size(),
+                       "launcher": os.environ.get("ODAM_BENCH_LAUNCHER", "external (RANK / WORLD_SIZE in the environment)"),
+                       "devices": "one shared (--one-device)" if args.one_device else "one per rank"}
+    else:
+        collectives = None
 
     coll_dev = device if (args.backend == "nccl" or args.native_collectives) else "cpu"
     N = args.frames
@@ -243,7 +310,6 @@ def main():
     att_n, att_ms, att_flops = detector.profile_read_attention(H, W)
     detector.profile(H, W, False)
     # the same scene with every fp32 layer on the fp32 matrix instruction (v_mfma_f32_32x32x2_f32): one untimed + one timed pass
-    from odam_amd import _lib
     split_mode = _lib.config()["cg.f32"] == 2
     f32_instr = None
     if split_mode and rank == 0 and ws == 1:
@@ -276,6 +342,8 @@ def main():
         "value": N * args.steps / dt,
         "unit": "frames/s",
         "n_gpus": ws,
+        "rccl_world": collectives["world"] if collectives and collectives["backend"].startswith("rccl") else (1 if ws == 1 else None),
+        "collectives": collectives,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps,

@@ -267,7 +267,8 @@ class Associator:
             _lib.check(fn(self._handle(), _lib.ptr(tr), ctypes.c_int(n_tracks), _lib.ptr(de), ctypes.c_int(n_det), _lib.ptr(Z),
                           ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), what)
             self._match = None
-            if threshold is not None and _lib.get_config("assoc.hungarian") and min(n_tracks, n_det) <= 32 and max(n_tracks, n_det) <= 128:
+            if threshold is not None and _lib.get_config("assoc.hungarian") and min(n_tracks, n_det) <= 32 and max(n_tracks, n_det) <= 128 \
+                    and n_det <= 31:      # the pinned result is 31 match words + the status word
                 # the Hungarian step behind the Sinkhorn loop on the same stream: match [n_det] + status into pinned memory next to Z
                 if getattr(self, "_pin_match", None) is None:
                     self._pin_match = torch.empty(32, dtype=torch.int32).pin_memory()

@@ -728,8 +728,12 @@ __global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
             unsigned long long* xq = A.xroots + slot * (size_t)(A.split * 9);
             float* xl = want_loss ? A.xloss + slot * (size_t)A.max_views * 4 : nullptr;
             const unsigned long long tag = (unsigned long long)(it + 1) << 32;
-            // wavefront w looks after residue classes w and w + 16 (a split of up to 32): its own class is published, a partner's collected
+            // wavefront w looks after residue classes w and w + 16 (a split of up to 32): its own class is published, a partner's collected.
+            // The own class goes FIRST (pass 0): a wavefront that waited for partner w before publishing class w + 16 would hand a late
+            // partner's delay on to everyone waiting for w + 16
+            for (int pass = 0; pass < 2; pass++)
             for (int jj = wid; jj < keff; jj += NT / 64) {
+            if ((jj == wj) != (pass == 0)) continue;
             if (jj == wj) {
                 // (the partners of an object share an XCD -- see the workgroup-id mapping above --, so the root only has to reach that XCD's
                 //  L2: a workgroup-scope store, read back below by loads that miss the vector L1 (sc0 sc1); tests/native/xcd_barrier_probe.hip)

@@ -68,12 +68,18 @@ def _native(device):
     peers (a deadlock) and, under a gloo group, hand CUDA tensors to gloo."""
     if not _NATIVE:
         return None
+    d = None if device is None else torch.device(device)
+    if (d is None or d.type == "cpu" or d.index is None) and len(_NATIVE) == 1:
+        # no device named (or host staging asked for): the communicator's OWN device, not the calling thread's current one -- a helper
+        # thread starts on device 0, and a rank-dependent error here would strand the peers inside the collective (ADVICE r5)
+        key = next(iter(_NATIVE))
+        return _NATIVE[key] + (key,)
     key = _dev_key(device)
     if key not in _NATIVE:
         from . import _lib
         raise _lib.OdamError(f"native collectives are on (use_native_collectives) but no communicator exists for {key}; "
                              f"have {sorted(_NATIVE)}")
-    return _NATIVE[key]
+    return _NATIVE[key] + (key,)
 
 
 def world():
@@ -135,6 +141,8 @@ def allgather_detections(blk, cnt, n_frames, device=None, force=False):
     per = -(-n_frames // ws)  # padded shard length so all_gather_into_tensor sees equal shapes
     W = MAX_DETS * DET_COLS
     nat = _native(dev)
+    if nat is not None:
+        dev = nat[3]
     if nat is not None:      # the library's own collective (include/odam_comm.h, odam_allgather_detections): block and counts stay separate
         import ctypes
         from . import _lib
@@ -189,6 +197,7 @@ def allgather_rows(local, n_total, owner_lists, device=None, force=False):
     per = max(len(o) for o in owner_lists)
     nat = _native(dev)
     if nat is not None:
+        dev = nat[3]
         import ctypes
         from . import _lib
         pad = torch.zeros((per,) + local.shape[1:], dtype=torch.float32, device=dev)

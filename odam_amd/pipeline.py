@@ -94,6 +94,7 @@ def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=
               runs, in chunk order on every rank; results are identical with and without (the same calls on the same data).
     Returns the second optim_process dict (what the reference pickles), identical on every rank; proc.tracks holds the
     unmerged tracks."""
+    import sys
     import time
     if detect is None:
         if frames is None:
@@ -108,39 +109,70 @@ def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=
     if overlap and len(spans) > 1:
         import queue
         import threading
+        import torch
         q = queue.Queue(maxsize=2)      # at most two chunks of detections ahead of the association loop
+        cancel = threading.Event()
+        # HIP's current device is per THREAD and a new thread starts on device 0: resolve the device here, on the caller's thread, to a
+        # full name ('cuda:N') and make it the worker's current device -- with device=None, rank r's worker would otherwise resolve
+        # 'cuda' (and parallel._dev_key(None)) to GPU 0 and put its collective tensors there
+        if device is None:
+            wdev = parallel._dev_key(None) if (torch.cuda.is_available() and torch.cuda.is_initialized()) else None
+        else:
+            wdev = str(device) if str(device) == "cpu" else parallel._dev_key(device)
+
+        def put(item):
+            while not cancel.is_set():
+                try:
+                    q.put(item, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
 
         def produce():
             try:
-                import torch
-                if device is not None and str(device) != "cpu" and torch.cuda.is_available():
-                    torch.cuda.set_device(torch.device(device))      # the device is per thread
+                if wdev is not None and wdev != "cpu":
+                    torch.cuda.set_device(torch.device(wdev))
                 for c0, c1 in spans:
+                    if cancel.is_set():      # the consumer failed: issue no further collective from this rank
+                        return
                     s0 = time.perf_counter()
                     rows = detect_gathered(detect, c0, c1, device, force)
-                    q.put((c0, rows, time.perf_counter() - s0))
-                q.put(None)
+                    if not put((c0, rows, time.perf_counter() - s0)):
+                        return
+                put(None)
             except BaseException as e:      # noqa: BLE001 -- handed to the consumer, which re-raises it
-                q.put(e)
+                put(e)
 
         th = threading.Thread(target=produce, name="odam-detect", daemon=True)
         th.start()
         waited = 0.0
-        while True:
-            s0 = time.perf_counter()
-            item = q.get()
-            waited += time.perf_counter() - s0
-            if item is None:
-                break
-            if isinstance(item, BaseException):
-                raise item
-            c0, rows, dt_detect = item
-            s1 = time.perf_counter()
-            for i, r in enumerate(rows):
-                proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
-            t["associate"] += time.perf_counter() - s1
-            t["detect_gather"] += dt_detect
-        th.join()
+        try:
+            while True:
+                s0 = time.perf_counter()
+                item = q.get()
+                waited += time.perf_counter() - s0
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                c0, rows, dt_detect = item
+                s1 = time.perf_counter()
+                for i, r in enumerate(rows):
+                    proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
+                t["associate"] += time.perf_counter() - s1
+                t["detect_gather"] += dt_detect
+        finally:
+            # on an exception (here or in the producer) the worker must not keep issuing collectives on this rank alone, nor stay blocked on
+            # a full queue: tell it to stop, make room, wait for it.  (A collective it is INSIDE completes only if the peers reach it too;
+            # the join is bounded so that this rank's exception surfaces either way.)
+            cancel.set()
+            try:
+                while True:
+                    q.get_nowait()
+            except queue.Empty:
+                pass
+            th.join(timeout=None if sys.exc_info()[0] is None else 30.0)
         t["overlapped"] = True
         t["associate_waited_for_detections"] = waited      # what the association loop did NOT hide
     else:

@@ -70,3 +70,35 @@ def test_whole_chain_two_ranks_equal_one_rank(tmp_path):
         for k in za.files:
             assert za[k].shape == z[k].shape, (path, k)
             assert np.array_equal(za[k].view(np.uint8), z[k].view(np.uint8)), (path, k)
+
+
+def test_bench_gpus_2_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE): bench.py::launch_ranks starts the two ranks itself -- fresh child
+    processes of a parent that made no HIP call, with the RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* environment the reference's
+    init_distributed_mode reads (src/utils/misc.py:390-412) -- and relays rank 0's line: n_gpus = 2, a collective world of 2, and the
+    same detections and fits as `--gpus 1`, bit for bit (cg.pin = 1 is the bench's default for every world size)."""
+    import json
+    bench = os.path.join(REPO, "bench.py")
+    a, b = (str(tmp_path / f"{n}.npz") for n in "ab")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "ODAM_CONFIG")}
+    one = subprocess.run([sys.executable, bench, "--gpus", "1", "--dump", a] + ARGS, cwd=REPO, env=env, capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    two = subprocess.run([sys.executable, bench, "--gpus", "2", "--one-device", "--backend", "gloo", "--dump", b] + ARGS, cwd=REPO, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    l1 = json.loads(one.stdout.strip().splitlines()[-1])
+    lines = [l for l in two.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, two.stdout[-2000:]      # rank 0's line and nothing else on stdout
+    l2 = json.loads(lines[0])
+    assert l1["n_gpus"] == 1 and l1["library_config"]["cg.pin"] == 1 and l1["collectives"] is None
+    assert l2["n_gpus"] == 2 and l2["library_config"]["cg.pin"] == 1
+    assert l2["collectives"]["world"] == 2 and l2["collectives"]["launcher"] == "bench.py" and l2["collectives"]["backend"] == "gloo"
+    assert l2["config"]["frames"] == 96 and "cpu_baseline" not in l2
+    za, zb = np.load(a), np.load(b)
+    assert np.array_equal(za["cnt"], zb["cnt"])
+    assert np.array_equal(za["blk"].view(np.uint32), zb["blk"].view(np.uint32))
+    assert np.array_equal(za["fitted"].view(np.uint32), zb["fitted"].view(np.uint32))
+    # a rank that dies takes the job down with a non-zero code instead of leaving the others in a collective
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--one-device", "--backend", "no-such-backend"] + ARGS, cwd=REPO, env=env,
+                         capture_output=True, text=True, timeout=900)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]

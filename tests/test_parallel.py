@@ -122,7 +122,7 @@ def test_allgather_gloo_world_of_8():
     assert len(res) == 8 and all(ok1 and ok2 and ok3 for _, ok1, ok2, ok3 in res), res
 
 
-def _chain(z, oracle, chunk, overlap=None):
+def _chain(z, oracle, chunk, overlap=None, device="cpu", fail_at=None):
     """odam_amd.pipeline.run_scene over the canned-detection sequence of tests/golden/process_tracks.npz with the oracle-backed
     test doubles (tests only): returns everything a rank ends up holding"""
     import sys
@@ -144,7 +144,15 @@ def _chain(z, oracle, chunk, overlap=None):
         calls.append((f0, f1))
         return [np.asarray(z[f"det{ids[f]}"], np.float64).reshape(-1, 79) for f in range(f0, f1)]
     stages = {}
-    out = pipeline.run_scene(proc, len(ids), ids, z["scene_T_wcs"], detect=detect, chunk=chunk, device="cpu", stages=stages, overlap=overlap)
+    if fail_at is not None:
+        inner = proc.process_frame
+
+        def failing(rgb, frame_id, T_wc, detections=None):
+            if frame_id == ids[fail_at]:
+                raise RuntimeError("association failed on purpose")
+            return inner(rgb, frame_id, T_wc, detections=detections)
+        proc.process_frame = failing
+    out = pipeline.run_scene(proc, len(ids), ids, z["scene_T_wcs"], detect=detect, chunk=chunk, device=device, stages=stages, overlap=overlap)
     assert bool(stages.get("overlapped", False)) == (bool(chunk) and chunk < len(ids) and (overlap is True or (overlap is None and dist.is_initialized() and dist.get_world_size() > 1)))
     first = stages["first_pass"]
     cat = lambda ts: np.concatenate([np.asarray(t).reshape(-1, 82) for t in ts])
@@ -155,12 +163,12 @@ def _chain(z, oracle, chunk, overlap=None):
             "pts": np.stack([q.compute_ellipsoid_points()[0] for q in out["quadrics"]])}
 
 
-def _worker_chain(rank, ws, port, chunk, q):
+def _worker_chain(rank, ws, port, chunk, q, device="cpu"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(1)
     dist.init_process_group("gloo", rank=rank, world_size=ws)
     from conftest import GOLDEN, Oracle
-    res = _chain(np.load(os.path.join(GOLDEN, "process_tracks.npz")), Oracle(), chunk)
+    res = _chain(np.load(os.path.join(GOLDEN, "process_tracks.npz")), Oracle(), chunk, device=device)
     q.put((rank, res))
     dist.destroy_process_group()
 
@@ -177,8 +185,36 @@ def test_run_scene_association_overlapped_with_detection_is_the_same_chain(oracl
         assert np.array_equal(np.ascontiguousarray(serial[k]).view(np.uint8), np.ascontiguousarray(over[k]).view(np.uint8)), k
 
 
-@pytest.mark.parametrize("chunk", [0, 16])
-def test_run_scene_world_of_2_equals_world_of_1(chunk, oracle, golden):
+def test_run_scene_consumer_failure_stops_the_producer(oracle, golden):
+    """An exception in the association loop (src/processor.py:306-345 raising on some frame) must not leave the detection worker
+    behind -- blocked on the full queue, or issuing collectives on this rank alone: run_scene re-raises and the thread is gone."""
+    import threading
+    z = golden("process_tracks.npz")
+    with pytest.raises(RuntimeError, match="on purpose"):
+        _chain(z, oracle, 4, overlap=True, fail_at=1)      # 4-frame chunks: the producer is several chunks ahead and blocked on put()
+    assert not [t for t in threading.enumerate() if t.name == "odam-detect" and t.is_alive()]
+
+
+def test_bench_gpus_n_refuses_to_run_fewer_ranks():
+    """`python bench.py --gpus N` starts N ranks itself (bench.py::launch_ranks); with fewer than N visible devices it must refuse
+    (rc 2, nothing on stdout) rather than print a line that says n_gpus = N.  (The launch itself is covered on the GPU:
+    tests/test_multirank_gpu.py::test_bench_gpus_2_launches_two_ranks.)"""
+    import subprocess
+    import sys
+    from conftest import REPO
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("needs a box with fewer than 8 devices")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--frames", "64"], capture_output=True, text=True,
+                       timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 2 and r.stdout == "" and "needs 8 visible GPUs" in r.stderr, (r.returncode, r.stdout, r.stderr[-500:])
+    # and a WORLD_SIZE that contradicts --gpus is refused too, before anything touches a device
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "8", "--frames", "64"], capture_output=True, text=True,
+                       timeout=300, env=dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr and r.stdout == ""
+
+
+@pytest.mark.parametrize("chunk,device", [(0, "cpu"), (16, "cpu"), (16, None)])
+def test_run_scene_world_of_2_equals_world_of_1(chunk, device, oracle, golden):
     """The whole driver chain (run_processor.py:70-83) through odam_amd.pipeline.run_scene: two gloo ranks -- each detects its
     share of every chunk, association replayed on both, the RESULTING tracks dealt over the ranks for both fit passes, merge in
     between -- end with what one rank computes alone, bit for bit, on both ranks: track rows and IDs, parameters, fitted flags,
@@ -191,8 +227,9 @@ def test_run_scene_world_of_2_equals_world_of_1(chunk, oracle, golden):
         assert np.array_equal(one["tracks"][one["lens"][:i].sum():one["lens"][:i + 1].sum(), :2], z[f"track{i}"][:, :2])
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + 131 + chunk) % 2000
-    procs = [ctx.Process(target=_worker_chain, args=(r, 2, port, chunk, q)) for r in range(2)]
+    port = 29500 + (os.getpid() + 131 + chunk + (7 if device is None else 0)) % 2000
+    # device=None: the collective's staging device is resolved inside run_scene (and, chunked, on its worker thread: ADVICE r5)
+    procs = [ctx.Process(target=_worker_chain, args=(r, 2, port, chunk, q, device)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(2))
