@@ -854,6 +854,7 @@ int lin(const Lin& L, const float* x, int lda, int M, const float* res, bool rel
     a.log2Cin = lg;
     a.Ho = 1; a.Wo = M; a.Cout = L.N; a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.Kpad = L.K;
     a.relu = relu ? 1 : 0; a.M = M; a.ldc = ldc;
+    a.no_pin = 1;      // replicated on every rank with identical rows: nothing to pin, and 4,000 rows want the small tiles
     return odam_cg::launch_conv_gemm(a, st);
 }
 

@@ -79,6 +79,8 @@ struct ConvGemmArgs {
     // ReLU makes zero padding equivalent to the -inf padding of max_pool2d.  M stays B Ho Wo (the conv's own size).
     // pool_ph x pool_pw is fixed at POOL_PH x POOL_PW below (compile-time divisors in the kernel).
     int pool = 0, pool_ph = 0, pool_pw = 0, Hp = 0, Wp = 0;
+    int no_pin = 0;                 // 1: odam_config cg.pin does not apply to this call (its M does not depend on the shard a rank holds: the
+                                    //    association network runs on the same rows on every rank, and small tiles are what its sizes want)
     int s1_window = 0;              // set by launch_conv_gemm (bf16 ring kernel, 3x3 stride 1): one LDS window per (channel slice, ky)
                                     //    serves the three horizontal taps (odam_config.h cg.s1)
 };

@@ -366,6 +366,9 @@ void split3_filters(const float* w, int Cout, int Kpad, unsigned short* out) {
 #define g_big_f32 odam_cfg::get(odam_cfg::CG_F32)
 void set_f32_mode(int mode) { odam_cfg::set(odam_cfg::CG_F32, mode == 1 ? 0 : mode); }
 int f32_mode() { return g_big_mode ? g_big_f32 : 0; }
+// cg.pin: the choice a device-filling problem gets, whatever M is -- for callers whose row count depends on how a scene is sharded
+// (the detector); a caller whose rows are the same on every rank (the replicated association network) opts out with no_pin
+static inline bool pinned(const ConvGemmArgs& a) { return odam_cfg::get(odam_cfg::CG_PIN) != 0 && !a.no_pin; }
 static bool big_eligible(const ConvGemmArgs& a, int bn) {
     const bool bf = a.dtype == ODAM_CG_BF16;
     if (!bf && !g_big_f32) return false;
@@ -376,7 +379,7 @@ static bool big_eligible(const ConvGemmArgs& a, int bn) {
     const long span = (256L / ((long)a.Ho * a.Wo) + 2) * a.H * a.W * lda + (long)(a.pad * a.W + a.pad) * lda + a.Cin;
     if (span * esz >= 0x7fffffffL || (long)a.Cout * a.Kpad * esz >= 0x7fffffffL) return false;
     if (g_big_mode >= 2) return true;
-    if (odam_cfg::get(odam_cfg::CG_PIN)) return a.Cout >= bn;      // the choice a device-filling problem gets, whatever M is
+    if (pinned(a)) return a.Cout >= bn;      // the choice a device-filling problem gets, whatever M is
     const long tiles = (long)((a.M + 255) / 256) * ((a.Cout + bn - 1) / bn);
     return tiles >= 192 && a.Cout >= bn;     // short-K expand layers too: with 16-byte stores its one block per CU streams faster than two 128x128 blocks
 }
@@ -452,7 +455,7 @@ bool pooled_stem_ok(const ConvGemmArgs& a) {
     if (a.Cout != 64 || a.ldc != 64 || a.res || !a.relu) return false;
     if (a.pool_ph != POOL_PH || a.pool_pw != POOL_PW) return false;
     if (a.Hp != (a.Ho + 2 - 3) / 2 + 1 || a.Wp != (a.Wo + 2 - 3) / 2 + 1) return false;
-    return big_eligible(a, 64) && ((a.M + 511) / 512 >= 256 || odam_cfg::get(odam_cfg::CG_PIN));
+    return big_eligible(a, 64) && ((a.M + 511) / 512 >= 256 || pinned(a));
 }
 
 int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
@@ -500,10 +503,10 @@ int launch_conv_gemm(const ConvGemmArgs& a, hipStream_t stream) {
             // cycles of matrix work) than the pipe needs -- with four per SIMD the pipe finds a ready wave more often, and the
             // filter tile is fetched once per 512 rows.  conv1: 1.44 -> 1.15 ms per 32 frames (same box, A/B by config).
             // (128-row tiles with two 4-wave workgroups per CU = the same two waves per SIMD: measured no change, not kept.)
-            if (x16 && (odam_cfg::get(odam_cfg::CG_TILES) & 8) && ((a.M + 511) / 512 >= 256 || odam_cfg::get(odam_cfg::CG_PIN))) return launch_big_f32(4, 64, 1024, a, stream);      // (fewer 512-row tiles than CUs: the 256-row ones)
+            if (x16 && (odam_cfg::get(odam_cfg::CG_TILES) & 8) && ((a.M + 511) / 512 >= 256 || pinned(a))) return launch_big_f32(4, 64, 1024, a, stream);      // (fewer 512-row tiles than CUs: the 256-row ones)
             return pre ? (x16 ? launch_big_f32(4, 64, 512, a, stream) : launch_big_f32(3, 64, 512, a, stream)) : launch_big_f32(2, 64, 512, a, stream);
         } else if (bf && (g_big_mode >= 2 || (a.lda > 0 && a.lda < a.Cin)) && a.Cout > 32 && a.Cout <= 64 && big_eligible(a, 64)) {
-            if ((odam_cfg::get(odam_cfg::CG_TILES) & 8) && !(a.KH * a.KW == 9 && a.stride == 1) && ((a.M + 511) / 512 >= 256 || odam_cfg::get(odam_cfg::CG_PIN))) return launch_big_bf16(64, 1024, a, stream);
+            if ((odam_cfg::get(odam_cfg::CG_TILES) & 8) && !(a.KH * a.KW == 9 && a.stride == 1) && ((a.M + 511) / 512 >= 256 || pinned(a))) return launch_big_bf16(64, 1024, a, stream);
             return launch_big_bf16(64, 512, a, stream);     // conv1 as a row convolution (pixel stride < row length); tests: layer1's 3x3 alone
         }
     }

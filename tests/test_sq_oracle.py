@@ -145,3 +145,25 @@ def test_first_divergence_is_a_tie(oracle, golden, fixture):
             assert first_dec is not None and first_dec <= first_dev, (c, first_dec, first_dev)
             assert max(dev[:first_dec]) <= 1e-4 if first_dec else True
     assert n_div >= (2 if "full" in fixture else 3)      # the fixtures do contain diverging cases
+
+
+@pytest.mark.parametrize("case", [0, 3, 5, 9])
+def test_autograd_restatement_is_the_reference_fit(golden, case):
+    """oracle/sq_autograd_oracle.py restates the reference's fit the way the reference computes it -- torch CPU tensors, autograd,
+    torch.optim.Adam, anomaly mode on (sq_libs.py:432-475) -- so that bench.py's cpu_baseline can time the reference's ALGORITHM on a
+    box without /root/reference.  Same ATen kernels in the same order: the nine parameters after 200 steps equal the reference's own
+    run of the problem (tests/golden/sq_survey.npz, `final`) bit for bit, with anomaly detection on and off."""
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import sq_autograd_oracle as ag
+    z = golden("sq_survey.npz")
+    icov = np.load(os.path.join(REPO, "odam_amd", "data", "scale_prior.npz"))["icov"].astype(np.float32).reshape(8, 3, 3)
+    keep = torch.get_num_threads()
+    torch.set_num_threads(1)      # the fixture's setting (make_golden_sq_survey.py:41)
+    try:
+        p0, cls = z[f"c{case}_p0"], int(z[f"c{case}_cls"])
+        out = ag.fit(p0, z[f"c{case}_P"], z[f"c{case}_tgt"], z[f"c{case}_mask"], icov[cls], anomaly=(case != 3))
+    finally:
+        torch.set_num_threads(keep)
+    assert np.array_equal(out.view(np.uint32), z["final"][case].view(np.uint32)), (out, z["final"][case])
