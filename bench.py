@@ -645,11 +645,9 @@ def association_block(per_frame, scene, device, N, ms_step_s, n_sample=200):
     proc, net = _new_process(device)
     n = min(n_sample, len(per_frame))
     ids, T = scene["img_names"], scene["T_wcs"]
-    for i in range(min(8, n)):      # warm-up: handles, first tracks
-        proc.process_frame(None, int(ids[i]), T[i], detections=per_frame[i])
+    proc.process_frames([int(ids[i]) for i in range(min(8, n))], [T[i] for i in range(min(8, n))], per_frame[:min(8, n)])      # warm-up: handles, first tracks
     torch.cuda.synchronize(); s0 = time.perf_counter()
-    for i in range(8, n):
-        proc.process_frame(None, int(ids[i]), T[i], detections=per_frame[i])
+    proc.process_frames([int(ids[i]) for i in range(8, n)], [T[i] for i in range(8, n)], per_frame[8:n])
     torch.cuda.synchronize()
     per = (time.perf_counter() - s0) / max(1, n - 8)
     res = {"ms_per_frame": 1e3 * per, "frames_sampled": n - 8, "live_tracks_at_end": len(proc.tracks),
@@ -679,8 +677,7 @@ def association_overlapped(detector, frames, chunk, scene, device, N, fit_ms):
                 if item is None:
                     return
                 c0, rows = item
-                for i, r in enumerate(rows):
-                    proc.process_frame(None, int(ids[c0 + i]), T[c0 + i], detections=r)
+                proc.process_frames([int(ids[c0 + i]) for i in range(len(rows))], [T[c0 + i] for i in range(len(rows))], rows)
         except Exception as e:      # noqa: BLE001
             err.append(repr(e))
     th = threading.Thread(target=worker)

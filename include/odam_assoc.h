@@ -101,6 +101,15 @@ int odam_trackwin_params(odam_trackwin* w, int T, float* out);
 int odam_trackwin_build_tracks(odam_trackwin* w, struct odam_sq_ctx* sq, int T, const double* T_cw12_K9, double cam_azi, double img_w,
                                double img_h, float* out, void* stream);
 
+/* One frame of OdamProcess.process_frame's device work behind one call (src/processor.py:320-337): _append of the n_app <= 30
+ * observations the PREVIOUS frame attached (app_ids / app_rows14 as in odam_trackwin_append; n_app = 0: none), _build_tracks for this
+ * frame's camera into tracks_out [dev][T][79][window], odam_assoc_forward on it.  The same entry points in the same order -- results are
+ * theirs bit for bit --, without the host time between three binding calls.  Stream-ordered, no host synchronisation; the caller
+ * synchronises, checks odam_assoc_lost_launches and, if it moved, re-runs odam_assoc_forward_sequence on tracks_out. */
+int odam_assoc_step(odam_assoc* m, odam_trackwin* w, struct odam_sq_ctx* sq, int n_app, const int* app_ids, const double* app_rows14,
+                    int T, const double* T_cw12_K9, double cam_azi, double img_w, double img_h, const float* detections, int n_det,
+                    float* tracks_out, float* Z_out, void* stream);
+
 /* diagnostics of the persistent matching kernel: enable != 0 makes the following forwards record a 100 MHz timestamp of
  * workgroup 0 at kernel start and after every stage (5 per GNN layer, final projection, score matrix, Sinkhorn loop);
  * out [host][n <= 128], if not null, receives the stamps of the last forward (synchronises the device). */

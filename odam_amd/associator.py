@@ -111,6 +111,17 @@ class TrackWindows:
                 self.lengths[t] += 1
             self.marks[t, 1] = row[0]; self.marks[t, 2] = row[9]
 
+    def append_raw(self, track_ids, rows82):
+        """append() without the host-side lengths / marks: OdamProcess's fast path keeps those stale while it runs and rebuilds them from
+        its track list when somebody looks (processor.py::_sync_host_view)"""
+        rows = np.ascontiguousarray(np.asarray(rows82, np.float64)[:, :14])
+        ids = np.ascontiguousarray(track_ids, np.int32)
+        for i0 in range(0, len(ids), 32):
+            n = min(32, len(ids) - i0)
+            with torch.cuda.device(self.device):
+                _lib.check(_lib.lib().odam_trackwin_append(self._h, ctypes.c_int(n), ids[i0:].ctypes.data_as(ctypes.c_void_p),
+                                                           rows[i0:].ctypes.data_as(ctypes.c_void_p), self._stream()), "odam_trackwin_append")
+
     def build(self, proj_px_dev, T_cw, cam_azi, img_w, img_h):
         T = len(self.lengths)
         out = torch.empty(T, 79, self.WINDOW, device=self.device, dtype=torch.float32)
@@ -309,6 +320,69 @@ class Associator:
         finally:
             self._pin_mode = False
         return Z if Z.is_cuda else Z.clone()      # (the pinned buffer is the next frame's)
+
+    # ---- one frame's device work behind one native call (include/odam_assoc.h, odam_assoc_step) -------------------------------------
+    def step_launch(self, win, fitter, app_ids, app_rows14, n_tracks, cam21, cam_azi, img_w, img_h, det32T):
+        """Enqueue, for one frame: the mirror append of what the previous frame attached (app_ids / app_rows14, may be empty), the
+        track input for this frame's camera and the association forward on it -- OdamProcess's fast path (processor.py::process_frames).
+        det32T [79, n_det] float32 (the frame's detection rows transposed, as process_frame hands them to the collater).  Nothing is
+        synchronised here; step_finish() waits and returns the log assignment."""
+        dev = self.device
+        n_det = det32T.shape[1]
+        if n_tracks > self.max_tracks:
+            self._grow(n_tracks)
+        if getattr(self, "_pin", None) is None:
+            self._pin = (torch.empty(79 * 30, dtype=torch.float32).pin_memory(), torch.empty((self.MAX_TRACKS + 1) * 31, dtype=torch.float32).pin_memory())
+        de = self._pin[0].view(79, 30).numpy()
+        de[:, n_det:] = -1.0                      # the collater's padding (processor.py:49-68)
+        de[:, :n_det] = det32T
+        buf = getattr(self, "_tracks_buf", None)
+        if buf is None or buf.shape[0] < n_tracks:
+            self._tracks_buf = buf = torch.empty(max(64, 2 * n_tracks), 79, TrackWindows.WINDOW, device=dev, dtype=torch.float32)
+        L = _lib.lib()
+        n_app = len(app_ids)
+        ids = np.ascontiguousarray(app_ids, np.int32)
+        rows = np.ascontiguousarray(app_rows14, np.float64)
+        with torch.cuda.device(dev), fitter._lock:
+            cur = torch.cuda.current_stream(dev)
+            stream = cur.cuda_stream
+            if fitter._last is not None and fitter._last[0] != stream:
+                cur.wait_event(fitter._last[1])
+            _lib.check(L.odam_assoc_step(self._handle(), win._h, fitter._h, ctypes.c_int(n_app), ids.ctypes.data_as(ctypes.c_void_p),
+                                         rows.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(n_tracks), cam21.ctypes.data_as(ctypes.c_void_p),
+                                         ctypes.c_double(cam_azi), ctypes.c_double(img_w), ctypes.c_double(img_h), _lib.ptr(self._pin[0]),
+                                         ctypes.c_int(n_det), _lib.ptr(buf), _lib.ptr(self._pin[1]), ctypes.c_void_p(stream)), "odam_assoc_step")
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            fitter._last = (stream, ev)
+        self._step = (n_tracks, n_det, fitter)
+
+    def step_finish(self):
+        """Wait for the frame enqueued by step_launch and return its log assignment [(T + 1), (n_det + 1)] -- a view of the pinned buffer,
+        valid until the next step_launch.  An abandoned persistent launch is re-run through the launch sequence, as in assignment_checked."""
+        n_tracks, n_det, fitter = self._step
+        dev = self.device
+        cur = torch.cuda.current_stream(dev)
+        cur.synchronize()
+        fitter._last = None                    # synchronised: no cross-stream wait is owed
+        n = ctypes.c_uint(0)
+        _lib.check(_lib.lib().odam_assoc_lost_launches(self._handle(), ctypes.byref(n)), "odam_assoc_lost_launches")
+        if n.value != self._lost_seen:
+            self._lost_seen = n.value
+            self.lost_launches += 1
+            self._lost_in_a_row = getattr(self, "_lost_in_a_row", 0) + 1
+            self._pin_mode = True
+            try:
+                self.assignment(self._tracks_buf[:n_tracks], self._pin[0].view(79, 30), n_tracks, n_det, sequence=True)
+                cur.synchronize()
+            finally:
+                self._pin_mode = False
+            if self._lost_in_a_row >= 3:
+                self.set_persistent(False)
+                self.persistent_given_up = True
+        else:
+            self._lost_in_a_row = 0
+        return self._pin[1][:(n_tracks + 1) * (n_det + 1)].view(n_tracks + 1, n_det + 1)
 
     def __call__(self, in_data, threshold, eval_only=False, device="cuda"):
         """Associator.forward for the batch-of-one call of OdamProcess (associator.py:202-268, eval_only=True)"""

@@ -1547,6 +1547,22 @@ extern "C" int odam_trackwin_build_tracks(odam_trackwin* w, struct odam_sq_ctx* 
     return 0;
 }
 
+// One frame of OdamProcess.process_frame's device work behind ONE call (src/processor.py:320-337): the observations the previous frame
+// attached (n_app <= 30 rows: odam_trackwin_append), this frame's track input for its camera (odam_trackwin_build_tracks) and the
+// association forward on it (odam_assoc_forward) -- the same three entry points in the same order, so the results are theirs bit for
+// bit; what goes is the host time between them (three binding calls, their argument marshalling and the interpreter in between, with the
+// device idle).  tracks_out [dev][T][79][window] is the caller's buffer (it needs it again if the frame has to be re-run through
+// odam_assoc_forward_sequence); detections / Z_out as in odam_assoc_forward (device or mapped pinned host memory).
+extern "C" int odam_assoc_step(odam_assoc* m, odam_trackwin* w, struct odam_sq_ctx* sq, int n_app, const int* app_ids, const double* app_rows14,
+                               int T, const double* T_cw12_K9, double cam_azi, double img_w, double img_h, const float* detections, int n_det,
+                               float* tracks_out, float* Z_out, void* stream) {
+    if (!m || !w || !sq || !tracks_out || !detections || !Z_out) return odam_fail(1, "odam_assoc_step: null pointer");
+    if (n_app < 0 || n_app > 32) return odam_fail(1, "odam_assoc_step: at most 32 observations per frame");
+    if (n_app) { if (int rc = odam_trackwin_append(w, n_app, app_ids, app_rows14, stream)) return rc; }
+    if (int rc = odam_trackwin_build_tracks(w, sq, T, T_cw12_K9, cam_azi, img_w, img_h, tracks_out, stream)) return rc;
+    return odam_assoc_forward(m, tracks_out, T, detections, n_det, Z_out, stream);
+}
+
 extern "C" int odam_trackwin_build(odam_trackwin* w, int T, const double* proj_px, const double* cam15, float* out, void* stream) {
     if (!w || T < 0 || T > w->max_tracks || (T && (!proj_px || !cam15 || !out))) return odam_fail(1, "odam_trackwin_build: bad argument");
     if (T == 0) return 0;

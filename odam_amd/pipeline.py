@@ -77,6 +77,17 @@ def sharded_optim(proc, tracks, device=None, force=False):
             "quadrics": quadrics, "params": rows[:, :9].copy(), "fitted": rows[:, 9] != 0}
 
 
+def _associate(proc, frame_ids, T_wcs, c0, rows):
+    """the sequential association loop (src/processor.py:306-345) over the frames c0 ... of a chunk whose detections are at hand: as one
+    process_frames call where the process object has it (the host's work then sits under the device's, processor.py), frame by frame otherwise"""
+    if hasattr(proc, "process_frames"):
+        n = len(rows)
+        proc.process_frames([int(frame_ids[c0 + i]) for i in range(n)], [T_wcs[c0 + i] for i in range(n)], rows)
+    else:
+        for i, r in enumerate(rows):
+            proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
+
+
 def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=0, device=None, force=False, stages=None, overlap=None):
     """The driver loop of run_processor.py:70-83 for one scene on the ranks of the current process group.
 
@@ -158,8 +169,7 @@ def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=
                     raise item
                 c0, rows, dt_detect = item
                 s1 = time.perf_counter()
-                for i, r in enumerate(rows):
-                    proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
+                _associate(proc, frame_ids, T_wcs, c0, rows)
                 t["associate"] += time.perf_counter() - s1
                 t["detect_gather"] += dt_detect
         finally:
@@ -180,8 +190,7 @@ def run_scene(proc, n_frames, frame_ids, T_wcs, detect=None, frames=None, chunk=
             s0 = time.perf_counter()
             rows = detect_gathered(detect, c0, c1, device, force)
             s1 = time.perf_counter()
-            for i, r in enumerate(rows):
-                proc.process_frame(None, int(frame_ids[c0 + i]), T_wcs[c0 + i], detections=r)
+            _associate(proc, frame_ids, T_wcs, c0, rows)
             t["detect_gather"] += s1 - s0
             t["associate"] += time.perf_counter() - s1
     s0 = time.perf_counter()

@@ -96,10 +96,56 @@ class OdamProcess:
         self.representation = representation
         self.no_code = no_code
         self.run_associator = False
-        self.tracks = None
+        self._tracks = None
+        self._pending = []          # fast path: (track ids, [k, 82] rows) attached per frame, not yet concatenated into self._tracks
+        self._pending_app = None    # fast path: the last frame's attach, not yet appended to the device mirror (goes with the next step)
+        self._n_tracks = 0
+        self._exposed = True        # somebody may hold (and edit) the list self.tracks returned: the mirror is re-checked before the next fast frame
         self.sequence_meta = None
         self.fitter = fitter
         self.logger = logging.getLogger('OdamProcess')
+
+    # `tracks` is the reference's attribute (src/processor.py:300; a list of [n, 82] arrays, index = track id).  The fast path of
+    # process_frames keeps what a frame attaches as (ids, rows) records and concatenates them into the arrays only when somebody asks
+    # for the list -- a concatenate per matched track per frame is a third of that path's host time otherwise.
+    @property
+    def tracks(self):
+        self._sync_host_view()
+        self._exposed = True
+        return self._tracks
+
+    @tracks.setter
+    def tracks(self, value):
+        self._pending = []
+        self._pending_app = None
+        self._tracks = value
+        self._n_tracks = len(value) if value is not None else 0
+        self._exposed = True
+
+    def _sync_host_view(self):
+        """fold the fast path's records into self._tracks and bring the device mirror's host-side bookkeeping (lengths, marks) in step"""
+        if self._pending:
+            add = {}
+            for ids, rows in self._pending:
+                for j, t in enumerate(ids):
+                    add.setdefault(t, []).append(rows[j:j + 1])
+            for t in sorted(add):
+                if t < len(self._tracks):
+                    self._tracks[t] = np.concatenate([self._tracks[t]] + add[t], axis=0)
+                else:
+                    assert t == len(self._tracks), (t, len(self._tracks))
+                    self._tracks.append(np.concatenate(add[t], axis=0))
+            self._pending = []
+        win = getattr(self, "_win", None)
+        if self._pending_app is not None:       # the last fast frame's attach has not reached the mirror yet
+            ids, rows = self._pending_app
+            self._pending_app = None
+            if win is not None:
+                win.append_raw(ids, rows)
+        if win is not None and getattr(self, "_win_meta_stale", False):
+            win.lengths = [len(t) for t in self._tracks]
+            win.marks = win._marks_of(self._tracks)
+            self._win_meta_stale = False
 
     def _fitter(self):
         if self.fitter is None:
@@ -111,6 +157,7 @@ class OdamProcess:
         self.run_associator = False
         self.sequence_meta = _Meta(K=intrinsics, img_h=img_h, img_w=img_w)
         self.tracks = []
+        self._win_meta_stale = False
         self.T_wcs = []
         self.P_cws = []
         self.usable_frames = []
@@ -351,6 +398,13 @@ class OdamProcess:
     def process_frame(self, rgb, frame_id, T_wc, detections=None):
         """`detections`: optional rows for this frame computed earlier by `detect_frames` (here or on another
         rank); None -> run the detector now, as the reference does."""
+        if detections is not None and self._fast_ok():
+            return self.process_frames([frame_id], [T_wc], [detections])
+        return self._process_frame_host(rgb, frame_id, T_wc, detections)
+
+    def _process_frame_host(self, rgb, frame_id, T_wc, detections=None):
+        """process_frame with every step a separate call, as the reference has them (src/processor.py:306-345): what runs when the
+        associator or the fitter is the caller's own (no native track store), with shape codes, or with the detector in the loop"""
         self._frame_token = object()      # one per call: what "_windows() checked the device mirror in this very frame" is keyed on
         self.usable_frames.append(frame_id)
         self.T_wcs.append(T_wc)
@@ -376,6 +430,145 @@ class OdamProcess:
         score_mat = predictions['pred'][0][0].cpu().exp().numpy()
         dets = data['detections'][0, :, :n_detections].numpy().T
         self._attach_to_tracks(pred_matches, dets, T_wc, score_mat)
+
+    # ---- the same loop for frames whose detections are at hand, with the host out of the device's way -------------------------------
+    def _fast_ok(self):
+        """process_frames' fast path applies: the associator and the fitter are this package's (native track store, odam_assoc_step),
+        no shape codes, one device, the Hungarian step on the host (scipy, the default)"""
+        a, f = self.associator, self._fitter()
+        if not (self.no_code and getattr(a, "native_windows", False) and hasattr(a, "step_launch") and hasattr(f, "build_track_windows")
+                and hasattr(f, "_h") and self._tracks is not None):
+            return False
+        if "assignment" in vars(a) or "_attach_to_tracks" in vars(self) or "_prepare_tracks" in vars(self):
+            return False      # somebody hooked a step of the per-frame path on this object (tests do): keep the steps separate
+        from . import _lib
+        if _lib.get_config("assoc.hungarian"):
+            return False
+        adev, fdev = getattr(a, "device", None), getattr(f, "device", None)
+        return adev is not None and fdev is not None and torch.device(adev) == torch.device(fdev)
+
+    def process_frames(self, frame_ids, T_wcs, detections_list):
+        """process_frame(None, frame_ids[k], T_wcs[k], detections=detections_list[k]) for k = 0, 1, ... -- the loop of
+        run_processor.py:70-79 for frames whose detections were computed ahead (detect_frames, another rank's all-gather) -- and the same
+        results: the same library calls on the same values in the same order.  What changes is where the host's work sits.  Per frame the
+        device runs one chain (mirror append -> track input -> association network -> Sinkhorn, ~0.47 ms at 40 tracks) and the host has
+        ~0.25 ms of its own (camera quantities, track rows, Hungarian step, list bookkeeping); frame by frame the two alternate, each
+        idle while the other works.  Here a frame's device work is ONE native call (odam_assoc_step), everything the host can know
+        before the assignment arrives -- the NEXT frame's camera quantities and track rows included -- is computed while the device works,
+        and the track list is extended lazily (self.tracks folds the records in when it is read).  Only the Hungarian step and the
+        threshold tests stay between one frame's result and the next frame's launch."""
+        n = len(frame_ids)
+        if not self._fast_ok():
+            for k in range(n):
+                self._process_frame_host(None, frame_ids[k], T_wcs[k], detections_list[k])
+            return None
+        m = self.sequence_meta
+        K = np.asarray(m.K, np.float64)
+        K9 = K[:3, :3].reshape(-1)
+        assoc, fitter = self.associator, self._fitter()
+
+        def prep(k):
+            """everything of frame k the host can compute without the association result (numpy, as the per-frame path computes it)"""
+            T_wc = T_wcs[k]
+            det = detections_list[k]
+            T_cw = np.linalg.inv(T_wc)
+            P = {"T_wc": T_wc, "P_cw": m.K @ T_cw[:3, :], "n": len(det)}
+            if len(det) == 0:
+                return P
+            det = np.asarray(det)
+            if len(det) > 30:
+                det = det[:30, :]
+            # the float32 round trip of the collater (processor.py:49-68, 337-339): the attach reads the detections back from the
+            # float32 tensor the associator was given
+            det32T = det.astype(np.float32).T
+            P["det32T"] = det32T
+            P["det"] = det
+            P["rows82"] = self._track_rows(det32T.T, T_wc, with_code=False)
+            P["cam_azi"] = get_cam_azi(T_wc)
+            P["cam21"] = np.ascontiguousarray(np.concatenate([T_cw[:3].reshape(-1), K9]))
+            return P
+
+        nxt = prep(0) if n else None
+        for k in range(n):
+            cur, nxt = nxt, None
+            self.usable_frames.append(frame_ids[k])
+            self.T_wcs.append(cur["T_wc"])
+            self.P_cws.append(cur["P_cw"])
+            launched = False
+            if cur["n"]:
+                if not self.run_associator:
+                    # the first frame with detections starts the tracks (processor.py:320-323): host rows, the mirror is loaded below
+                    self.run_associator = True
+                    self.tracks = self._init_tracks(cur["det"], cur["T_wc"])
+                else:
+                    win = self._fast_mirror()
+                    if win is None:      # more tracks than the native store holds: this frame takes the host path
+                        self._rewind_frame()
+                        self._process_frame_host(None, frame_ids[k], T_wcs[k], detections_list[k])
+                        if k + 1 < n:
+                            nxt = prep(k + 1)
+                        continue
+                    app = self._pending_app or ((), np.zeros((0, 82)))
+                    self._pending_app = None
+                    assoc.step_launch(win, fitter, app[0], np.asarray(app[1])[:, :14], self._n_tracks, cur["cam21"], float(cur["cam_azi"]),
+                                      float(m.img_w), float(m.img_h), cur["det32T"])
+                    launched = True
+            if k + 1 < n:
+                nxt = prep(k + 1)                 # under the device's work on frame k
+            if launched:
+                Z = assoc.step_finish()
+                self._attach_fast(Z, cur)
+        return None
+
+    def _rewind_frame(self):
+        self.usable_frames.pop(); self.T_wcs.pop(); self.P_cws.pop()
+
+    def _fast_mirror(self):
+        """the device mirror, in step with the tracks as the fast path knows them; None where the native store does not apply"""
+        if getattr(self, "_win", None) is None:
+            from .associator import TrackWindows
+            self._win = TrackWindows(str(getattr(self.associator, "device", "cuda:0")))
+        w = self._win
+        if self._exposed:
+            # the list was handed out (or replaced) since the last fast frame: fold everything in and check the mirror against it once
+            self._sync_host_view()
+            self._n_tracks = len(self._tracks)
+            if self._n_tracks + 30 > w.max_tracks:
+                return None
+            if not w.in_step(self._tracks):
+                w.load(self._tracks)
+            self._exposed = False
+        elif self._n_tracks + 30 > w.max_tracks:
+            return None
+        return w
+
+    def _attach_fast(self, Z, cur):
+        """hungarian_matching + _attach_to_tracks (src/models/associator.py:19-35, src/processor.py:212-257) on the assignment of a
+        fast frame: the same tests on the same float32 values; the rows go to the record list and to the mirror's next append"""
+        from .associator import hungarian_matching
+        n_det = cur["det32T"].shape[1]
+        match = hungarian_matching(Z[:-1, :-1].exp(), self.match_threshold).astype(np.int32)
+        score_mat = Z.exp().numpy()
+        rows = cur["rows82"]
+        ids, picked = [], []
+        n_tracks = self._n_tracks
+        for det_id in range(n_det):
+            track_id = int(match[det_id])
+            if score_mat[track_id, det_id] < self.score_threshold:
+                continue
+            if track_id == -1:
+                ids.append(n_tracks)
+                n_tracks += 1
+            else:
+                ids.append(track_id)
+            picked.append(det_id)
+        if ids:
+            assert len(set(ids)) == len(ids), ids      # a track receives at most one observation per frame (the Hungarian step's matching)
+            sel = rows[picked]
+            self._pending.append((ids, sel))
+            self._pending_app = (ids, sel)
+            self._n_tracks = n_tracks
+            self._win_meta_stale = True
 
     # ---- back end (processor.py:347-368) -----------------------------------------------------------
     def merge_process(self, data):

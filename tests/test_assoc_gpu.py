@@ -287,6 +287,133 @@ def test_process_sequence_with_network(golden):
     net.close()
 
 
+def test_process_frames_fast_path_equals_the_frame_by_frame_path(golden):
+    """OdamProcess.process_frames (one native call per frame -- odam_assoc_step --, the host's work under the device's, the track list
+    extended lazily) against the loop with every step a separate call (src/processor.py:306-345 as restated in _process_frame_host), on
+    the canned-detection sequence with the scene association weights: every assignment matrix and every track row equal BIT FOR BIT;
+    also frame by frame through process_frame, with the track list read -- and once edited -- in between (the mirror is re-checked after
+    every exposure), and with an abandoned persistent launch in the middle (re-run through the launch sequence)."""
+    import os, sys
+    from conftest import REPO
+    sys.path.insert(0, os.path.join(REPO, "tools"))
+    import scene_weights
+    from odam_amd import _lib, associator, sq
+    from odam_amd.processor import OdamProcess
+    z = golden("process_tracks.npz")
+    ids = [int(f) for f in z["img_names"]]
+    T = [z["scene_T_wcs"][i] for i in range(len(ids))]
+    dets = [np.asarray(z[f"det{f}"], np.float64).reshape(-1, 79) for f in ids]
+    assert len(ids) >= 30 and sum(len(d) for d in dets) >= 60
+
+    class _Det:
+        device = DEV
+
+    def make():
+        net = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"],
+                                     "sinkhorn_iterations": 100}, max_tracks=64, device=DEV)
+        net.load_state_dict(scene_weights.make_scene_associator_state_dict(2, 8, seed=0))
+        proc = OdamProcess(_Det(), net, None, None, fitter=sq.SqFitter(DEV, 1))
+        proc.init_sequence(z["K"], 480, 640)
+        return proc, net
+
+    def log_Z(net, Zs):
+        fin = net.step_finish
+
+        def wrapped():
+            Z = fin()
+            Zs.append(Z.clone().numpy())
+            return Z
+        net.step_finish = wrapped
+
+    # A: every step a separate call; the assignment matrices logged through the associator's call
+    proc_a, net_a = make()
+    Za = []
+    for i in range(len(ids)):
+        proc_a._process_frame_host(None, ids[i], T[i], dets[i])
+    tracks_a = [t.copy() for t in proc_a.tracks]
+    assert len(tracks_a) >= 2 and max(len(t) for t in tracks_a) >= 10
+    # ... once more with the matrices kept (assignment_checked returns them)
+    proc_a2, net_a2 = make()
+    chk = net_a2.assignment_checked
+
+    def logged(*a, **k):
+        Zt = chk(*a, **k)
+        Za.append(Zt.cpu().numpy().copy())
+        return Zt
+    net_a2.assignment_checked = logged
+    for i in range(len(ids)):
+        proc_a2._process_frame_host(None, ids[i], T[i], dets[i])
+
+    def same_tracks(got):
+        assert len(got) == len(tracks_a)
+        for t, r in zip(got, tracks_a):
+            assert t.shape == r.shape and np.array_equal(t.view(np.uint8), np.ascontiguousarray(r).view(np.uint8))
+
+    # B: the whole sequence in one process_frames call
+    proc_b, net_b = make()
+    Zb = []
+    log_Z(net_b, Zb)
+    assert proc_b._fast_ok()
+    proc_b.process_frames(ids, T, dets)
+    assert len(Zb) == len(Za) >= 20
+    for a_, b_ in zip(Za, Zb):
+        assert a_.shape == b_.shape and np.array_equal(a_.view(np.uint32), b_.view(np.uint32))
+    same_tracks(proc_b.tracks)
+    assert proc_b.usable_frames == proc_a.usable_frames and len(proc_b.P_cws) == len(ids)
+    assert all(np.array_equal(p, q) for p, q in zip(proc_b.P_cws, proc_a.P_cws))
+    # the mirror's host-side bookkeeping was brought in step when the list was read
+    assert proc_b._win.in_step(proc_b.tracks)
+
+    # C: frame by frame through process_frame (the reference's call), chunks of 3 through process_frames in between; the list is read
+    # every fifth frame (after every exposure the mirror is checked against it again)
+    proc_c, net_c = make()
+    i = 0
+    while i < len(ids):
+        if i % 7 == 3:
+            proc_c.process_frames(ids[i:i + 3], T[i:i + 3], dets[i:i + 3]); i += 3
+        else:
+            proc_c.process_frame(None, ids[i], T[i], detections=dets[i]); i += 1
+        if i % 5 == 0:
+            assert sum(len(t) for t in proc_c.tracks) > 0
+    same_tracks(proc_c.tracks)
+    # ... and an EDIT of the list between two frames is noticed (equal lengths, another last observation): one more frame on both paths
+    k = max(range(len(tracks_a)), key=lambda j: len(tracks_a[j]))
+    for pr in (proc_a, proc_c):
+        pr.tracks[k][-1, 9:12] += 0.25
+    extra = dets[-1].copy(); extra[:, 0] = ids[-1] + 1
+    proc_a._process_frame_host(None, ids[-1] + 1, T[-1], extra)
+    proc_c.process_frame(None, ids[-1] + 1, T[-1], detections=extra)
+    ta, tc = proc_a.tracks, proc_c.tracks
+    assert len(ta) == len(tc) and sum(len(t) for t in ta) > sum(len(t) for t in tracks_a)
+    for t, r in zip(tc, ta):
+        assert t.shape == r.shape and np.array_equal(np.ascontiguousarray(t).view(np.uint8), np.ascontiguousarray(r).view(np.uint8))
+
+    # D: an abandoned persistent launch in the middle (every barrier wait of frame 12 times out): re-run through the sequence, same bits
+    proc_d, net_d = make()
+    launch = net_d.step_launch
+    n_launch = [0]
+
+    def lossy(*a, **k):
+        n_launch[0] += 1
+        if n_launch[0] == 12:
+            _lib.check(_lib.lib().odam_assoc_set_barrier_timeout_us(net_d._handle(), 0), "timeout")
+        launch(*a, **k)
+        if n_launch[0] == 12:
+            _lib.check(_lib.lib().odam_assoc_set_barrier_timeout_us(net_d._handle(), 20000), "timeout")
+    net_d.step_launch = lossy
+    info = (ctypes.c_int(), ctypes.c_int(), ctypes.c_int())
+    _lib.check(_lib.lib().odam_assoc_info(net_d._handle(), ctypes.byref(info[0]), ctypes.byref(info[1]), ctypes.byref(info[2])), "info")
+    proc_d.process_frames(ids, T, dets)
+    if info[0].value:      # the persistent path is in use on this device
+        assert net_d.lost_launches == 1
+    got = proc_d.tracks
+    assert len(got) == len(tracks_a)
+    for t, r in zip(got, tracks_a):      # the launch sequence sums in another order than the persistent kernel: same decisions, rows equal
+        assert t.shape == r.shape and np.array_equal(t.view(np.uint8), np.ascontiguousarray(r).view(np.uint8))
+    for n_ in (net_a, net_a2, net_b, net_c, net_d):
+        n_.close()
+
+
 def _random_tracks(rs, lengths):
     tracks = []
     for n in lengths:

@@ -145,13 +145,13 @@ def _chain(z, oracle, chunk, overlap=None, device="cpu", fail_at=None):
         return [np.asarray(z[f"det{ids[f]}"], np.float64).reshape(-1, 79) for f in range(f0, f1)]
     stages = {}
     if fail_at is not None:
-        inner = proc.process_frame
+        inner = proc._process_frame_host      # (what process_frames calls per frame for a process object without the native track store)
 
         def failing(rgb, frame_id, T_wc, detections=None):
             if frame_id == ids[fail_at]:
                 raise RuntimeError("association failed on purpose")
-            return inner(rgb, frame_id, T_wc, detections=detections)
-        proc.process_frame = failing
+            return inner(rgb, frame_id, T_wc, detections)
+        proc._process_frame_host = failing
     out = pipeline.run_scene(proc, len(ids), ids, z["scene_T_wcs"], detect=detect, chunk=chunk, device=device, stages=stages, overlap=overlap)
     assert bool(stages.get("overlapped", False)) == (bool(chunk) and chunk < len(ids) and (overlap is True or (overlap is None and dist.is_initialized() and dist.get_world_size() > 1)))
     first = stages["first_pass"]
