@@ -470,12 +470,21 @@ def main():
             sq_ms = sorted(a_.elapsed_time(b_) for a_, b_ in rec["ev"])[len(rec["ev"]) // 2]
             views = rec["views"]
             alg = sum(12000 + 80 * v + 40 for v in views) * 200.0   # streaming-formulation bytes per object-step
-            vu = pmc.get("sq_fit", {}).get("valu_util")
+            sqp = pmc.get("sq_fit", {})
+            sq5 = pmc.get("sq_fit_500x256", {})
             result["sq_fit_kernel"] = {
-                # the bound that applies: the kernel keeps everything in LDS for all 200 steps, so it is
-                # bound by per-step latency / vector issue, not by HBM.  frac = share of wave cycles issuing vector instructions
-                "bound": "valu/latency", "frac": vu, "unit": "share of SQ_WAVE_CYCLES issuing VALU",
-                "frac_from_profiles": pmc.get("sq_fit", {}).get("source"),
+                # The bound that applies: the kernel keeps everything in LDS for all 200 steps, so HBM is not it; its
+                # largest phase, the arg-extreme scan of 1000 projected surface points per view, is ~36 vector instructions per point and view of
+                # which a third are compares and selects -- so flops against the 157 TFLOP/s vector peak (what only a stream of v_pk_fma_f32
+                # reaches) say little, and the honest ceiling is VALU ISSUE: frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x cycles of the
+                # launch), the share of the chip's vector issue slots the launch filled (PMC pass on prof_sq.py, see `frac_from_profiles`).
+                "bound": "valu-issue", "frac": sqp.get("valu_issue_frac"), "unit": "share of SIMD issue cycles holding a VALU instruction",
+                "frac_at_configs4_size": ({"value": sq5.get("valu_issue_frac"), "valu_insts_per_launch": sq5.get("valu_insts_per_launch"),
+                                           "note": sq5.get("source")} if sq5 else None),
+                "per_wave_view": {"valu_util": sqp.get("valu_util"), "wait_frac": sqp.get("wait_frac"),
+                                  "note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES and SQ_WAIT_ANY / SQ_WAVE_CYCLES: per RESIDENT WAVE (four per SIMD "
+                                          "here), so 0.25 would be a SIMD that never idles -- the figure earlier rounds quoted as `frac`"},
+                "frac_from_profiles": sqp.get("source"),
                 "objects": len(views), "max_views": max(views), "ms_per_launch": sq_ms, "us_per_adam_step": 1e3 * sq_ms / 200,
                 "hbm_secondary": {"achieved": alg / (sq_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
                                   "frac": alg / (sq_ms * 1e-3) / PEAK_HBM,

@@ -14,6 +14,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   run sq_$c $c $R/tests/native/prof_sq.py
 done
 run sq_valu "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE" $R/tests/native/prof_sq.py
+run sq500_valu "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE" $R/tests/native/prof_sq.py 500 256
 run r50f32_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" $R/tests/native/prof_detr1.py 32 fp32 resnet50
 run r101bf16_mfma "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" $R/tests/native/prof_detr1.py 32 bf16 resnet101
 python3 $R/tests/native/sum_pmc.py --summary $R/gpurun_out > $R/gpurun_out/pmc_summary.json

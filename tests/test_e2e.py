@@ -143,7 +143,7 @@ def test_whole_pipeline_matches_the_reference_run(golden, measured, hungarian_mo
     # the same association once more through OdamProcess.process_frames (detections at hand -- what a rank holds after the all-gather:
     # one native call per frame, the host's work under the device's, processor.py): the track list of the loop above, bit for bit, and
     # every assignment matrix inside the same 2e-4 of the reference's
-    net.assignment = plain
+    del net.assignment          # (the instance-level hook of the loop above; with it in place process_frames keeps the steps separate)
     proc2 = OdamProcess(det, net, transforms.Transforms(size=SEQ["h"]), None)
     proc2.init_sequence(seq["K"], SEQ["h"], SEQ["w"])
     fin, dP2 = net.step_finish, []
@@ -153,10 +153,12 @@ def test_whole_pipeline_matches_the_reference_run(golden, measured, hungarian_mo
         dP2.append(np.abs(np.exp(Zt.numpy()) - np.exp(z[f"Z{len(dP2)}"])).max())
         return Zt
     net.step_finish = fin_checked
-    assert proc2._fast_ok()
+    # (with the Hungarian step on the device process_frames keeps the steps separate -- the same loop as above, hooks gone: no matrices logged)
+    assert proc2._fast_ok() == (hungarian_mode == 0)
     proc2.process_frames(list(seq["img_names"]), list(seq["T_wcs"]), [np.asarray(rows[fid], np.float64).reshape(-1, 79) for fid in seq["img_names"]])
     net.step_finish = fin
-    assert len(dP2) == int(z["n_calls"]) and max(dP2) <= 2e-4, (len(dP2), max(dP2))
+    if hungarian_mode == 0:
+        assert len(dP2) == int(z["n_calls"]) and max(dP2) <= 2e-4, (len(dP2), max(dP2))
     assert len(proc2.tracks) == len(proc.tracks)
     for t2, t1 in zip(proc2.tracks, proc.tracks):
         assert t2.shape == t1.shape and np.array_equal(np.ascontiguousarray(t2).view(np.uint8), np.ascontiguousarray(t1).view(np.uint8))
