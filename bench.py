@@ -185,6 +185,9 @@ def main():
     ap.add_argument("--chain-chunk", type=int, default=0, help="frames per all-gather of the --full-chain block (0 = the whole scene)")
     ap.add_argument("--chain-overlap", default="auto", choices=["auto", "on", "off"], help="--full-chain block: association of chunk i under the "
                     "detection + gather of chunk i + 1 (pipeline.run_scene overlap; auto = on for more than one rank and more than one chunk)")
+    ap.add_argument("--chain-variants", action="store_true", help="--full-chain block on more than one rank: also time the chunked and the "
+                    "chunked + overlapped forms (on one rank they are always timed); off by default there -- the overlapped form issues its collectives "
+                    "from a worker thread, which no multi-GPU box has run yet, and a secondary figure must not be able to take the N-rank line down")
     ap.add_argument("--dump-chain", default="", help="every rank r writes tracks, fits and merge result of the --full-chain block to <path>.r<r>.npz")
     ap.add_argument("--only-chain", action="store_true", help="run nothing but the --full-chain block (tests)")
     ap.add_argument("--no-pin", action="store_true", help="leave odam_config cg.pin at 0 (kernel choice by problem size: a rank's result then "
@@ -206,10 +209,13 @@ def main():
         if ws == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // ws)))   # ranks share the host cores
+        import datetime
+        # a collective that a peer never reaches must end the job (non-zero exit, the launcher stops the others), not hang it
+        tmo = datetime.timedelta(seconds=900)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", rank=rank, world_size=ws, device_id=torch.device(f"cuda:{local_rank}"), timeout=tmo)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=ws)
+            dist.init_process_group(args.backend, rank=rank, world_size=ws, timeout=tmo)
     device = f"cuda:{local_rank}"
     from odam_amd import _lib
     if not args.no_pin:
@@ -608,7 +614,7 @@ def full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, 
            "association_overlapped_with_detection": overlapped,
            "note": "odam_amd.pipeline.run_scene: detect (sharded) -> all-gather -> association replayed on every rank -> fit of the "
                    "resulting tracks (sharded) -> all-gather -> merge -> fit (sharded) -> all-gather; wall clock of rank 0 between barriers"}
-    if not args.only_chain and not args.chain_chunk and args.chain_overlap == "auto":
+    if not args.only_chain and not args.chain_chunk and args.chain_overlap == "auto" and (ws == 1 or args.chain_variants):
         # the same chain in chunks of 4 batches, association of chunk i under detection + gather of chunk i + 1 (pipeline.run_scene
         # overlap=True) and, for comparison, the same chunks one after the other: what chunking + overlap buy on THIS number of ranks
         ck = 4 * args.batch * max(ws, 1)

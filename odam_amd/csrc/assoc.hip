@@ -179,6 +179,7 @@ struct GnnArgs {
     unsigned long long timeout_ticks; // bound of one barrier wait in 100 MHz ticks (0: give up at the first barrier -- tests)
     unsigned long long* stamps;       // diagnostics (odam_assoc_stage_stamps): 100 MHz timer of workgroup 0 after every stage, or null
     int fake_misplaced;               // tests (odam_assoc_debug_misplace): gnn_rowpart_kernel's placement check behaves as if a group straddled XCDs
+    int merged;                       // odam_config assoc.merge: m0_w / m0_b hold [W0x | W0m Wm] / b0 + W0m bm, the attention writes into X[:, 256:], no merge stage
 };
 
 constexpr int SC1 = 16;      // cache-policy bit of the buffer intrinsics on gfx94x / gfx950
@@ -295,7 +296,7 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // softmax(Q K^T / 8) V per (query row, head), head dimension 64 (associator.py:75-82); one wavefront per item:
 // lane j scores key j, lane d accumulates output channel d, 64 source rows at a time (online softmax across chunks);
 // the key rows and the value columns of a chunk are all in flight together.  sc: this wave's LDS strip [64].
-__device__ void stage_attn(const float* kv, int T, int cross, float* att, float* sc, int wave_g, int lane) {
+__device__ void stage_attn(const float* kv, int T, int cross, float* att, int ldatt, float* sc, int wave_g, int lane) {
     const int MX = T + ND;
     const __amdgpu_buffer_rsrc_t kb = coh_buf(kv), ab = coh_buf(att);
     for (int item = wave_g; item < MX * 4; item += PG_WG * PG_NW) {
@@ -336,7 +337,7 @@ __device__ void stage_attn(const float* kv, int T, int cross, float* att, float*
             for (int jj = 0; jj < 64; jj++) o += (jj < nj ? sc[jj] : 0.0f) * vv[jj];
             __builtin_amdgcn_wave_barrier();
         }
-        coh_st(ab, q * 256 + hd * 64 + lane, o / run_sum);
+        coh_st(ab, q * ldatt + hd * 64 + lane, o / run_sum);
     }
 }
 
@@ -357,10 +358,15 @@ __global__ __launch_bounds__(PG_NT) void gnn_persistent_kernel(GnnArgs a) {
         const GnnLayerW& P = a.L[l];
         stage_gemm<D, false>(a.X, 512, P.qkv_w, P.qkv_b, MX, 3 * D, nullptr, a.kv, 3 * D, red, wave, lane);
         PG_BARRIER();
-        stage_attn(a.kv, T, P.cross, a.att, sc, wave_g, lane);
-        PG_BARRIER();
-        stage_gemm<D, false>(a.att, D, P.mg_w, P.mg_b, MX, D, nullptr, a.X + D, 512, red, wave, lane);
-        PG_BARRIER();
+        if (a.merged) {      // the attention's rows ARE the second half of the MLP's input (merge folded into m0_w)
+            stage_attn(a.kv, T, P.cross, a.X + D, 512, sc, wave_g, lane);
+            PG_BARRIER();
+        } else {
+            stage_attn(a.kv, T, P.cross, a.att, 256, sc, wave_g, lane);
+            PG_BARRIER();
+            stage_gemm<D, false>(a.att, D, P.mg_w, P.mg_b, MX, D, nullptr, a.X + D, 512, red, wave, lane);
+            PG_BARRIER();
+        }
         stage_gemm<2 * D, true>(a.X, 512, P.m0_w, P.m0_b, MX, 2 * D, nullptr, a.h, 2 * D, red, wave, lane);
         PG_BARRIER();
         stage_gemm<2 * D, false>(a.h, 2 * D, P.m2_w, P.m2_b, MX, D, a.X, a.X, 512, red, wave, lane);
@@ -460,7 +466,7 @@ __device__ void stage_gemm_rows(const float* X, int lda, const float* W, const f
 
 // stage_attn for the queries [r0, r0 + nR) (items dealt over the n_waves wavefronts of this XCD); keys and values of every row come
 // from kv (sc1 loads), the output stays in this XCD (plain store)
-__device__ void stage_attn_rows(const float* kv, int T, int cross, float* att, float* sc, int r0, int nR, int wave_x, int n_waves, int lane) {
+__device__ void stage_attn_rows(const float* kv, int T, int cross, float* att, int ldatt, float* sc, int r0, int nR, int wave_x, int n_waves, int lane) {
     const __amdgpu_buffer_rsrc_t kb = coh_buf(kv);
     for (int item = wave_x; item < nR * 4; item += n_waves) {
         const int q = r0 + (item >> 2), hd = item & 3;
@@ -500,7 +506,7 @@ __device__ void stage_attn_rows(const float* kv, int T, int cross, float* att, f
             for (int jj = 0; jj < 64; jj++) o += (jj < nj ? sc[jj] : 0.0f) * vv[jj];
             __builtin_amdgcn_wave_barrier();
         }
-        att[(size_t)q * 256 + hd * 64 + lane] = o / run_sum;
+        att[(size_t)q * ldatt + hd * 64 + lane] = o / run_sum;
     }
 }
 
@@ -540,10 +546,15 @@ __global__ __launch_bounds__(PG_NT) void gnn_rowpart_kernel(GnnArgs a) {
         float* kv = (l & 1) ? a.kv2 : a.kv;
         stage_gemm_rows<D, false, true>(a.X, 512, P.qkv_w, P.qkv_b, r0, nR, 3 * D, nullptr, kv, 3 * D, red, wave, lane, wi, nw);
         PG_BARRIER();
-        stage_attn_rows(kv, T, P.cross, a.att, sc, r0, nR, wave_x, n_waves, lane);
-        PX_BARRIER();
-        stage_gemm_rows<D, false, false>(a.att, D, P.mg_w, P.mg_b, r0, nR, D, nullptr, a.X + D, 512, red, wave, lane, wi, nw);
-        PX_BARRIER();
+        if (a.merged) {
+            stage_attn_rows(kv, T, P.cross, a.X + D, 512, sc, r0, nR, wave_x, n_waves, lane);
+            PX_BARRIER();
+        } else {
+            stage_attn_rows(kv, T, P.cross, a.att, 256, sc, r0, nR, wave_x, n_waves, lane);
+            PX_BARRIER();
+            stage_gemm_rows<D, false, false>(a.att, D, P.mg_w, P.mg_b, r0, nR, D, nullptr, a.X + D, 512, red, wave, lane, wi, nw);
+            PX_BARRIER();
+        }
         stage_gemm_rows<2 * D, true, false>(a.X, 512, P.m0_w, P.m0_b, r0, nR, 2 * D, nullptr, a.h, 2 * D, red, wave, lane, wi, nw);
         PX_BARRIER();
         stage_gemm_rows<2 * D, false, false>(a.h, 2 * D, P.m2_w, P.m2_b, r0, nR, D, a.X, a.X, 512, red, wave, lane, wi, nw);
@@ -886,6 +897,7 @@ struct odam_assoc {
     bool want_stamps = false;
     bool fake_misplaced = false;             // tests: odam_assoc_debug_misplace
     bool bar_clean = false;                  // the counters are zero: the one-wavefront Sinkhorn kernel zeroes them behind the launch that used them
+    bool merged = false;                     // odam_config assoc.merge as read by odam_assoc_finalize: every Prop's m0 holds the merge projection too
 
     // Zeroing goes through a private non-blocking stream that finalize waits for: hipMemset would be ordered on the NULL stream -- it
     // may still be pending when it returns (and then land behind the first results of a caller that works on a stream of its own),
@@ -968,16 +980,42 @@ int pack_prop(odam_assoc* m, Prop& P, const std::string& pre) {
     RC(pack(m, P.merge, *wm, bm, D, nullptr, &hp));      // its input channels arrive head-major
     NEEDW(m0w, pre + "mlp.0.weight"); NEEDW(m0b, pre + "mlp.0.bias");
     NEEDW(m2w, pre + "mlp.2.weight"); NEEDW(m2b, pre + "mlp.2.bias");
-    RC(pack(m, P.m0, *m0w, m0b, 2 * D, nullptr, nullptr));
+    if (m->merged) {
+        // message = Wm att + bm feeds only the first MLP layer, h = relu(W0x x + W0m message + b0) (associator.py:92-97): the same function of
+        // [x | att] with W0' = [W0x | W0m Wm] and b0' = b0 + W0m bm -- products in binary64, rounded to float32 once.  att arrives head-major
+        // (column c' of the attention's output is the reference's channel hp[c']), so the folded columns are taken in that order.
+        HostT w0f, b0f;
+        w0f.shape = {2 * D, 2 * D}; b0f.shape = {2 * D};
+        w0f.data.resize((size_t)2 * D * 2 * D); b0f.data.resize(2 * D);
+        for (int o = 0; o < 2 * D; o++) {
+            const float* w0row = m0w->data.data() + (size_t)o * 2 * D;
+            for (int c = 0; c < D; c++) w0f.data[(size_t)o * 2 * D + c] = w0row[c];
+            for (int c = 0; c < D; c++) {
+                double s_ = 0.0;
+                for (int r = 0; r < D; r++) s_ += (double)w0row[D + r] * (double)wm->data[(size_t)r * D + hp[c]];
+                w0f.data[(size_t)o * 2 * D + D + c] = (float)s_;
+            }
+            double sb = (double)m0b->data[o];
+            for (int r = 0; r < D; r++) sb += (double)w0row[D + r] * (double)bm->data[r];
+            b0f.data[o] = (float)sb;
+        }
+        RC(pack(m, P.m0, w0f, &b0f, 2 * D, nullptr, nullptr));
+    } else {
+        RC(pack(m, P.m0, *m0w, m0b, 2 * D, nullptr, nullptr));
+    }
     RC(pack(m, P.m2, *m2w, m2b, 2 * D, nullptr, nullptr));
     return 0;
 }
 
 // self-attention layer over Bt sequences of L rows (the fuser): message into cat_x[:, 256:], delta added in place
-int prop_forward_self(const Prop& P, float* cat_x, int Mx, int Bt, int L, float* qkvb, float* attb, float* hb, hipStream_t st) {
+int prop_forward_self(const Prop& P, float* cat_x, int Mx, int Bt, int L, float* qkvb, float* attb, float* hb, hipStream_t st, bool merged) {
     RC(lin(P.qkv, cat_x, 512, Mx, nullptr, false, qkvb, 3 * D, nullptr, st));
-    RC(odam_dk::launch_attention_d64(qkvb, 3 * D, qkvb + D, 3 * D, qkvb + 2 * D, 3 * D, attb, D, Bt, 4, L, L, st));
-    RC(lin(P.merge, attb, D, Mx, nullptr, false, cat_x + D, 512, nullptr, st));
+    if (merged) {      // the attention's rows are the second half of the MLP's input as they stand (merge folded into P.m0: pack_prop)
+        RC(odam_dk::launch_attention_d64(qkvb, 3 * D, qkvb + D, 3 * D, qkvb + 2 * D, 3 * D, cat_x + D, 512, Bt, 4, L, L, st));
+    } else {
+        RC(odam_dk::launch_attention_d64(qkvb, 3 * D, qkvb + D, 3 * D, qkvb + 2 * D, 3 * D, attb, D, Bt, 4, L, L, st));
+        RC(lin(P.merge, attb, D, Mx, nullptr, false, cat_x + D, 512, nullptr, st));
+    }
     RC(lin(P.m0, cat_x, 512, Mx, nullptr, true, hb, 2 * D, nullptr, st));
     RC(lin(P.m2, hb, 2 * D, Mx, cat_x, false, cat_x, 512, nullptr, st));
     return 0;
@@ -1032,6 +1070,7 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
         RC(m->upload(&m->div_term, dv->data));
         RC(m->upload(&m->sc16, std::vector<float>(ND, 1.0f / 16.0f)));   // scores / descriptor_dim ** 0.5
     }
+    m->merged = odam_cfg::get(odam_cfg::ASSOC_MERGE) != 0;
     for (int i = 0; i < m->n_self; i++) {
         Prop P;
         RC(pack_prop(m, P, "fuser.layers." + std::to_string(i) + "."));
@@ -1104,7 +1143,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
     RC(lin(m->enc2, m->h256, D, N + ND, m->catT, false, m->catT, 512, nullptr, st));           // + pe, in place
     // fuser: self-attention over each track's 100 time steps (associator.py:143-160, 230)
     for (const Prop& P : m->fuser)
-        RC(prop_forward_self(P, m->catT, N, T, NT, m->kv, m->att, m->h512, st));
+        RC(prop_forward_self(P, m->catT, N, T, NT, m->kv, m->att, m->h512, st, m->merged));
     hipLaunchKernelGGL(time_mean_kernel, dim3(T + ND), dim3(256), 0, st, m->catT, NT, X, T);
     ODAM_HIP(hipGetLastError());
     // matching GNN between the fused tracks [T] and all 30 detection slots (associator.py:111-139, 240).  Both sets
@@ -1124,6 +1163,7 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         g.bar = m->bar; g.timeout_ticks = m->timeout_ticks;
         g.stamps = m->want_stamps ? m->stamps : nullptr;
         g.fake_misplaced = m->fake_misplaced ? 1 : 0;
+        g.merged = m->merged ? 1 : 0;
         // counters and the error flag start from zero every launch: zeroed here, unless the Sinkhorn kernel behind the previous launch did it
         if (!m->bar_clean) ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * PG_BAR_WORDS, st));
         m->bar_clean = false;
@@ -1149,10 +1189,12 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         const float* srcT = cross ? m->kvX + (size_t)T * 3 * D : m->kvX;     // source rows of the track queries
         const float* srcD = cross ? m->kvX : m->kvX + (size_t)T * 3 * D;     // ... of the detection queries
         const int nT = cross ? ND : T, nD = cross ? T : ND;
-        RC(odam_dk::launch_attention_d64(m->kvX, 3 * D, srcT + D, 3 * D, srcT + 2 * D, 3 * D, m->attX, D, 1, 4, T, nT, st));
+        float* attO = m->merged ? X + D : m->attX;
+        const int ldO = m->merged ? 512 : D;
+        RC(odam_dk::launch_attention_d64(m->kvX, 3 * D, srcT + D, 3 * D, srcT + 2 * D, 3 * D, attO, ldO, 1, 4, T, nT, st));
         RC(odam_dk::launch_attention_d64(m->kvX + (size_t)T * 3 * D, 3 * D, srcD + D, 3 * D, srcD + 2 * D, 3 * D,
-                                         m->attX + (size_t)T * D, D, 1, 4, ND, nD, st));
-        RC(lin(P.merge, m->attX, D, MX, nullptr, false, X + D, 512, nullptr, st));
+                                         attO + (size_t)T * ldO, ldO, 1, 4, ND, nD, st));
+        if (!m->merged) RC(lin(P.merge, m->attX, D, MX, nullptr, false, X + D, 512, nullptr, st));
         RC(lin(P.m0, X, 512, MX, nullptr, true, m->hX, 2 * D, nullptr, st));
         RC(lin(P.m2, m->hX, 2 * D, MX, X, false, X, 512, nullptr, st));
     }

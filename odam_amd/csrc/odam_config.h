@@ -39,6 +39,10 @@ enum Key {
     ASSOC_HUNGARIAN,  // the Hungarian step of the association (associator.py:19-35): 1 on the device behind the Sinkhorn loop (odam_assoc_hungarian: scipy's
                     // solver restated on one wavefront), 0 (default) scipy on the host as the reference does -- measured 0.01 ms per frame FASTER than the
                     // device form (the host waits for the device either way).  Read by the HOST side (odam_amd/associator.py), the library only keeps it
+    ASSOC_MERGE,    // association: the attention's merge projection folded into the first MLP layer at load time (W0' = [W0x | W0m Wm], b0' = b0 + W0m bm,
+                    // products in binary64, rounded once): one launch per fuser layer and one barrier stage per matching layer fewer.  The same
+                    // function of the weights, not the same roundings (differences of ~1e-7 relative in the layer's hidden row).  Read when a
+                    // handle is finalised.  Default: see odam_common.hip
     N_KEYS
 };
 int get(Key k);
