@@ -296,7 +296,8 @@ __device__ __forceinline__ float wave_sum64(float v) {
 // softmax(Q K^T / 8) V per (query row, head), head dimension 64 (associator.py:75-82); one wavefront per item:
 // lane j scores key j, lane d accumulates output channel d, 64 source rows at a time (online softmax across chunks);
 // the key rows and the value columns of a chunk are all in flight together.  sc: this wave's LDS strip [64].
-__device__ void stage_attn(const float* kv, int T, int cross, float* att, int ldatt, float* sc, int wave_g, int lane) {
+template <int ldatt>
+__device__ void stage_attn(const float* kv, int T, int cross, float* att, float* sc, int wave_g, int lane) {
     const int MX = T + ND;
     const __amdgpu_buffer_rsrc_t kb = coh_buf(kv), ab = coh_buf(att);
     for (int item = wave_g; item < MX * 4; item += PG_WG * PG_NW) {
@@ -341,6 +342,7 @@ __device__ void stage_attn(const float* kv, int T, int cross, float* att, int ld
     }
 }
 
+template <bool MERGED>      // odam_config assoc.merge (two instantiations: one kernel holding both forms went from 245 to 248 + 32 registers and 256 B of scratch)
 __global__ __launch_bounds__(PG_NT) void gnn_persistent_kernel(GnnArgs a) {
     __shared__ float red[(PG_NW - 1) * 64 * 4];
     __shared__ float scs[PG_NW * 64];
@@ -358,11 +360,11 @@ __global__ __launch_bounds__(PG_NT) void gnn_persistent_kernel(GnnArgs a) {
         const GnnLayerW& P = a.L[l];
         stage_gemm<D, false>(a.X, 512, P.qkv_w, P.qkv_b, MX, 3 * D, nullptr, a.kv, 3 * D, red, wave, lane);
         PG_BARRIER();
-        if (a.merged) {      // the attention's rows ARE the second half of the MLP's input (merge folded into m0_w)
-            stage_attn(a.kv, T, P.cross, a.X + D, 512, sc, wave_g, lane);
+        if constexpr (MERGED) {      // the attention's rows ARE the second half of the MLP's input (merge folded into m0_w)
+            stage_attn<512>(a.kv, T, P.cross, a.X + D, sc, wave_g, lane);
             PG_BARRIER();
         } else {
-            stage_attn(a.kv, T, P.cross, a.att, 256, sc, wave_g, lane);
+            stage_attn<256>(a.kv, T, P.cross, a.att, sc, wave_g, lane);
             PG_BARRIER();
             stage_gemm<D, false>(a.att, D, P.mg_w, P.mg_b, MX, D, nullptr, a.X + D, 512, red, wave, lane);
             PG_BARRIER();
@@ -466,7 +468,8 @@ __device__ void stage_gemm_rows(const float* X, int lda, const float* W, const f
 
 // stage_attn for the queries [r0, r0 + nR) (items dealt over the n_waves wavefronts of this XCD); keys and values of every row come
 // from kv (sc1 loads), the output stays in this XCD (plain store)
-__device__ void stage_attn_rows(const float* kv, int T, int cross, float* att, int ldatt, float* sc, int r0, int nR, int wave_x, int n_waves, int lane) {
+template <int ldatt>
+__device__ void stage_attn_rows(const float* kv, int T, int cross, float* att, float* sc, int r0, int nR, int wave_x, int n_waves, int lane) {
     const __amdgpu_buffer_rsrc_t kb = coh_buf(kv);
     for (int item = wave_x; item < nR * 4; item += n_waves) {
         const int q = r0 + (item >> 2), hd = item & 3;
@@ -510,6 +513,7 @@ __device__ void stage_attn_rows(const float* kv, int T, int cross, float* att, i
     }
 }
 
+template <bool MERGED>
 __global__ __launch_bounds__(PG_NT) void gnn_rowpart_kernel(GnnArgs a) {
     __shared__ float red[(PG_NW - 1) * 64 * 4];
     __shared__ float scs[PG_NW * 64];
@@ -546,11 +550,11 @@ __global__ __launch_bounds__(PG_NT) void gnn_rowpart_kernel(GnnArgs a) {
         float* kv = (l & 1) ? a.kv2 : a.kv;
         stage_gemm_rows<D, false, true>(a.X, 512, P.qkv_w, P.qkv_b, r0, nR, 3 * D, nullptr, kv, 3 * D, red, wave, lane, wi, nw);
         PG_BARRIER();
-        if (a.merged) {
-            stage_attn_rows(kv, T, P.cross, a.X + D, 512, sc, r0, nR, wave_x, n_waves, lane);
+        if constexpr (MERGED) {
+            stage_attn_rows<512>(kv, T, P.cross, a.X + D, sc, r0, nR, wave_x, n_waves, lane);
             PX_BARRIER();
         } else {
-            stage_attn_rows(kv, T, P.cross, a.att, 256, sc, r0, nR, wave_x, n_waves, lane);
+            stage_attn_rows<256>(kv, T, P.cross, a.att, sc, r0, nR, wave_x, n_waves, lane);
             PX_BARRIER();
             stage_gemm_rows<D, false, false>(a.att, D, P.mg_w, P.mg_b, r0, nR, D, nullptr, a.X + D, 512, red, wave, lane, wi, nw);
             PX_BARRIER();
@@ -1114,7 +1118,7 @@ extern "C" int odam_assoc_finalize(odam_assoc* m) {
         int dev = 0, n_cu = 0, per_cu = 0;
         ODAM_HIP(hipGetDevice(&dev));
         ODAM_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        ODAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gnn_persistent_kernel, PG_NT, 0));
+        ODAM_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)gnn_persistent_kernel<false>, PG_NT, 0));
         m->resident_capacity = (per_cu > 1 ? per_cu - 1 : per_cu) * n_cu;
         if (getenv("HSA_CU_MASK") != nullptr || getenv("ROC_GLOBAL_CU_MASK") != nullptr) m->resident_capacity = 0;
         if (m->resident_capacity < PG_WG) m->persist = false;
@@ -1167,8 +1171,14 @@ static int enqueue_forward(odam_assoc* m, const float* tracks, int T, const floa
         // counters and the error flag start from zero every launch: zeroed here, unless the Sinkhorn kernel behind the previous launch did it
         if (!m->bar_clean) ODAM_HIP(hipMemsetAsync(m->bar, 0, sizeof(unsigned) * PG_BAR_WORDS, st));
         m->bar_clean = false;
-        if (odam_cfg::get(odam_cfg::ASSOC_PERSIST) == 2) hipLaunchKernelGGL(gnn_rowpart_kernel, dim3(PG_WG), dim3(PG_NT), 0, st, g);
-        else hipLaunchKernelGGL(gnn_persistent_kernel, dim3(PG_WG), dim3(PG_NT), 0, st, g);
+        const bool rowpart = odam_cfg::get(odam_cfg::ASSOC_PERSIST) == 2;
+        if (m->merged) {
+            if (rowpart) hipLaunchKernelGGL(gnn_rowpart_kernel<true>, dim3(PG_WG), dim3(PG_NT), 0, st, g);
+            else hipLaunchKernelGGL(gnn_persistent_kernel<true>, dim3(PG_WG), dim3(PG_NT), 0, st, g);
+        } else {
+            if (rowpart) hipLaunchKernelGGL(gnn_rowpart_kernel<false>, dim3(PG_WG), dim3(PG_NT), 0, st, g);
+            else hipLaunchKernelGGL(gnn_persistent_kernel<false>, dim3(PG_WG), dim3(PG_NT), 0, st, g);
+        }
         ODAM_HIP(hipGetLastError());
         // The score matrix keeps its own launch on the tiles of conv_gemm.hip: with saturated scores (the hand-built scene
         // weights reach +-1000) the Sinkhorn loop shares a detection's mass equally among several tracks and which of them

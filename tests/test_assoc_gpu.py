@@ -71,12 +71,22 @@ def test_sinkhorn_rows_on_lanes_vs_float64(m, n, scale):
         assert (np.abs(np.exp(o) - np.exp(ref)) / np.maximum(np.exp(ref), 1.0)).max() <= 2 * tol      # entries are probabilities x (m + n)
 
 
-def test_forward_vs_reference_associator(golden):
-    from odam_amd import associator, weights
+@pytest.mark.parametrize("merge", [1, 0], ids=["merge projection folded into the MLP", "merge projection as its own layer"])
+def test_forward_vs_reference_associator(golden, merge):
+    """the association forward against the reference's own (src/models/associator.py:202-254 run on the CPU, tests/golden/assoc.npz), in both
+    forms of odam_config assoc.merge: the attention's merge projection as its own layer (what the reference computes, step by step) and folded
+    into the first MLP layer at load time (the default: one launch / one barrier stage per layer fewer) -- the same bounds for both"""
+    from odam_amd import _lib, associator, weights
     z = golden("assoc.npz")
     a = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"],
                                "sinkhorn_iterations": 100}, max_tracks=64, device=DEV)
     a.load_state_dict(weights.make_associator_state_dict(2, 8, seed=0))
+    old = _lib.get_config("assoc.merge")
+    _lib.set_config("assoc.merge", merge)
+    try:
+        a._handle()                                        # the switch is read when the handle is finalised
+    finally:
+        _lib.set_config("assoc.merge", old)
     for c in range(int(z["n_cases"])):
         tr, de, Zr, mr = z[f"c{c}_tracks"], z[f"c{c}_det"], z[f"c{c}_Z"], z[f"c{c}_matches"]
         T, n_det = Zr.shape[0] - 1, Zr.shape[1] - 1
@@ -90,6 +100,43 @@ def test_forward_vs_reference_associator(golden):
         assert np.abs(Z[big] - Zr[big]).max() <= 2e-3, c
         assert np.array_equal(out["matches"][0], mr), c          # object IDs: exact
     a.close()
+
+
+def test_folded_merge_projection_is_the_same_network(golden):
+    """odam_config assoc.merge = 1 against 0 on few and many tracks, on all three forms of the matching layers (rows dealt to the XCDs, device-
+    wide barriers, launch sequence): W0' = [W0x | W0m Wm] is the same function of the weights -- assignment probabilities equal to fp32 rounding
+    noise (the folded product is rounded once where the layer-by-layer form rounds the message and re-multiplies it)"""
+    from odam_amd import _lib, associator, weights
+    z = golden("assoc.npz")
+    sd = weights.make_associator_state_dict(2, 8, seed=0)
+    cfg = {"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}
+    nets = {}
+    old = (_lib.get_config("assoc.merge"), _lib.get_config("assoc.persist"))
+    try:
+        for merge in (0, 1):
+            for persist in (2, 1, 0):
+                _lib.set_config("assoc.merge", merge); _lib.set_config("assoc.persist", persist)
+                n_ = associator.Associator(cfg, max_tracks=160, device=DEV)
+                n_.load_state_dict(sd)
+                n_._handle()
+                nets[(merge, persist)] = n_
+    finally:
+        _lib.set_config("assoc.merge", old[0]); _lib.set_config("assoc.persist", old[1])
+    g = torch.Generator().manual_seed(9)
+    base_t = torch.from_numpy(z["c0_tracks"]); base_d = torch.from_numpy(z["c0_det"])
+    worst = 0.0
+    for T, n in ((1, 1), (5, 30), (17, 9), (42, 21), (70, 30), (129, 17)):
+        tr = base_t[torch.randint(0, base_t.shape[0], (T,), generator=g)].clone()
+        tr[:, 1:] += 0.05 * torch.randn(tr[:, 1:].shape, generator=g) * (tr[:, 1:] != -1)
+        Z = {k: v.assignment(tr.to(DEV), base_d.to(DEV), T, n).cpu().numpy() for k, v in nets.items()}
+        for persist in (2, 1, 0):
+            a_, b_ = Z[(0, persist)], Z[(1, persist)]
+            assert np.isfinite(b_).all()
+            worst = max(worst, float(np.abs(np.exp(a_) - np.exp(b_)).max()))
+        assert np.array_equal(Z[(1, 2)], Z[(1, 1)])        # the two persistent kernels stay bit-identical in the folded form too
+    assert worst <= 5e-5, worst
+    for n_ in nets.values():
+        n_.close()
 
 
 def test_persistent_matching_kernel_vs_launch_sequence(golden):

@@ -41,14 +41,17 @@ def _key(t):
     return tuple(map(tuple, np.asarray(t)[:, :2]))
 
 
-@pytest.fixture(params=[1, 0], ids=["hungarian on the device", "hungarian by scipy"])
+@pytest.fixture(params=[1, 0], ids=["hungarian on the device, merge projection as its own layer", "hungarian by scipy, merge projection folded (defaults)"])
 def hungarian_mode(request):
-    """the whole-chain test runs with the Hungarian step on the device (odam_assoc_hungarian) and on the host (scipy, the library's default)"""
+    """the whole-chain test runs with the Hungarian step on the device (odam_assoc_hungarian) and on the host (scipy, the library's default) --
+    and, so that both forms of the association network go through the whole chain, the first with odam_config assoc.merge = 0 (the merge
+    projection as its own layer) and the second with the default (folded into the MLP at load time)"""
     from odam_amd import _lib
-    old = _lib.get_config("assoc.hungarian")
+    old = (_lib.get_config("assoc.hungarian"), _lib.get_config("assoc.merge"))
     _lib.set_config("assoc.hungarian", request.param)
+    _lib.set_config("assoc.merge", 0 if request.param == 1 else 1)
     yield request.param
-    _lib.set_config("assoc.hungarian", old)
+    _lib.set_config("assoc.hungarian", old[0]); _lib.set_config("assoc.merge", old[1])
 
 
 def test_whole_pipeline_matches_the_reference_run(golden, measured, hungarian_mode):
