@@ -28,7 +28,8 @@ extern "C" {
 
 #define ODAM_SQ_POINTS 1000      /* surface samples per super-quadric   (sq_libs.py:545) */
 #define ODAM_SQ_MAX_VIEWS 1024   /* views one workgroup reduces; an object split over k workgroups may have k times as many
-                                    (k <= 32 -- odam_config sq.split --, and k * padded object count <= number of CUs) */
+                                    (k <= 32, odam_config sq.split, and k * padded object count <= number of CUs; odam_sq_fit_batch takes at most
+                                    16 * ODAM_SQ_MAX_VIEWS views per object) */
 
 /* representation codes, sq_libs.py:362-386 */
 #define ODAM_SQ_SUPER_QUADRIC 0  /* 9 parameters optimised */

@@ -19,6 +19,9 @@ for c0, rows16 in det.detect_resident_chunks(frames, (synth.IMG_W, synth.IMG_H),
         sel = det.select(rows16[i], 0.6, True, 30)
         per_frame.append(detection_array({k: [v] for k, v in sel.items()}, 0, scene["img_names"][c0 + i], synth.IMG_W, synth.IMG_H))
 det.close()
+if os.environ.get("ASSOC_CG_FORCE"):      # experiment: one tile shape for every contraction of the association network (odam_config cg.force)
+    from odam_amd import _lib
+    _lib.set_config("cg.force", int(os.environ["ASSOC_CG_FORCE"]))
 net = associator.Associator({"GNN_layers": ["self", "cross"] * 4, "self_GNN_layers": ["self", "self"], "sinkhorn_iterations": 100}, max_tracks=128, device=dev)
 net.load_state_dict(scene_weights.make_scene_associator_state_dict(2, 8, seed=0))
 class _Det: device = dev
