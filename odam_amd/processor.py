@@ -510,15 +510,33 @@ class OdamProcess:
                         continue
                     app = self._pending_app or ((), np.zeros((0, 82)))
                     self._pending_app = None
-                    assoc.step_launch(win, fitter, app[0], np.asarray(app[1])[:, :14], self._n_tracks, cur["cam21"], float(cur["cam_azi"]),
-                                      float(m.img_w), float(m.img_h), cur["det32T"])
+                    try:
+                        assoc.step_launch(win, fitter, app[0], np.asarray(app[1])[:, :14], self._n_tracks, cur["cam21"], float(cur["cam_azi"]),
+                                          float(m.img_w), float(m.img_h), cur["det32T"])
+                    except BaseException:
+                        self._mirror_unknown()
+                        raise
                     launched = True
             if k + 1 < n:
                 nxt = prep(k + 1)                 # under the device's work on frame k
             if launched:
-                Z = assoc.step_finish()
+                try:
+                    Z = assoc.step_finish()
+                except BaseException:
+                    self._mirror_unknown()
+                    raise
                 self._attach_fast(Z, cur)
         return None
+
+    def _mirror_unknown(self):
+        """a native call of the fast path failed: what the device mirror holds is not known any more (the append of the last attach may or may
+        not have run) -- forget its host-side bookkeeping, so that whoever uses it next (either path) rebuilds it from the track list"""
+        self._pending_app = None
+        self._exposed = True
+        self._win_meta_stale = False
+        win = getattr(self, "_win", None)
+        if win is not None:
+            win.lengths = [-1]          # no track list has this: in_step() fails, load() follows
 
     def _rewind_frame(self):
         self.usable_frames.pop(); self.T_wcs.pop(); self.P_cws.pop()

@@ -457,7 +457,28 @@ def test_process_frames_fast_path_equals_the_frame_by_frame_path(golden):
     assert len(got) == len(tracks_a)
     for t, r in zip(got, tracks_a):      # the launch sequence sums in another order than the persistent kernel: same decisions, rows equal
         assert t.shape == r.shape and np.array_equal(t.view(np.uint8), np.ascontiguousarray(r).view(np.uint8))
-    for n_ in (net_a, net_a2, net_b, net_c, net_d):
+    # E: a native call of the fast path fails (here: before it reaches the library, with the previous frame's attach already taken off the
+    # pending list): the exception comes out, the mirror's content is unknown -- the next frame, on either path, rebuilds it from the track
+    # list; retried from the failed frame the sequence ends where the others do
+    proc_e, net_e = make()
+    launch_e = net_e.step_launch
+    n_e = [0]
+
+    def failing(*a, **k):
+        n_e[0] += 1
+        if n_e[0] == 9:
+            raise RuntimeError("launch failed on purpose")
+        return launch_e(*a, **k)
+    net_e.step_launch = failing
+    with pytest.raises(RuntimeError, match="on purpose"):
+        proc_e.process_frames(ids, T, dets)
+    done = len(proc_e.usable_frames) - 1          # the failed frame's bookkeeping is in; its association never ran
+    proc_e._rewind_frame()
+    assert 5 <= done < len(ids) - 5
+    assert not proc_e._win.in_step(proc_e.tracks)      # nobody may trust the mirror now
+    proc_e.process_frames(ids[done:], T[done:], dets[done:])
+    same_tracks(proc_e.tracks)
+    for n_ in (net_a, net_a2, net_b, net_c, net_d, net_e):
         n_.close()
 
 
