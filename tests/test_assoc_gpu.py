@@ -478,7 +478,24 @@ def test_process_frames_fast_path_equals_the_frame_by_frame_path(golden):
     assert not proc_e._win.in_step(proc_e.tracks)      # nobody may trust the mirror now
     proc_e.process_frames(ids[done:], T[done:], dets[done:])
     same_tracks(proc_e.tracks)
-    for n_ in (net_a, net_a2, net_b, net_c, net_d, net_e):
+    # F: the corners of process_frame's contract (src/processor.py:312-323): a frame without detections in the middle (bookkeeping only), one
+    # with more than 30 (truncated), an empty FIRST frame (tracks start at the second) -- both paths, same inputs
+    dets_f = [d.copy() for d in dets]
+    dets_f[0] = np.zeros((0, 79))
+    dets_f[6] = np.zeros((0, 79))
+    many = np.concatenate([dets[9]] * 12)[:34].copy()
+    many[:, 9:12] += np.linspace(0.0, 0.5, len(many))[:, None]
+    dets_f[9] = many
+    proc_h, net_h = make()
+    for i in range(len(ids)):
+        proc_h._process_frame_host(None, ids[i], T[i], dets_f[i])
+    proc_f, net_f = make()
+    proc_f.process_frames(ids, T, dets_f)
+    th, tf = proc_h.tracks, proc_f.tracks
+    assert len(th) == len(tf) >= 2 and proc_h.usable_frames == proc_f.usable_frames == ids
+    for t, r in zip(tf, th):
+        assert t.shape == r.shape and np.array_equal(np.ascontiguousarray(t).view(np.uint8), np.ascontiguousarray(r).view(np.uint8))
+    for n_ in (net_a, net_a2, net_b, net_c, net_d, net_e, net_h, net_f):
         n_.close()
 
 
