@@ -136,6 +136,17 @@ def launch_ranks(n, argv, one_device):
         # ranks other than 0 print nothing on stdout by contract; whatever a library writes there goes to stderr, so stdout is the line alone
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr))
+    # a parent that is told to stop (a driver's timeout) takes its ranks with it -- exactly the processes it started, by handle
+    import atexit
+    import signal
+
+    def stop_children(*_):
+        for p_ in procs:
+            if p_.poll() is None:
+                p_.terminate()
+    atexit.register(stop_children)
+    for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+        signal.signal(sig, lambda signum, frame: (stop_children(), sys.exit(128 + signum)))
     rc = 0
     alive = list(range(n))
     while alive:

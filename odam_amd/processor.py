@@ -563,23 +563,28 @@ class OdamProcess:
     def _attach_fast(self, Z, cur):
         """hungarian_matching + _attach_to_tracks (src/models/associator.py:19-35, src/processor.py:212-257) on the assignment of a
         fast frame: the same tests on the same float32 values; the rows go to the record list and to the mirror's next append"""
-        from .associator import hungarian_matching
+        from scipy.optimize import linear_sum_assignment
         n_det = cur["det32T"].shape[1]
-        match = hungarian_matching(Z[:-1, :-1].exp(), self.match_threshold).astype(np.int32)
+        # hungarian_matching (associator.py:19-35) on the float32 scores torch computes, without its Python loop: the assignment of
+        # linear_sum_assignment(1 - scores), kept where the matched score exceeds the match threshold
+        scores = Z[:-1, :-1].exp().numpy()
+        r_, c_ = linear_sum_assignment(1 - scores)
+        ok = scores[r_, c_] > self.match_threshold
+        match = np.full(n_det, -1, np.int32)
+        match[c_[ok]] = r_[ok]
+        # _attach_to_tracks' tests (processor.py:228-231): a detection is dropped if the score of its pair -- for an unmatched one the
+        # dustbin row, index -1 -- is below the score threshold (a NaN is not below anything: kept, as in the loop)
         score_mat = Z.exp().numpy()
-        rows = cur["rows82"]
-        ids, picked = [], []
+        keep = ~(score_mat[match, np.arange(n_det)] < self.score_threshold)
+        picked = np.flatnonzero(keep)
+        mk = match[picked]
+        new = mk == -1
         n_tracks = self._n_tracks
-        for det_id in range(n_det):
-            track_id = int(match[det_id])
-            if score_mat[track_id, det_id] < self.score_threshold:
-                continue
-            if track_id == -1:
-                ids.append(n_tracks)
-                n_tracks += 1
-            else:
-                ids.append(track_id)
-            picked.append(det_id)
+        ids_a = mk.astype(np.int64)
+        ids_a[new] = n_tracks + np.arange(int(new.sum()))
+        n_tracks += int(new.sum())
+        ids = ids_a.tolist()
+        rows = cur["rows82"]
         if ids:
             assert len(set(ids)) == len(ids), ids      # a track receives at most one observation per frame (the Hungarian step's matching)
             sel = rows[picked]
