@@ -6,7 +6,7 @@
  * changes which kernel runs -- and with it the order of an fp32 summation -- is an explicit, named switch of the process, set
  * by the host program; the library never reads the environment for them.  Keys, defaults and ranges: odam_amd/csrc/odam_config.h.
  *   cg.ring cg.f32 cg.fuse cg.fuse_bf16 cg.s1 cg.ut cg.tiles cg.force cg.presplit cg.mfma16 att.x3 att.bf16_mfma stem.rows
- *   assoc.persist sq.split sq.split_wait sq.lanes stem.pool cg.pin cg.small_x3 assoc.sk_fast assoc.hungarian assoc.merge
+ *   assoc.persist sq.split sq.split_wait sq.lanes stem.pool cg.pin cg.small_x3 assoc.sk_fast assoc.hungarian assoc.merge sq.two_per_cu
  * Return codes as in odam_sq.h (0 = OK; odam_last_error() has the message).  Setting a switch affects launches made after
  * the call; handles created earlier keep what they sized from it (assoc.persist is read when a handle is finalised).
  */

@@ -22,6 +22,7 @@ const Entry TABLE[N_KEYS] = {
     {"assoc.sk_fast", 1, 0, 3},
     {"assoc.hungarian", 0, 0, 1},
     {"assoc.merge", 1, 0, 1},
+    {"sq.two_per_cu", 1, 0, 1},
 };
 std::atomic<int> g_val[N_KEYS];
 std::atomic<bool> g_init{false};

@@ -44,7 +44,7 @@ using namespace odam_sq;
 #ifndef ODAM_SQ_NT
 #define ODAM_SQ_NT 1024
 #endif
-constexpr int NT = ODAM_SQ_NT;  // threads per workgroup
+constexpr int NT_MAX = ODAM_SQ_NT;  // threads per workgroup: 1024 (one workgroup per CU), or 512 where two per CU pay (launch_fit)
 constexpr int BUFP = 208;       // padded theta-buffer length
 constexpr int QCAP = 200;       // pending arcs per curve per level (sum of n over a level <= 199)
 constexpr int NONE = 0x7fffffff;
@@ -120,9 +120,16 @@ struct Lds {
     float* lterm;   // [views][4], only when the loss is logged
 };
 
+// The breadth-first queues of phase B2 (q: 8000 words) are dead from the end of B2 to the next step's B2; the surface points, their buffer
+// indices, the per-view gradient rows and the loss terms live from phase D to phase F.  The two sets share one region (round 6): 97 KB -> 81 KB
+// at <= 433 rows, which is what lets two 512-thread workgroups share a CU's 160 KB.
+__host__ __device__ inline size_t lds_shared_region_words(int rows, int loss_rows) {
+    const size_t q = (size_t)2 * 2 * QCAP * 10, pts = 3 * 1024 + 1024 + (size_t)rows * 9 + (size_t)loss_rows * 4;
+    return q > pts ? q : pts;
+}
 __host__ __device__ inline size_t lds_words(int rows, int loss_rows) {
-    return 12 * 6 + 8 + 8 + 32 + 288 + 3 * 1024 + 1024 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (size_t)2 * 2 * QCAP * 10 + 3 * 2 * 520 +
-           4 * 2 * 520 + 520 + 2 * 512 + 2 * BUFP + (size_t)rows * 9 + (size_t)loss_rows * 4;
+    return 12 * 6 + 8 + 8 + 32 + 288 + 2 * BUFP + 2 * BUFP + 8 * BUFP + 3 * 2 * 520 +
+           4 * 2 * 520 + 520 + 2 * 512 + 2 * BUFP + lds_shared_region_words(rows, loss_rows);
 }
 
 __device__ inline Lds carve(float* base, int pn) {
@@ -138,16 +145,10 @@ __device__ inline Lds carve(float* base, int pn) {
     L.cnt = (int*)w; w += 8;
     L.xready = (int*)w; w += 32;
     L.xroot = w; w += 288;
-    L.pwx = w; w += 1024;
-    L.pwy = w; w += 1024;
-    L.pwz = w; w += 1024;
-    L.ie = (unsigned short*)w; w += 512;
-    L.io = (unsigned short*)w; w += 512;
     L.buf = w; w += 2 * BUFP;
     L.cdf = w; w += BUFP;
     L.term = w; w += BUFP;
     L.fac = w; w += 8 * BUFP;
-    L.q = (QArc*)w; w += 2 * 2 * QCAP * 10;
     L.tth = w; w += 2 * 520;
     L.tcx = w; w += 2 * 520;
     L.tcy = w; w += 2 * 520;
@@ -158,6 +159,13 @@ __device__ inline Lds carve(float* base, int pn) {
     L.tfx = w; w += 520;
     L.rtab = w; w += 2 * 512;
     L.bufq = (int*)w; w += 2 * BUFP;
+    // the shared region (lds_shared_region_words): phase B2's queues, or -- from phase D on -- points | indices | gradient rows | loss terms
+    L.q = (QArc*)w;
+    L.pwx = w; w += 1024;
+    L.pwy = w; w += 1024;
+    L.pwz = w; w += 1024;
+    L.ie = (unsigned short*)w; w += 512;
+    L.io = (unsigned short*)w; w += 512;
     L.vgrad = w; w += (size_t)pn * 9;
     L.lterm = w;
     return L;
@@ -180,7 +188,8 @@ __device__ inline void merge_max(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
-__global__ __launch_bounds__(NT) void sq_fit_kernel(FitArgs A) {
+template <int NT>      // 1024: sixteen waves, one workgroup per CU; 512: eight waves at <= 128 registers, two workgroups per CU (launch_fit decides)
+__global__ __launch_bounds__(NT, 4) void sq_fit_kernel(FitArgs A) {      // (second argument: waves per SIMD -- 128 registers either way)
     extern __shared__ __align__(16) float smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -911,8 +920,8 @@ extern "C" int odam_sq_create(int max_iters, odam_sq_ctx** out) {
         ODAM_HIP(hipMemcpy(c->d_draws, draws.data(), sizeof(float) * N_PTS, hipMemcpyHostToDevice));
         ODAM_HIP(hipMemcpy(c->d_omega_idx, oidx.data(), sizeof(unsigned short) * N_PTS, hipMemcpyHostToDevice));
         ODAM_HIP(hipMemcpy(c->d_adam, tab.data(), sizeof(float) * tab.size(), hipMemcpyHostToDevice));
-        ODAM_HIP(hipFuncSetAttribute((const void*)sq_fit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     160 * 1024));
+        ODAM_HIP(hipFuncSetAttribute((const void*)sq_fit_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ODAM_HIP(hipFuncSetAttribute((const void*)sq_fit_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         return ODAM_OK;
     }();
     if (rc != ODAM_OK) {
@@ -997,7 +1006,12 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     A.pn_views = rows;
     const size_t bytes = lds_words(rows, A.loss_log ? max_views : 0) * sizeof(float);
     if (bytes > 160 * 1024) return odam_fail(ODAM_E_LIMIT, "odam_sq: LDS budget exceeded (loss logging with this many views)");
-    hipLaunchKernelGGL(sq_fit_kernel, dim3(grid), dim3(NT), bytes, stream, A);
+    // More workgroups than CUs (no view split then: one workgroup per object) and two of them fit a CU's LDS: eight-wave workgroups, two per
+    // CU, so that one's latency-bound phases (sampler chain, row tree, Adam) run under the other's vector-bound extent scan (odam_config
+    // sq.two_per_cu; same bits: nothing of a step depends on the workgroup size).
+    const bool two = NT_MAX == 1024 && odam_cfg::get(odam_cfg::SQ_TWO_PER_CU) != 0 && A.split == 1 && grid > ctx->n_cu && 2 * bytes <= 160 * 1024;
+    if (two) hipLaunchKernelGGL(sq_fit_kernel<512>, dim3(grid), dim3(512), bytes, stream, A);
+    else hipLaunchKernelGGL(sq_fit_kernel<NT_MAX>, dim3(grid), dim3(NT_MAX), bytes, stream, A);
     ODAM_HIP(hipGetLastError());
     return ODAM_OK;
 }

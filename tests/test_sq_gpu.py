@@ -232,3 +232,30 @@ def test_view_split_is_bit_identical_on_every_path():
         assert out.returncode == 0, out.stderr[-2000:]
         digests[name] = [l for l in out.stdout.splitlines() if l.startswith("digest")][0]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_two_workgroups_per_cu_give_the_same_bits():
+    """odam_config sq.two_per_cu: a launch of more workgroups than CUs (one per object) as 512-thread workgroups, two per CU, against the
+    1024-thread form -- every parameter of every object bit for bit (nothing of a step depends on the workgroup size: phases are strided loops,
+    the reductions have fixed shapes); 300 objects of 10 ... 70 views, 40 steps.  (The LDS regions the two forms share -- phase B2's queues
+    with points / gradient rows -- are exercised by every fit of this file.)"""
+    import torch
+    from odam_amd import _lib, sq, synth
+    probs = [synth.make_sq_problem(10 + (i * 7) % 61, 900 + i % 40) for i in range(300)]
+    p0 = np.stack([sq.init_params(p["translate"], p["angle"], p["dims"]) for p in probs])
+    p0[:, 1] += np.linspace(0, 0.03, len(probs)).astype(np.float32)
+    tm = [sq.lines_to_targets(p["bbox_lines"]) for p in probs]
+    P = np.concatenate([p["P"].astype(np.float32).reshape(-1, 12) for p in probs])
+    tgt = np.concatenate([t for t, _ in tm]); mask = np.concatenate([m for _, m in tm])
+    vc = [len(p["P"]) for p in probs]; cls = [p["class_id"] for p in probs]
+    f = sq.SqFitter("cuda:0", 40)
+    outs = {}
+    old = _lib.get_config("sq.two_per_cu")
+    try:
+        for mode in (0, 1):
+            _lib.set_config("sq.two_per_cu", mode)
+            outs[mode] = f.fit(p0, cls, vc, P, tgt, mask, n_iters=40)["params"].cpu().numpy()
+    finally:
+        _lib.set_config("sq.two_per_cu", old)
+    assert np.isfinite(outs[0]).all() and not np.array_equal(outs[0], p0)
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
