@@ -11,7 +11,8 @@
  * (0 = OK, otherwise an ODAM_E_* value; odam_last_error() returns a static message), caller-owned
  * buffers, work is enqueued on the caller's hipStream_t (passed as void*).  All scratch lives in the handle: the
  * *_batch calls neither synchronise nor allocate, except that odam_sq_fit_batch grows the handle's exchange
- * buffer (hipMalloc) the first time a larger problem is seen.  A handle serves one launch at a time (use one
+ * buffer (hipMalloc) the first time a larger problem is seen and, for a call with more objects than the device has CUs, reads the
+ * view counts back (one small copy and a synchronisation of the caller's stream) to fit the objects longest first.  A handle serves one launch at a time (use one
  * per stream / thread).
  * Pointers marked [dev] are device pointers, [host] host pointers.
  */

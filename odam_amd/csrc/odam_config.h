@@ -44,8 +44,9 @@ enum Key {
                     // function of the weights, not the same roundings (differences of ~1e-7 relative in the layer's hidden row).  Read when a
                     // handle is finalised.  Default 1: every reference-run fixture holds in both forms (assignment probabilities within 2e-4, identical
                     // decisions through the whole chain), the association loop is 0.045 ms per frame shorter (0.59 -> 0.54 at 42 tracks)
-    SQ_TWO_PER_CU,  // super-quadric fit: a launch of more workgroups than CUs (one per object, no view split) runs as 512-thread workgroups, two per
-                    // CU, where their LDS allows (<= 433 views per object).  Same bits; 500 x 256: 29 -> 24 ms per launch, 300 x 128 -17 %.  Default 1
+    SQ_TWO_PER_CU,  // super-quadric fit, launches of more objects than CUs (one workgroup per object, no view split): 1 (default) = read the view counts
+                    // back and either fit the objects longest first (unequal view counts: the launch ends with the last long object) or, for about
+                    // equal ones, run 512-thread workgroups two per CU (500 x 256: 29 -> 24 ms per launch, 300 x 128 -17 %).  Same bits.  0 = neither
     N_KEYS
 };
 int get(Key k);

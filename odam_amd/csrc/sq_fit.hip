@@ -27,6 +27,7 @@
 // correctly rounded forms, hipcc's default).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -83,6 +84,7 @@ struct FitArgs {
     unsigned* done;                   // [n_obj][split]: steps published by each workgroup, zeroed before launch
     int force_lanes_per_view;         // 0 = choose (experiments: ODAM_SQ_S)
     unsigned split_wait_ticks;        // bounded wait for a partner's rows, 100 MHz wall clock (30 us: > one slice of phase E)
+    const int* order;                 // launches of more workgroups than CUs (no view split): workgroup b fits object order[b] -- longest first; or null
 };
 
 struct Lds {
@@ -120,19 +122,21 @@ struct Lds {
     float* lterm;   // [views][4], only when the loss is logged
 };
 
-// The breadth-first queues of phase B2 (q: 8000 words) are dead from the end of B2 to the next step's B2; the surface points, their buffer
-// indices, the per-view gradient rows and the loss terms live from phase D to phase F.  The two sets share one region (round 6): 97 KB -> 81 KB
-// at <= 433 rows, which is what lets two 512-thread workgroups share a CU's 160 KB.
-__host__ __device__ inline size_t lds_shared_region_words(int rows, int loss_rows) {
-    const size_t q = (size_t)2 * 2 * QCAP * 10, pts = 3 * 1024 + 1024 + (size_t)rows * 9 + (size_t)loss_rows * 4;
-    return q > pts ? q : pts;
-}
+// LDS regions with disjoint lifetimes share their words (round 6: 97 KB + 36 B per view -> 81 KB for any view count, which is what lets two
+// 512-thread workgroups share a CU's 160 KB):
+//   * the breadth-first queues of phase B2 (q: 8000 words; dead from the end of B2 to the next step's B2) | the surface points and their
+//     buffer indices (4096 words; phase D to phase E);
+//   * the dyadic tables of phases B1 / B2 / C (theta, curve points, per-entry factors, split ratios, slot origins: 9240 words; dead after
+//     phase C) | the per-view gradient rows and the loss terms (9 words per row + 4 per logged view; phase E to phase F).
+constexpr size_t LDS_TABLE_WORDS = 3 * 2 * 520 + 4 * 2 * 520 + 520 + 2 * 512 + 2 * BUFP;      // tth tcx tcy | tct tst tfc tfs | tfx | rtab | bufq
+constexpr size_t LDS_QUEUE_WORDS = (size_t)2 * 2 * QCAP * 10;
+static_assert(LDS_QUEUE_WORDS >= 3 * 1024 + 1024, "points + indices fit the queue region");
 __host__ __device__ inline size_t lds_words(int rows, int loss_rows) {
-    return 12 * 6 + 8 + 8 + 32 + 288 + 2 * BUFP + 2 * BUFP + 8 * BUFP + 3 * 2 * 520 +
-           4 * 2 * 520 + 520 + 2 * 512 + 2 * BUFP + lds_shared_region_words(rows, loss_rows);
+    const size_t grad = (size_t)rows * 9 + (size_t)loss_rows * 4;
+    return 12 * 6 + 8 + 8 + 32 + 288 + 2 * BUFP + 2 * BUFP + 8 * BUFP + (grad > LDS_TABLE_WORDS ? grad : LDS_TABLE_WORDS) + LDS_QUEUE_WORDS;
 }
 
-__device__ inline Lds carve(float* base, int pn) {
+__device__ inline Lds carve(float* base, int pn, int loss_rows) {
     Lds L;
     float* w = base;
     L.p = w; w += 12;
@@ -149,6 +153,10 @@ __device__ inline Lds carve(float* base, int pn) {
     L.cdf = w; w += BUFP;
     L.term = w; w += BUFP;
     L.fac = w; w += 8 * BUFP;
+    // tables (phases B1 .. C) | gradient rows + loss terms (phases E, F)
+    float* tables = w;
+    L.vgrad = w;
+    L.lterm = w + (size_t)pn * 9;
     L.tth = w; w += 2 * 520;
     L.tcx = w; w += 2 * 520;
     L.tcy = w; w += 2 * 520;
@@ -159,15 +167,15 @@ __device__ inline Lds carve(float* base, int pn) {
     L.tfx = w; w += 520;
     L.rtab = w; w += 2 * 512;
     L.bufq = (int*)w; w += 2 * BUFP;
-    // the shared region (lds_shared_region_words): phase B2's queues, or -- from phase D on -- points | indices | gradient rows | loss terms
+    const size_t grad = (size_t)pn * 9 + (size_t)loss_rows * 4;
+    w = tables + (grad > LDS_TABLE_WORDS ? grad : LDS_TABLE_WORDS);
+    // phase B2's queues | points + indices (phases D, E)
     L.q = (QArc*)w;
     L.pwx = w; w += 1024;
     L.pwy = w; w += 1024;
     L.pwz = w; w += 1024;
     L.ie = (unsigned short*)w; w += 512;
     L.io = (unsigned short*)w; w += 512;
-    L.vgrad = w; w += (size_t)pn * 9;
-    L.lterm = w;
     return L;
 }
 
@@ -208,8 +216,10 @@ __global__ __launch_bounds__(NT, 4) void sq_fit_kernel(FitArgs A) {      // (sec
         wj = slot % A.split;
         obj = (slot / A.split) * 8 + xcd;
         if (obj >= A.n_obj) return;
+    } else if (A.order) {
+        obj = A.order[blockIdx.x];
     }
-    Lds L = carve(smem, A.pn_views);
+    Lds L = carve(smem, A.pn_views, A.loss_log ? A.max_views : 0);
 
     int v0 = 0, F = 0;
     if (A.view_offsets) {
@@ -880,6 +890,9 @@ struct odam_sq_ctx {
     float* d_proj_pts = nullptr;
     size_t proj_pts_n = 0;
     double* d_cam = nullptr;      // (unused: the camera travels in the kernel arguments)
+    // launches of more objects than CUs: the objects longest first (grow-only)
+    int* d_order = nullptr;
+    size_t order_n = 0;
 };
 
 static std::vector<float> sampler_draws() {
@@ -948,6 +961,7 @@ extern "C" int odam_sq_destroy(odam_sq_ctx* c) {
     (void)hipFree(c->d_adam);
     if (c->d_xch) (void)hipFree(c->d_xch);
     if (c->d_done) (void)hipFree(c->d_done);
+    if (c->d_order) (void)hipFree(c->d_order);
     delete c;
     return ODAM_OK;
 }
@@ -1006,10 +1020,39 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
     A.pn_views = rows;
     const size_t bytes = lds_words(rows, A.loss_log ? max_views : 0) * sizeof(float);
     if (bytes > 160 * 1024) return odam_fail(ODAM_E_LIMIT, "odam_sq: LDS budget exceeded (loss logging with this many views)");
-    // More workgroups than CUs (no view split then: one workgroup per object) and two of them fit a CU's LDS: eight-wave workgroups, two per
-    // CU, so that one's latency-bound phases (sampler chain, row tree, Adam) run under the other's vector-bound extent scan (odam_config
-    // sq.two_per_cu; same bits: nothing of a step depends on the workgroup size).
-    const bool two = NT_MAX == 1024 && odam_cfg::get(odam_cfg::SQ_TWO_PER_CU) != 0 && A.split == 1 && grid > ctx->n_cu && 2 * bytes <= 160 * 1024;
+    // More workgroups than CUs (no view split then: one workgroup per object).  Two things decide how long such a launch takes, and both
+    // need the view counts, which live on the device: the one small read-back + stream synchronisation below is paid by these launches only
+    // (tens of milliseconds each).
+    //   * objects of very different view counts (a real scene: 10 ... 300): the launch ends when the last LONG object does -- a 300-view
+    //     object that happens to start in the second round finishes 15 ms after everything else.  Workgroup b therefore fits object
+    //     order[b], longest first (500 objects of 10 ... 300 views: 29.3 -> see profiles/r6_sq_two_per_cu.txt);
+    //   * objects of about equal view counts: eight-wave workgroups, two per CU, so that one's latency-bound phases (sampler chain, row
+    //     tree, Adam) run under the other's vector-bound extent scan (500 x 256: 29 -> 24 ms).  With unequal objects this form LOSES (a
+    //     long object alone on its CU's half of the lanes is the last to finish: 29.3 -> 32.4 ms), hence the test on max / mean.
+    // Same bits either way: nothing of an object's fit depends on its workgroup's id or size.  81 KB per workgroup up to 1026 rows (lds_words).
+    A.order = nullptr;
+    bool uniform = false;
+    if (A.split == 1 && grid > ctx->n_cu && A.view_offsets && A.n_iters > 0 && odam_cfg::get(odam_cfg::SQ_TWO_PER_CU) != 0) {
+        std::vector<int> off((size_t)n_obj + 1);
+        ODAM_HIP(hipMemcpyAsync(off.data(), A.view_offsets, sizeof(int) * ((size_t)n_obj + 1), hipMemcpyDeviceToHost, stream));
+        ODAM_HIP(hipStreamSynchronize(stream));
+        long total = 0; int mx = 0;
+        for (int i = 0; i < n_obj; i++) { const int v = off[i + 1] - off[i]; total += v; if (v > mx) mx = v; }
+        uniform = (double)mx * n_obj <= 1.25 * (double)total;
+        if (!uniform) {
+            std::vector<int> ord((size_t)n_obj);
+            for (int i = 0; i < n_obj; i++) ord[i] = i;
+            std::stable_sort(ord.begin(), ord.end(), [&](int a_, int b_) { return off[a_ + 1] - off[a_] > off[b_ + 1] - off[b_]; });
+            if ((size_t)n_obj > ctx->order_n) {
+                if (ctx->d_order) { (void)hipFree(ctx->d_order); ctx->d_order = nullptr; ctx->order_n = 0; }      // (the stream was synchronised above)
+                ODAM_HIP(hipMalloc(&ctx->d_order, sizeof(int) * (size_t)n_obj));
+                ctx->order_n = (size_t)n_obj;
+            }
+            ODAM_HIP(hipMemcpy(ctx->d_order, ord.data(), sizeof(int) * (size_t)n_obj, hipMemcpyHostToDevice));      // synchronous: ord is a local
+            A.order = ctx->d_order;
+        }
+    }
+    const bool two = NT_MAX == 1024 && uniform && 2 * bytes <= 160 * 1024;
     if (two) hipLaunchKernelGGL(sq_fit_kernel<512>, dim3(grid), dim3(512), bytes, stream, A);
     else hipLaunchKernelGGL(sq_fit_kernel<NT_MAX>, dim3(grid), dim3(NT_MAX), bytes, stream, A);
     ODAM_HIP(hipGetLastError());

@@ -7,9 +7,15 @@ import numpy as np, torch
 from odam_amd import _lib, sq, synth
 n_obj = int(sys.argv[1]) if len(sys.argv) > 1 else 500
 views = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+mixed = len(sys.argv) > 3 and sys.argv[3] == "mixed"      # view counts spread over 10 ... views (a real scene) instead of all equal
 f = sq.SqFitter("cuda:0", 200)
-base = [synth.make_sq_problem(views, s) for s in range(min(n_obj, 64))]
-probs = [base[i % len(base)] for i in range(n_obj)]
+rs = np.random.RandomState(3)
+vlist = [int(v) for v in (rs.randint(10, views + 1, n_obj) if mixed else [views] * n_obj)]
+cache = {}
+def prob(v, s):
+    if (v, s) not in cache: cache[(v, s)] = synth.make_sq_problem(v, s)
+    return cache[(v, s)]
+probs = [prob(vlist[i], i % 16) for i in range(n_obj)]
 p0 = np.stack([sq.init_params(p["translate"], p["angle"], p["dims"]) for p in probs])
 p0[:, 0] += np.linspace(0, 0.05, n_obj).astype(np.float32)          # not 500 copies of 64 problems
 tm = [sq.lines_to_targets(p["bbox_lines"]) for p in probs]
@@ -22,10 +28,10 @@ for rep in range(4):
         _lib.set_config("sq.two_per_cu", mode)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        e0.record(); r = f.fit(p0, cls, [views] * n_obj, P, tgt, mask); e1.record()
+        e0.record(); r = f.fit(p0, cls, vlist, P, tgt, mask); e1.record()
         torch.cuda.synchronize()
         ms[mode].append(e0.elapsed_time(e1))
         out[mode] = r["params"].cpu().numpy()
 _lib.set_config("sq.two_per_cu", 0)
-print("%d objects x %d views, 200 steps: one 1024-thread workgroup per CU %s ms | two 512-thread workgroups per CU %s ms | same bits: %s" % (
-    n_obj, views, " ".join("%.2f" % m for m in ms[0]), " ".join("%.2f" % m for m in ms[1]), np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))))
+print("%d objects x %s views, 200 steps: sq.two_per_cu = 0 (1024 threads, object b on workgroup b) %s ms | = 1 (%s) %s ms | same bits: %s" % (
+    n_obj, ("10 ... %d" % views) if mixed else str(views), " ".join("%.2f" % m for m in ms[0]), "longest first" if mixed else "two 512-thread workgroups per CU", " ".join("%.2f" % m for m in ms[1]), np.array_equal(out[0].view(np.uint32), out[1].view(np.uint32))))

@@ -234,14 +234,18 @@ def test_view_split_is_bit_identical_on_every_path():
     assert len(set(digests.values())) == 1, digests
 
 
-def test_two_workgroups_per_cu_give_the_same_bits():
-    """odam_config sq.two_per_cu: a launch of more workgroups than CUs (one per object) as 512-thread workgroups, two per CU, against the
-    1024-thread form -- every parameter of every object bit for bit (nothing of a step depends on the workgroup size: phases are strided loops,
-    the reductions have fixed shapes); 300 objects of 10 ... 70 views, 40 steps.  (The LDS regions the two forms share -- phase B2's queues
-    with points / gradient rows -- are exercised by every fit of this file.)"""
+@pytest.mark.parametrize("kind", ["equal view counts: two 512-thread workgroups per CU", "unequal view counts: longest object first"])
+def test_oversubscribed_launch_forms_give_the_same_bits(kind):
+    """odam_config sq.two_per_cu on a launch of more objects than CUs (one workgroup per object): objects of about equal view counts run as
+    512-thread workgroups, two per CU; objects of unequal view counts are fitted longest first (workgroup b takes object order[b]).  Either way
+    every parameter of every object equals the plain form's (1024 threads, object b on workgroup b) bit for bit -- nothing of a fit depends on
+    its workgroup's id or size: phases are strided loops, the reductions have fixed shapes.  300 objects, 40 steps.  (The LDS regions that
+    share their words since round 6 -- phase B2's queues with the surface points, the dyadic tables with the gradient rows -- are exercised by
+    every fit of this file.)"""
     import torch
     from odam_amd import _lib, sq, synth
-    probs = [synth.make_sq_problem(10 + (i * 7) % 61, 900 + i % 40) for i in range(300)]
+    equal = kind.startswith("equal")
+    probs = [synth.make_sq_problem(24 if equal else 10 + (i * 7) % 61, 900 + i % 40) for i in range(300)]
     p0 = np.stack([sq.init_params(p["translate"], p["angle"], p["dims"]) for p in probs])
     p0[:, 1] += np.linspace(0, 0.03, len(probs)).astype(np.float32)
     tm = [sq.lines_to_targets(p["bbox_lines"]) for p in probs]
