@@ -499,8 +499,8 @@ def main():
                 "frac_at_configs4_size": ({"value": sq5.get("valu_issue_frac"), "valu_insts_per_launch": sq5.get("valu_insts_per_launch"),
                                            "note": sq5.get("source")} if sq5 else None),
                 "per_wave_view": {"valu_util": sqp.get("valu_util"), "wait_frac": sqp.get("wait_frac"),
-                                  "note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES and SQ_WAIT_ANY / SQ_WAVE_CYCLES: per RESIDENT WAVE (four per SIMD "
-                                          "here), so 0.25 would be a SIMD that never idles -- the figure earlier rounds quoted as `frac`"},
+                                  "note": "SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES and SQ_WAIT_ANY / SQ_WAVE_CYCLES: shares of RESIDENT-WAVE time (four waves "
+                                          "to a SIMD here), not of the SIMDs' issue slots -- the figure earlier rounds quoted as `frac`"},
                 "frac_from_profiles": sqp.get("source"),
                 "objects": len(views), "max_views": max(views), "ms_per_launch": sq_ms, "us_per_adam_step": 1e3 * sq_ms / 200,
                 "hbm_secondary": {"achieved": alg / (sq_ms * 1e-3) / 1e9, "peak": PEAK_HBM / 1e9, "unit": "GB/s",
