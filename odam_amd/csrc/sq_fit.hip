@@ -892,6 +892,7 @@ struct odam_sq_ctx {
     double* d_cam = nullptr;      // (unused: the camera travels in the kernel arguments)
     // launches of more objects than CUs: the objects longest first (grow-only)
     int* d_order = nullptr;
+    int* h_order = nullptr;       // pinned staging of the same size (the upload is stream-ordered: no NULL-stream copy that would wait for other streams)
     size_t order_n = 0;
 };
 
@@ -962,6 +963,7 @@ extern "C" int odam_sq_destroy(odam_sq_ctx* c) {
     if (c->d_xch) (void)hipFree(c->d_xch);
     if (c->d_done) (void)hipFree(c->d_done);
     if (c->d_order) (void)hipFree(c->d_order);
+    if (c->h_order) (void)hipHostFree(c->h_order);
     delete c;
     return ODAM_OK;
 }
@@ -1044,11 +1046,16 @@ static int launch_fit(odam_sq_ctx* ctx, int n_obj, FitArgs& A, int max_views, hi
             for (int i = 0; i < n_obj; i++) ord[i] = i;
             std::stable_sort(ord.begin(), ord.end(), [&](int a_, int b_) { return off[a_ + 1] - off[a_] > off[b_ + 1] - off[b_]; });
             if ((size_t)n_obj > ctx->order_n) {
-                if (ctx->d_order) { (void)hipFree(ctx->d_order); ctx->d_order = nullptr; ctx->order_n = 0; }      // (the stream was synchronised above)
+                if (ctx->d_order) { (void)hipFree(ctx->d_order); ctx->d_order = nullptr; }      // (the stream was synchronised above: nothing reads them)
+                if (ctx->h_order) { (void)hipHostFree(ctx->h_order); ctx->h_order = nullptr; }
+                ctx->order_n = 0;
                 ODAM_HIP(hipMalloc(&ctx->d_order, sizeof(int) * (size_t)n_obj));
+                ODAM_HIP(hipHostMalloc((void**)&ctx->h_order, sizeof(int) * (size_t)n_obj, hipHostMallocDefault));
                 ctx->order_n = (size_t)n_obj;
             }
-            ODAM_HIP(hipMemcpy(ctx->d_order, ord.data(), sizeof(int) * (size_t)n_obj, hipMemcpyHostToDevice));      // synchronous: ord is a local
+            // (the pinned staging is free: the previous launch that read d_order finished before the synchronisation above)
+            std::memcpy(ctx->h_order, ord.data(), sizeof(int) * (size_t)n_obj);
+            ODAM_HIP(hipMemcpyAsync(ctx->d_order, ctx->h_order, sizeof(int) * (size_t)n_obj, hipMemcpyHostToDevice, stream));
             A.order = ctx->d_order;
         }
     }
