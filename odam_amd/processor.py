@@ -435,12 +435,14 @@ class OdamProcess:
     def _fast_ok(self):
         """process_frames' fast path applies: the associator and the fitter are this package's (native track store, odam_assoc_step),
         no shape codes, one device, the Hungarian step on the host (scipy, the default)"""
-        a, f = self.associator, self._fitter()
-        if not (self.no_code and getattr(a, "native_windows", False) and hasattr(a, "step_launch") and hasattr(f, "build_track_windows")
-                and hasattr(f, "_h") and self._tracks is not None):
-            return False
+        a = self.associator
+        if not (self.no_code and getattr(a, "native_windows", False) and hasattr(a, "step_launch") and self._tracks is not None):
+            return False      # (decided before the fitter is touched: a caller with its own associator may have no GPU fitter at all)
         if "assignment" in vars(a) or "_attach_to_tracks" in vars(self) or "_prepare_tracks" in vars(self):
             return False      # somebody hooked a step of the per-frame path on this object (tests do): keep the steps separate
+        f = self._fitter()
+        if not (hasattr(f, "build_track_windows") and hasattr(f, "_h")):
+            return False
         from . import _lib
         if _lib.get_config("assoc.hungarian"):
             return False
