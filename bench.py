@@ -171,7 +171,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--objects", type=int, default=30)
-    ap.add_argument("--batch", type=int, default=0, help="frames per forward; 0 = by shard size")
+    ap.add_argument("--batch", type=int, default=0, help="frames per forward; 0 = by the number of frames a call covers (Detector.batch_for: 42 up to 300 "
+                    "frames, 38 beyond)")
     ap.add_argument("--streams", type=int, default=0, help="concurrent HIP streams; 0 = by shard size")
     ap.add_argument("--chunk", type=int, default=0, help="frames per device->host copy of detections; 0 = 4 batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -204,6 +205,7 @@ def main():
     ap.add_argument("--no-pin", action="store_true", help="leave odam_config cg.pin at 0 (kernel choice by problem size: a rank's result then "
                     "depends on its shard size at the 1e-5 level and an N-rank line is not bit-comparable with the one-rank line)")
     args = ap.parse_args()
+    args.batch_given = args.batch > 0
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.one_device))
@@ -253,15 +255,19 @@ def main():
     img_size = (synth.IMG_W, synth.IMG_H)
 
     n_local = f1 - f0
+    BATCH = args.batch if args.batch > 0 else "auto"      # what every detect_resident_chunks call of this run is given
     if args.batch <= 0:
-        args.batch = 32   # best at every shard size measured (125 ... 1000 frames, tests/native/sweep_shard.sh)
+        # by the number of frames a call covers (round 6, cg.pin = 1, tests/native/sweep_shard_batch.sh: a 125-frame shard in three equal
+        # batches of 42 -- one per stream -- 135 ms against 141 with 32 + 32 + 32 + 29; 1000 frames: 38 per forward, +0.6 % over 32)
+        args.batch = det_mod.Detector.batch_for(n_local)
     if args.streams <= 0:
         # the ring kernels hold a CU's whole LDS, so streams mix at workgroup granularity: with three, more CUs are in different
         # phases of different layers at any moment (tests/native/sweep_streams.sh, same box: 2 / 3 / 4 streams = 1006 / 1020 /
         # 1004 frames/s; configs[3]: 1856 / 1932 / 1935)
         args.streams = 3
     args.chunk = args.chunk or 4 * args.batch
-    detector = det_mod.Detector(max_batch=args.batch, device=device, n_streams=args.streams)
+    detector = det_mod.Detector(max_batch=max(args.batch, 42) if BATCH == "auto" else args.batch, device=device, n_streams=args.streams)
+    detector.bench_batch = BATCH
     # scene weights: calibrated batch-norm statistics + centred heads -> 10-25 detections per frame after NMS, so the
     # host side of the step (threshold, NMS, row packing) runs at the load a trained detector gives it
     detector.load_state_dict(weights.make_state_dict(seed=0, scene=True))
@@ -294,7 +300,7 @@ def main():
         per_frame = []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for c0, rows16 in detector.detect_resident_chunks(src, img_size, K, chunk=args.chunk):
+        for c0, rows16 in detector.detect_resident_chunks(src, img_size, K, chunk=args.chunk, batch=BATCH):
             for i in range(rows16.shape[0]):   # host: threshold + NMS + 79-column rows, overlapped with the GPU
                 sel = detector.select(rows16[i], 0.6, True, 30)
                 objs = {k: [v] for k, v in sel.items()}
@@ -366,7 +372,7 @@ def main():
 
     # stage split (informational): one more untimed scene with explicit timers
     torch.cuda.synchronize(); s0 = time.perf_counter()
-    for _ in detector.detect_resident_chunks(frames, img_size, K, chunk=args.chunk):
+    for _ in detector.detect_resident_chunks(frames, img_size, K, chunk=args.chunk, batch=BATCH):
         pass
     torch.cuda.synchronize(); t_det = time.perf_counter() - s0
 
@@ -399,7 +405,8 @@ def main():
                 "for the SQ fit)",
         "config": {"workload": f"one scene: {N} frames 640x480 -> 800x1066, DETR-R50 detect + 2 passes of "
                                f"200-step SQ fit over {len(tracks)} objects (10-300 views), fp32",
-                   "frames": N, "objects": len(tracks), "detector_batch": args.batch, "detector_streams": args.streams,
+                   "frames": N, "objects": len(tracks), "detector_batch": args.batch, "detector_batch_rule": ("--batch" if args.batch_given else "Detector.batch_for(frames of a call): 42 up to 300 frames, 38 beyond"),
+                   "detector_streams": args.streams,
                    "parallelism": f"frames and objects sharded over {ws} GPU(s)" + (", RCCL all-gather" if ws > 1 else "") +
                                   (" through odam_allgather_detections (include/odam_comm.h)" if args.native_collectives and ws > 1 else "")},
         "library_config": _lib.config(),      # every kernel-selecting switch in force (include/odam_config.h); defaults unless ODAM_CONFIG says otherwise
@@ -588,7 +595,8 @@ def full_chain_block(detector, frames, f0, scene, device, coll_dev, args, rank, 
 
     def detect(a, b):
         rows = []
-        for c0, rows16 in detector.detect_resident_chunks(frames[a - f0:b - f0], img_size, synth.K_SCANNET, chunk=args.chunk):
+        for c0, rows16 in detector.detect_resident_chunks(frames[a - f0:b - f0], img_size, synth.K_SCANNET, chunk=args.chunk,
+                                                          batch=(args.batch if args.batch_given else "auto")):
             for i in range(rows16.shape[0]):
                 sel = detector.select(rows16[i], 0.6, True, 30)
                 rows.append(detection_array({k: [v] for k, v in sel.items()}, 0, ids[a + c0 + i], synth.IMG_W, synth.IMG_H))
@@ -709,7 +717,8 @@ def association_overlapped(detector, frames, chunk, scene, device, N, fit_ms):
     th = threading.Thread(target=worker)
     torch.cuda.synchronize(); s0 = time.perf_counter()
     th.start()
-    for c0, rows16 in detector.detect_resident_chunks(frames, (synth.IMG_W, synth.IMG_H), synth.K_SCANNET, chunk=chunk):
+    for c0, rows16 in detector.detect_resident_chunks(frames, (synth.IMG_W, synth.IMG_H), synth.K_SCANNET, chunk=chunk,
+                                                      batch=getattr(detector, "bench_batch", None)):
         rows = []
         for i in range(rows16.shape[0]):
             sel = detector.select(rows16[i], 0.6, True, 30)

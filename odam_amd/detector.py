@@ -338,7 +338,15 @@ class Detector:
             out[c0:c0 + rows.shape[0]] = rows
         return out
 
-    def detect_resident_chunks(self, frames, img_size, intr_mat, chunk=128):
+    @staticmethod
+    def batch_for(n_frames):
+        """frames per forward for a call over n_frames on three streams (bench.py --batch 0): measured on one box with cg.pin = 1
+        (tests/native/sweep_shard_batch.sh, profiles/r6_shard_batch_sweep.txt) -- 125 frames: 42 per forward (three equal batches, one per
+        stream) 135 ms against 141 with 32 (32 + 32 + 32 + 29: the fourth runs alone); 250: 42; 500 and 1000: 38 (whole rounds of 256 tiles in
+        layer3 / layer4; 0.6-1.8 % over 32)"""
+        return 42 if n_frames <= 300 else 38
+
+    def detect_resident_chunks(self, frames, img_size, intr_mat, chunk=128, batch=None):
         """Forward + per-query post-processing over frames resident in HBM -- or, when `frames` is a (pinned) host
         tensor, uploaded batch by batch on a copy stream into two staging buffers per compute stream, so the
         PCIe transfer of batch n+1 runs under the kernels of batch n -- where (1) batches alternate between `n_streams` HIP streams, each with its own
@@ -347,7 +355,8 @@ class Detector:
         GPU keeps working: everything is enqueued first (forward + post-processing per batch, then per chunk an
         asynchronous copy into pinned host memory + an event), and the generator yields
         (first_frame, rows[n,Q,16]) as each chunk's event completes -- host-side thresholding / NMS of chunk i
-        overlaps the kernels of chunks i+1.. ."""
+        overlaps the kernels of chunks i+1.. .
+        batch: frames per forward (<= max_batch, the default); "auto" = batch_for(number of frames)."""
         raw = frames.dtype == torch.uint8     # [N,h,w,3] frames as decoded: the input transform runs on the device
         if raw:
             from .transforms import target_size
@@ -358,10 +367,11 @@ class Detector:
         Q = a["num_queries"]
         dev = self.device
         L = _lib.lib()
-        mb = self.max_batch
+        mb = self.max_batch                                   # what every buffer is sized for
+        bb = mb if not batch else min(mb, self.batch_for(N) if batch == "auto" else int(batch))      # frames per forward of THIS call
         ns = self.n_streams
         handles = [self._handle(H, W, k) for k in range(ns)]
-        chunk = max(mb, (chunk // mb) * mb)
+        chunk = max(bb, (chunk // bb) * bb)
         rows = torch.empty(N, Q, 16, device=dev, dtype=torch.float32)
         if getattr(self, "_pinned", None) is None or self._pinned.shape[0] < N:
             self._pinned = torch.empty(N, Q, 16, dtype=torch.float32, pin_memory=True)
@@ -394,8 +404,8 @@ class Detector:
             for c0 in range(0, N, chunk):
                 c1 = min(N, c0 + chunk)
                 used = set()
-                for b0 in range(c0, c1, mb):
-                    B = min(mb, c1 - b0)
+                for b0 in range(c0, c1, bb):
+                    B = min(bb, c1 - b0)
                     k = nb % ns
                     nb += 1
                     used.add(k)
