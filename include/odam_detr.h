@@ -151,6 +151,11 @@ int odam_op_conv_f32_mode(int mode);
 long long odam_op_pooled_stem_launches(void);
 int odam_op_attention(const float* Q, int ldq, const float* K, int ldk, const float* V, int ldv, float* O, int ldo,
                       int B, int H, int Lq, int Lk, void* stream);
+/* the same op on bf16 tensors (config 4: nn.MultiheadAttention's scaled-dot-product core, src/models/transformer.py:154-167, on
+ * v_mfma_f32_32x32x16_bf16): Q / K / V / O [dev] bf16 with the given row pitches (multiples of 8 / 8 / 8 / 4 elements), head h at columns
+ * 32 h .. 32 h + 31; standalone entry for tests and timing -- the detector calls the same launcher */
+int odam_op_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                           int B, int H, int Lq, int Lk, void* stream);
 int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y, int M,
                           void* stream);
 int odam_op_maxpool3x3s2_nhwc(const float* x, float* y, int B, int H, int W, int C, void* stream);

@@ -206,8 +206,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const T* __restrict__ Q,
 // product; its k order inside a 16-key step is 16 s + 8 (j >> 2) + 4 half + (j & 3), so the A operand (V^T) is read
 // from an LDS image [channel][key] as two 4-key groups per step.  Softmax in fp32 with exp2 (scale * log2 e folded in).
 // LDS: K tile [64 keys][64 B] with the 16-byte chunk c of key r at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128, as
-// in conv_gemm's bf16 kernel); V^T tile [32 channels][64 keys + 4 pad] (136-byte rows: the 32 lanes' 8-byte reads fall
-// on 64 distinct banks).
+// in conv_gemm's bf16 kernel); V tile [64 keys][64 B] row-major, read transposed by ds_read_b64_tr_b16 (see the kernel).
 // =================================================================================================
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
@@ -216,9 +215,14 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
                                                              const bf16_t* __restrict__ V, int ldv,
                                                              bf16_t* __restrict__ O, int ldo, int Lq, int Lk, float c_log2,
                                                              const unsigned char* __restrict__ key_mask) {
-    constexpr int KT = 64, D = 32, VLD = KT + 4;
+    constexpr int KT = 64, D = 32;
     __shared__ __align__(16) uint4 Ks[2][KT * 4];
-    __shared__ __align__(16) unsigned short Vt[2][D][VLD];
+    // V stays row-major in LDS ([key][32 channels], 64-byte rows, as it comes from HBM: one 16-byte store per thread) and reaches the PV
+    // product's A operand (V^T: channel on the lane, four consecutive keys in the register pair) through ds_read_b64_tr_b16 -- the hardware
+    // transpose: a 16-lane group reads a block of 4 keys x 16 channels and lane i receives channel i of the four keys.  (Round 6; until
+    // then every thread wrote its 8 values into a transposed image with 8 two-byte stores per tile.  Same values in the same operand
+    // lanes: bit-identical.)  The 32 lanes of a half read 4 keys x 64 bytes = 256 contiguous bytes: conflict-free without a swizzle.
+    __shared__ __align__(16) uint4 Vs[2][KT * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -246,13 +250,12 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
     };
     auto store_kv = [&](int buf, const uint4& kr, const uint4& vr) {
         Ks[buf][lk * 4 + (lc ^ ((lk >> 2) & 3))] = kr;
-        const unsigned w[4] = {vr.x, vr.y, vr.z, vr.w};
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            Vt[buf][lc * 8 + 2 * e][lk] = (unsigned short)(w[e] & 0xffffu);
-            Vt[buf][lc * 8 + 2 * e + 1][lk] = (unsigned short)(w[e] >> 16);
-        }
+        Vs[buf][lk * 4 + lc] = vr;
     };
+    // transposed read of V: lane 4 q + p of 16-lane group g supplies the address of key row q, channels 4 p .. 4 p + 3 of the group's
+    // channel block (g & 1); the group's half (g >> 1) selects keys 4 half .. of an 8-key step, as the P operand's k order wants them
+    typedef short tr4_t __attribute__((ext_vector_type(4)));
+    const int tr_off = (((lane >> 5) * 4 + ((lane & 15) >> 2)) * 64) + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;      // bytes inside a tile image
 
     floatx16 oacc;
 #pragma unroll
@@ -320,8 +323,11 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
 #pragma unroll
                 for (int e = 0; e < 4; e++)
                     pw[e] = (unsigned)f2bf(s[jh][8 * st + 2 * e]) | ((unsigned)f2bf(s[jh][8 * st + 2 * e + 1]) << 16);
-                const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[cur][col][jh * 32 + 16 * st + 4 * half]);
-                const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[cur][col][jh * 32 + 16 * st + 8 + 4 * half]);
+                typedef tr4_t __attribute__((address_space(3))) * lds_tr_ptr;
+                const char* vb = reinterpret_cast<const char*>(&Vs[cur][0]) + (jh * 32 + 16 * st) * 64 + tr_off;
+                const tr4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vb));               // keys 4 half .. + 3 of the step
+                const tr4_t hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vb + 8 * 64));      // keys 8 + 4 half .. + 3
+                const uint2 lo = __builtin_bit_cast(uint2, lo4), hi = __builtin_bit_cast(uint2, hi4);
                 const uint4 vf = uint4{lo.x, lo.y, hi.x, hi.y};
                 oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, vf),
                                                                __builtin_bit_cast(bf16x8_t, uint4{pw[0], pw[1], pw[2], pw[3]}), oacc, 0, 0, 0);

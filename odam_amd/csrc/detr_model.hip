@@ -854,6 +854,13 @@ extern "C" int odam_op_attention(const float* Q, int ldq, const float* K, int ld
     return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, 0, (hipStream_t)stream);
 }
 
+extern "C" int odam_op_attention_bf16(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O,
+                                      int ldo, int B, int H, int Lq, int Lk, void* stream) {
+    if (!Q || !K || !V || !O) return odam_fail(1, "odam_op_attention_bf16: null pointer");
+    if (ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4) return odam_fail(1, "odam_op_attention_bf16: row pitches must be multiples of 8 / 8 / 8 / 4 elements");
+    return odam_dk::launch_attention(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Lq, Lk, 1, (hipStream_t)stream);
+}
+
 extern "C" int odam_op_add_layernorm(const float* x, const float* r, const float* gamma, const float* beta, float* y,
                                      int M, void* stream) {
     if (!x || !gamma || !beta || !y) return odam_fail(1, "odam_op_add_layernorm: null pointer");
