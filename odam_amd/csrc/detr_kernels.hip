@@ -376,9 +376,9 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
                                                            const float* __restrict__ V, int ldv,
                                                            float* __restrict__ O, int ldo, int Lq, int Lk, float scale,
                                                            const unsigned char* __restrict__ key_mask) {
-    constexpr int KT = 64, D = 32, VLD = KT + 4;
+    constexpr int KT = 64, D = 32;
     __shared__ __align__(16) uint4 Ks[2][3][KT * 4];
-    __shared__ __align__(16) unsigned short Vt[2][3][D][VLD];
+    __shared__ __align__(16) uint4 Vs[2][3][KT * 4];      // V's three planes row-major, read transposed (ds_read_b64_tr_b16) as in attention_bf16_kernel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, col = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -419,15 +419,11 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
         for (int pl = 0; pl < 3; pl++) Ks[buf][pl][lk * 4 + (lc ^ ((lk >> 2) & 3))] = p[pl];
         att_split8(vr[0], vr[1], p[0], p[1], p[2]);
 #pragma unroll
-        for (int pl = 0; pl < 3; pl++) {
-            const unsigned w[4] = {p[pl].x, p[pl].y, p[pl].z, p[pl].w};
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                Vt[buf][pl][lc * 8 + 2 * e][lk] = (unsigned short)(w[e] & 0xffffu);
-                Vt[buf][pl][lc * 8 + 2 * e + 1][lk] = (unsigned short)(w[e] >> 16);
-            }
-        }
+        for (int pl = 0; pl < 3; pl++) Vs[buf][pl][lk * 4 + lc] = p[pl];
     };
+    typedef short tr4_t __attribute__((ext_vector_type(4)));
+    typedef tr4_t __attribute__((address_space(3))) * lds_tr_ptr;
+    const int tr_off = (((lane >> 5) * 4 + ((lane & 15) >> 2)) * 64) + (((lane >> 4) & 1) * 16 + (lane & 3) * 4) * 2;      // see attention_bf16_kernel
 #define ODAM_MMA(acc, a, bq) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, bq), acc, 0, 0, 0)
 
     floatx16 oacc;
@@ -500,8 +496,9 @@ __global__ __launch_bounds__(256) void attention_x3_kernel(const float* __restri
                 uint4 vf[3];
 #pragma unroll
                 for (int pl = 0; pl < 3; pl++) {
-                    const uint2 lo = *reinterpret_cast<const uint2*>(&Vt[cur][pl][col][jh * 32 + 16 * st + 4 * half]);
-                    const uint2 hi = *reinterpret_cast<const uint2*>(&Vt[cur][pl][col][jh * 32 + 16 * st + 8 + 4 * half]);
+                    const char* vb = reinterpret_cast<const char*>(&Vs[cur][pl][0]) + (jh * 32 + 16 * st) * 64 + tr_off;
+                    const uint2 lo = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vb)));
+                    const uint2 hi = __builtin_bit_cast(uint2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vb + 8 * 64)));
                     vf[pl] = uint4{lo.x, lo.y, hi.x, hi.y};
                 }
                 ODAM_MMA(oacc, vf[2], ph); ODAM_MMA(oacc, vf[1], pm); ODAM_MMA(oacc, vf[0], pl_);
