@@ -148,7 +148,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
                 }
             const size_t o = (((size_t)pl_b * a.Hp + py) * a.Wp + px) * a.ldc + c4p * 4;
             if constexpr (BF16) {
-                const unsigned lo = (unsigned)f2bf(m4.x) | ((unsigned)f2bf(m4.y) << 16), hi = (unsigned)f2bf(m4.z) | ((unsigned)f2bf(m4.w) << 16);
+                const unsigned lo = pack_bf16x2(m4.x, m4.y), hi = pack_bf16x2(m4.z, m4.w);
                 *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.C) + o) = uint2{lo, hi};
             } else {
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + o) = m4;

@@ -57,6 +57,13 @@ static __device__ unsigned long long g_tail_stamps[8];
 
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
+// two floats -> one register of two bf16 (lo in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32 -- the scalar form
+// f2bf(lo) | f2bf(hi) << 16 compiles to two conversions, a shift and an or (round 6: four instructions per pair in every bf16 epilogue)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB_VOFF = 0x80000000u;   // >= num_records of every buffer descriptor below: the load returns zeros
@@ -150,7 +157,7 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
                         lo += __builtin_bit_cast(float, rw[c] << 16);
                         hi += __builtin_bit_cast(float, rw[c] & 0xffff0000u);
                         if (a.relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
-                        ow[c] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                        ow[c] = pack_bf16x2(lo, hi);
                     }
                     if (n_ok && m < a.M) *reinterpret_cast<uint4*>(outp + (size_t)m * a.ldc + n) = uint4{ow[0], ow[1], ow[2], ow[3]};
                 }
@@ -230,8 +237,8 @@ __device__ __forceinline__ void epilogue(const ConvGemmArgs& a, floatx16 (&acc)[
                     if (out_f32) {
                         *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.C) + idx) = o;
                     } else {
-                        ushort4 u = {f2bf(o.x), f2bf(o.y), f2bf(o.z), f2bf(o.w)};
-                        *reinterpret_cast<ushort4*>(reinterpret_cast<unsigned short*>(a.C) + idx) = u;
+                        const uint2 u = uint2{pack_bf16x2(o.x, o.y), pack_bf16x2(o.z, o.w)};
+                        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a.C) + idx) = u;
                     }
                 }
             }
@@ -356,7 +363,7 @@ __device__ __forceinline__ void epilogue2(const ConvGemmArgs& a, floatx16 (&acc)
                     lo += __builtin_bit_cast(float, rw[c] << 16);
                     hi += __builtin_bit_cast(float, rw[c] & 0xffff0000u);
                     lo = act(lo); hi = act(hi);
-                    ow[c] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                    ow[c] = pack_bf16x2(lo, hi);
                 }
                 __builtin_amdgcn_raw_buffer_store_b128(ow, out_rs, voff(i, it), 0, 0);
             } else {

@@ -163,7 +163,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
                 lo += __builtin_bit_cast(float, rw[c] << 16);
                 hi += __builtin_bit_cast(float, rw[c] & 0xffff0000u);
                 if (a.F_relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
-                ow[c] = (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+                ow[c] = pack_bf16x2(lo, hi);
             }
             const u32x4 o = u32x4{ow[0], ow[1], ow[2], ow[3]};
             __builtin_amdgcn_raw_buffer_store_b128(o, out_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 128), 0, 0);
@@ -213,8 +213,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
                 const int m = m_base + row;
                 const float4 v0 = *reinterpret_cast<const float4*>(&slab[row * 64 + (((2 * c8) ^ (row & 15)) << 2)]);
                 const float4 v1 = *reinterpret_cast<const float4*>(&slab[row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2)]);
-                const u32x4 o = u32x4{(unsigned)f2bf(v0.x) | ((unsigned)f2bf(v0.y) << 16), (unsigned)f2bf(v0.z) | ((unsigned)f2bf(v0.w) << 16),
-                                      (unsigned)f2bf(v1.x) | ((unsigned)f2bf(v1.y) << 16), (unsigned)f2bf(v1.z) | ((unsigned)f2bf(v1.w) << 16)};
+                const u32x4 o = u32x4{pack_bf16x2(v0.x, v0.y), pack_bf16x2(v0.z, v0.w), pack_bf16x2(v1.x, v1.y), pack_bf16x2(v1.z, v1.w)};
                 __builtin_amdgcn_raw_buffer_store_b128(o, g_rs, m < a.M ? (unsigned)((size_t)m * PN * 2 + h * 128 + c8 * 16) : OOB_VOFF, 0, 0);
             }
         }

@@ -13,6 +13,13 @@ typedef unsigned short bf16_t;   // raw bfloat16 bits (bf16 mode: activations in
 
 __device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two floats -> one register of two bf16 (lo in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32 (the scalar casts of
+// f2bf(lo) | f2bf(hi) << 16 compile to two conversions, a shift and an or)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{lo, hi}, bf16x2_t));
+}
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
     const ushort4 u = *reinterpret_cast<const ushort4*>(p);
@@ -20,7 +27,7 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
-    *reinterpret_cast<ushort4*>(p) = ushort4{f2bf(v.x), f2bf(v.y), f2bf(v.z), f2bf(v.w)};
+    *reinterpret_cast<uint2*>(p) = uint2{pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
 }
 #define ODAM_DISPATCH(dtype, KERNEL, ...)                                                  \
     do {                                                                                  \
@@ -322,7 +329,7 @@ __global__ __launch_bounds__(256) void attention_bf16_kernel(const bf16_t* __res
                 unsigned pw[4];
 #pragma unroll
                 for (int e = 0; e < 4; e++)
-                    pw[e] = (unsigned)f2bf(s[jh][8 * st + 2 * e]) | ((unsigned)f2bf(s[jh][8 * st + 2 * e + 1]) << 16);
+                    pw[e] = pack_bf16x2(s[jh][8 * st + 2 * e], s[jh][8 * st + 2 * e + 1]);
                 typedef tr4_t __attribute__((address_space(3))) * lds_tr_ptr;
                 const char* vb = reinterpret_cast<const char*>(&Vs[cur][0]) + (jh * 32 + 16 * st) * 64 + tr_off;
                 const tr4_t lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_ptr)(vb));               // keys 4 half .. + 3 of the step
