@@ -111,6 +111,13 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
+    const __amdgpu_buffer_rsrc_t sc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F_scale), 0, a.F_scale ? 4 * P * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t bi_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F_bias), 0, a.F_bias ? 4 * P * 4 : 0, 0x00020000);
+    const unsigned have_sc = a.F_scale ? 0xffffffffu : 0u, relu_m = a.F_relu ? 0xffffffffu : 0u;
+    auto act = [&](float v) {      // F_relu ? (v > 0 ? v : 0) : v, without a branch
+        const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
+        return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
+    };
     floatx16 acc3[PN ? PN / 32 : 1];
 #pragma unroll
     for (int jc = 0; jc < (PN ? PN / 32 : 1); jc++)
@@ -145,9 +152,20 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
                 slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
         wave_sync();
         const int n = g * 64 + c8 * 8;
+        // scale / bias of the lane's 8 channels: two 16-byte loads each through descriptors that hold no records when the pointer is null
+        // (the load then returns zeros; a missing scale becomes 1 by a select) -- no branch around a load, so the group stays ONE basic block
+        // (round 6: `p ? p[n + c] : 1` per element was 16 scalar loads and 31 branches per group, which also fenced the scheduler in)
         float sc[8], bi[8];
+        {
+            const u32x4 s0 = __builtin_amdgcn_raw_buffer_load_b128(sc_rs, (unsigned)n * 4u, 0, 0), s1 = __builtin_amdgcn_raw_buffer_load_b128(sc_rs, (unsigned)n * 4u + 16u, 0, 0);
+            const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(bi_rs, (unsigned)n * 4u, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(bi_rs, (unsigned)n * 4u + 16u, 0, 0);
+            const unsigned sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int c = 0; c < 8; c++) { sc[c] = a.F_scale ? a.F_scale[n + c] : 1.0f; bi[c] = a.F_bias ? a.F_bias[n + c] : 0.0f; }
+            for (int c = 0; c < 8; c++) {
+                sc[c] = __builtin_bit_cast(float, (sw[c] & have_sc) | (0x3f800000u & ~have_sc));
+                bi[c] = __builtin_bit_cast(float, bw[c]);
+            }
+        }
 #pragma unroll
         for (int it = 0; it < 4; it++) {
             const int row = it * 8 + (lane >> 3);
@@ -162,7 +180,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
                 float lo = v[2 * c] * sc[2 * c] + bi[2 * c], hi = v[2 * c + 1] * sc[2 * c + 1] + bi[2 * c + 1];
                 lo += __builtin_bit_cast(float, rw[c] << 16);
                 hi += __builtin_bit_cast(float, rw[c] & 0xffff0000u);
-                if (a.F_relu) { lo = lo > 0.f ? lo : 0.f; hi = hi > 0.f ? hi : 0.f; }
+                lo = act(lo); hi = act(hi);
                 ow[c] = pack_bf16x2(lo, hi);
             }
             const u32x4 o = u32x4{ow[0], ow[1], ow[2], ow[3]};
