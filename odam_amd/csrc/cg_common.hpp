@@ -382,14 +382,17 @@ __device__ __forceinline__ void epilogue2(const ConvGemmArgs& a, floatx16 (&acc)
 
 // The wave's 32-row accumulator tile as (row, column, value) triples, 64 columns at a time, for either matrix-instruction
 // shape: 32x32 blocks (lane: column l & 31, rows (r & 3) + 8 (r >> 2) + 4 (l >> 5)) or 16x16 blocks (lane: column l & 15,
-// rows 4 (l >> 4) + r).  f(row 0..31, column 0..63 inside the group, channel = 64 h2 + column, value).
+// rows 4 (l >> 4) + r).  f(row 0..31, column 0..63 inside the group, column block j, value): the lane's channel inside
+// block j is the same for every row, so a tail fetches its scale / bias once per block (cols64_affine) -- written as
+// `a.scale ? a.scale[n] : 1` inside f they were re-fetched for EVERY element, each in its own branch with its own wait
+// (the slab stores in between may alias them as far as the compiler knows).
 template <int TN, class F>
 __device__ __forceinline__ void acc_cols64(floatx16 (&acc)[1][TN], int h2, int lane, F&& f) {
     const int half = lane >> 5, l32 = lane & 31;
 #pragma unroll
     for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) f((r & 3) + 8 * (r >> 2) + 4 * half, j * 32 + l32, h2 * 64 + j * 32 + l32, acc[0][2 * h2 + j][r]);
+        for (int r = 0; r < 16; r++) f((r & 3) + 8 * (r >> 2) + 4 * half, j * 32 + l32, j, acc[0][2 * h2 + j][r]);
 }
 template <int NJ, class F>
 __device__ __forceinline__ void acc_cols64(floatx4 (&acc)[2][NJ], int h2, int lane, F&& f) {
@@ -399,7 +402,42 @@ __device__ __forceinline__ void acc_cols64(floatx4 (&acc)[2][NJ], int h2, int la
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) f(mi * 16 + 4 * kq + r, j * 16 + r16, h2 * 64 + j * 16 + r16, acc[mi][4 * h2 + j][r]);
+            for (int r = 0; r < 4; r++) f(mi * 16 + 4 * kq + r, j * 16 + r16, j, acc[mi][4 * h2 + j][r]);
+}
+
+// Scale / bias / ReLU of a tail without a branch.  A missing scale or bias vector is a descriptor of zero records (every
+// load returns zero bits; the scale's are replaced by 1.0f under a mask), ReLU is a mask on the value's bits: the loads are
+// plain buffer instructions the wait counts of a tail can count, and a group of the tail is ONE basic block.
+struct TailAffine {
+    __amdgpu_buffer_rsrc_t sc_rs, bi_rs;
+    unsigned have_sc, relu_m;
+    __device__ __forceinline__ TailAffine(const float* scale, const float* bias, int relu, int n_ch)
+        : sc_rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? n_ch * 4 : 0, 0x00020000)),
+          bi_rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? n_ch * 4 : 0, 0x00020000)),
+          have_sc(scale ? 0xffffffffu : 0u), relu_m(relu ? 0xffffffffu : 0u) {}
+    __device__ __forceinline__ float one_or(unsigned w) const { return __builtin_bit_cast(float, (w & have_sc) | (0x3f800000u & ~have_sc)); }
+    __device__ __forceinline__ float scale1(int n) const { return one_or(__builtin_amdgcn_raw_buffer_load_b32(sc_rs, n * 4, 0, 0)); }
+    __device__ __forceinline__ float bias1(int n) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bi_rs, n * 4, 0, 0)); }
+    __device__ __forceinline__ float4 scale4(int n) const {
+        const u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(sc_rs, n * 4, 0, 0);
+        return float4{one_or(w.x), one_or(w.y), one_or(w.z), one_or(w.w)};
+    }
+    __device__ __forceinline__ float4 bias4(int n) const { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bi_rs, n * 4, 0, 0)); }
+    __device__ __forceinline__ float act(float v) const {      // relu ? (v > 0 ? v : 0) : v
+        const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
+        return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
+    }
+};
+// the lane's scale / bias of column block j of channels 64 h2 .. + 63, for either accumulator layout (see acc_cols64)
+template <int TN>
+__device__ __forceinline__ void cols64_affine(floatx16 (&)[1][TN], const TailAffine& t, int h2, int lane, float (&sc)[4], float (&bi)[4]) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) { sc[j] = t.scale1(h2 * 64 + j * 32 + (lane & 31)); bi[j] = t.bias1(h2 * 64 + j * 32 + (lane & 31)); }
+}
+template <int NJ>
+__device__ __forceinline__ void cols64_affine(floatx4 (&)[2][NJ], const TailAffine& t, int h2, int lane, float (&sc)[4], float (&bi)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) { sc[j] = t.scale1(h2 * 64 + j * 16 + (lane & 15)); bi[j] = t.bias1(h2 * 64 + j * 16 + (lane & 15)); }
 }
 
 __device__ __forceinline__ void cg_split8(const float4& c0, const float4& c1, uint4& hi, uint4& mid, uint4& lo) {

@@ -57,20 +57,25 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
     };
     load_res(0);
     // (1) this layer's epilogue -> mid
+    {
+        // (the lane's channel of column block j is the same for every row tile: one branch-free fetch per block -- TailAffine)
+        const TailAffine t1(a.scale, a.bias, a.relu, P);
+        float sc1[TN], bi1[TN];
 #pragma unroll
-    for (int i = 0; i < TM; i++)
+        for (int j = 0; j < TN; j++) { sc1[j] = t1.scale1(wn * (P / WN) + j * 32 + l32); bi1[j] = t1.bias1(wn * (P / WN) + j * 32 + l32); }
 #pragma unroll
-        for (int j = 0; j < TN; j++) {
-            const int n = wn * (P / WN) + j * 32 + l32;
-            const float sc = a.scale ? a.scale[n] : 1.0f, bi = a.bias ? a.bias[n] : 0.0f;
+        for (int i = 0; i < TM; i++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = wm * (256 / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                float v = acc[i][j][r] * sc + bi;
-                if (a.relu) v = v > 0.f ? v : 0.f;
-                *reinterpret_cast<unsigned short*>(lds + row * PITCH + (swz(row, n >> 3) << 4) + (n & 7) * 2) = f2bf(v);
+            for (int j = 0; j < TN; j++) {
+                const int n = wn * (P / WN) + j * 32 + l32;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = wm * (256 / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const float v = t1.act(acc[i][j][r] * sc1[j] + bi1[j]);
+                    *reinterpret_cast<unsigned short*>(lds + row * PITCH + (swz(row, n >> 3) << 4) + (n & 7) * 2) = f2bf(v);
+                }
             }
-        }
+    }
     __syncthreads();
     // (2) my 32 rows as A fragments: lane (row l32, half) holds k = 16 s + 8 half .. + 7
     uint4 af[P / 16];
@@ -210,6 +215,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
         // the reduce's own epilogue: scale / bias / ReLU -> bf16 [32 rows][PN], 64 channels at a time through the slab
         const size_t g_bytes = (size_t)a.M * PN * 2;
         const __amdgpu_buffer_rsrc_t g_rs = __builtin_amdgcn_make_buffer_rsrc(a.G_C, 0, (int)g_bytes, 0x00020000);
+        const TailAffine tG(a.G_scale, a.G_bias, 1, PN);
 #pragma unroll
         for (int h = 0; h < PN / 64; h++) {
             __builtin_amdgcn_wave_barrier();

@@ -20,6 +20,10 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, ACC& acc, fl
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     const int half = lane >> 5, l32 = lane & 31;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this layer's and the expand's scale / bias / ReLU: branch-free (TailAffine); this layer's are requested now
+    const TailAffine t1(a.scale, a.bias, a.relu, a.Cout), tF(a.F_scale, a.F_bias, a.F_relu, a.F_ldc);
+    float sc1[4], bi1[4];
+    cols64_affine(acc, t1, 0, lane, sc1, bi1);
     // (1) expand filters -> LDS: piece q = wave + 8 j covers (k-step, plane) = q / 8, rows 32 (q % 8) .. + 31
     {
         const unsigned long long pf = (unsigned long long)a.F_Wt3;
@@ -51,11 +55,7 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, ACC& acc, fl
     // (2) this layer's epilogue in registers, tile -> slab
     float* slab = smem + FUSE_W3_BYTES / 4 + wave * (32 * 64);
     auto slab_at = [](int row, int col) { return row * 64 + ((((col >> 2) ^ (row & 15)) << 2) | (col & 3)); };
-    acc_cols64(acc, 0, lane, [&](int row, int c64, int n, float x) {
-        float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        slab[slab_at(row, c64)] = v;
-    });
+    acc_cols64(acc, 0, lane, [&](int row, int c64, int j, float x) { slab[slab_at(row, c64)] = t1.act(x * sc1[j] + bi1[j]); });
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -74,6 +74,8 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, ACC& acc, fl
     const int b_off = l32 * 32 + ((half ^ ((l32 >> 3) & 1)) * 16);
 #pragma unroll
     for (int g = 0; g < 4; g++) {
+        const int n = g * 64 + c4 * 4;
+        const float4 sc = tF.scale4(n), bi = tF.bias4(n);      // requested here: their round trip runs under the matrix instructions
         floatx16 acc2[2];
 #pragma unroll
         for (int jb = 0; jb < 2; jb++) {
@@ -101,10 +103,6 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, ACC& acc, fl
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int n = g * 64 + c4 * 4;
-        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
-        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int row = it * 4 + (lane >> 4);
@@ -112,7 +110,7 @@ __device__ __forceinline__ void fused_second(const ConvGemmArgs& a, ACC& acc, fl
             const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
             float4 o = {v.x * sc.x + bi.x + rv[g & 1][it].x, v.y * sc.y + bi.y + rv[g & 1][it].y, v.z * sc.z + bi.z + rv[g & 1][it].z,
                         v.w * sc.w + bi.w + rv[g & 1][it].w};
-            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+            o.x = tF.act(o.x); o.y = tF.act(o.y); o.z = tF.act(o.z); o.w = tF.act(o.w);
             if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
         }
         if (g + 2 < 4) load_res(g + 2);
@@ -134,6 +132,10 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
     constexpr int SLABS = 8 * 32 * 64 * 4, GB = 4 * 3 * 64 * 32;      // 64 KB of slabs; 24 KB per filter group
     const int half = lane >> 5, l32 = lane & 31;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this layer's and the expand's scale / bias / ReLU: branch-free (TailAffine); this layer's are requested now
+    const TailAffine t1(a.scale, a.bias, a.relu, a.Cout), tF(a.F_scale, a.F_bias, a.F_relu, a.F_ldc);
+    float sc1[4], bi1[4];
+    cols64_affine(acc, t1, 0, lane, sc1, bi1);
     const unsigned long long pf = (unsigned long long)a.F_Wt3, pg = (unsigned long long)a.G_Wt3;
     const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
     const u32x4 rsg = u32x4{(unsigned)pg, (unsigned)(pg >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
@@ -190,11 +192,7 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    acc_cols64(acc, 0, lane, [&](int row, int c64, int n, float x) {
-        float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        slab[slab_at(row, c64)] = v;
-    });
+    acc_cols64(acc, 0, lane, [&](int row, int c64, int j, float x) { slab[slab_at(row, c64)] = t1.act(x * sc1[j] + bi1[j]); });
     wave_sync();
     uint4 ah[4], am[4], al[4];
     frags(ah, am, al);
@@ -218,6 +216,8 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
         if (g + 1 < 4) dma_group(g + 1);
         const char* wf = lds_c + SLABS + (g & 1) * GB;
         const char* wg = lds_c + SLABS + 2 * GB + (g & 1) * GB;
+        const int n = g * 64 + c4 * 4;
+        const float4 sc = tF.scale4(n), bi = tF.bias4(n);      // requested here: their round trip runs under the matrix instructions
         floatx16 acc2[2];
 #pragma unroll
         for (int jb = 0; jb < 2; jb++) {
@@ -241,10 +241,6 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
                 slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
         wave_sync();
         CG_TSTAMP(1);
-        const int n = g * 64 + c4 * 4;
-        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
-        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int row = it * 4 + (lane >> 4);
@@ -253,7 +249,7 @@ __device__ __forceinline__ void fused_chain(const ConvGemmArgs& a, ACC& acc, flo
             const float4 v = *sp_;
             float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
                         v.w * sc.w + bi.w + rv[it].w};
-            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+            o.x = tF.act(o.x); o.y = tF.act(o.y); o.z = tF.act(o.z); o.w = tF.act(o.w);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 256), 0, 0);
             *sp_ = o;                                           // the final values: this group's slice of the reduce's input
         }
@@ -321,6 +317,10 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, 
     int half = lane >> 5, l32 = lane & 31;      // laundered inside the group loop: the ~60 slab addresses derived from them are
                                                 // loop invariants the compiler would otherwise keep in registers (and spill others)
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this layer's and the expand's scale / bias / ReLU: branch-free (TailAffine); this layer's are requested now
+    const TailAffine t1(a.scale, a.bias, a.relu, a.Cout), tF(a.F_scale, a.F_bias, a.F_relu, a.F_ldc);
+    float sc1[4], bi1[4];
+    cols64_affine(acc, t1, 0, lane, sc1, bi1);
     const unsigned long long pf = (unsigned long long)a.F_Wt3, pg = (unsigned long long)a.G_Wt3;
     const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
     const u32x4 rsg = u32x4{(unsigned)pg, (unsigned)(pg >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
@@ -347,14 +347,22 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, 
     };
     const int c4 = lane & 15;
     const int m_base = m0 + wave * 32;
+    // residual rows and output rows through buffer descriptors (a row past M: out-of-range offset -- zeros / dropped), so that
+    // every wave issues every load and store and the waits below can COUNT; the offsets are rebuilt from one register per use
+    // (eight kept ones do not fit this tail's registers)
+    const size_t out_bytes = (size_t)a.M * a.F_ldc * 4;
+    const __amdgpu_buffer_rsrc_t res_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F_res), 0, a.F_res ? (int)out_bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out_rs = __builtin_amdgcn_make_buffer_rsrc(a.F_C, 0, (int)out_bytes, 0x00020000);
+    const unsigned ldc_b = (unsigned)a.F_ldc * 4u;
+    const int m_lane = m_base + (lane >> 4);
+    const unsigned off_lane = (unsigned)m_lane * ldc_b + (unsigned)(c4 * 16);
+    auto voff = [&](int it, int g) -> unsigned {
+        return (m_lane + it * 4 < a.M) ? off_lane + (unsigned)(it * 4) * ldc_b + (unsigned)(g * 256) : OOB_VOFF;
+    };
     float4 rv[8];
     auto load_res = [&](int g) {
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int m = m_base + it * 4 + (lane >> 4);
-            rv[it] = float4{0.f, 0.f, 0.f, 0.f};
-            if (a.F_res && m < a.M) rv[it] = *reinterpret_cast<const float4*>(a.F_res + (size_t)m * a.F_ldc + g * 64 + c4 * 4);
-        }
+        for (int it = 0; it < 8; it++) rv[it] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(res_rs, voff(it, g), 0, 0));
     };
     dma_expand(0);
     float* slab = smem + wave * (32 * 64);
@@ -364,11 +372,7 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, 
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    acc_cols64(acc, 0, lane, [&](int row, int c64, int n, float x) {
-        float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
-        if (a.relu) v = v > 0.f ? v : 0.f;
-        slab[slab_at(row, c64)] = v;
-    });
+    acc_cols64(acc, 0, lane, [&](int row, int c64, int j, float x) { slab[slab_at(row, c64)] = t1.act(x * sc1[j] + bi1[j]); });
     wave_sync();
     uint4 ah[4], am[4], al[4];
 #pragma unroll
@@ -384,17 +388,21 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, 
         for (int r = 0; r < 16; r++) acc3[jc][r] = 0.0f;
     const char* lds_c = reinterpret_cast<const char*>(smem);
 #define ODAM_MM2(accv, x, y) accv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, x), __builtin_bit_cast(bf16x8, y), accv, 0, 0, 0)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // my pieces of group 0's expand filters
 #pragma unroll 1
     for (int g = 0; g < 4; g++) {
         asm volatile("" : "+v"(half), "+v"(l32));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                        // group g's expand filters are in; everybody is done with group g - 1
+        // group g's expand filters are in: group 0's by the wait before the loop, the others' by the wait in the middle of
+        // group g - 1 (they were requested before the reduce slice that wait is for); only that group's stores are in flight
+        __syncthreads();                                        // ... everybody's; and everybody is done with group g - 1
         if (g + 1 < 4) dma_expand(g + 1);
         dma_reduce(g);
         load_res(g);                                            // this group's residual rows: under the expand's matrix instructions
         const int b_off = l32 * 32 + ((half ^ ((l32 >> 3) & 1)) * 16);
         const char* wf = lds_c + SLABS + (g & 1) * GB;
         const char* wg = lds_c + SLABS + 2 * GB;
+        const int n = g * 64 + c4 * 4;
+        const float4 sc = tF.scale4(n), bi = tF.bias4(n);      // requested here: their round trip runs under the matrix instructions
         floatx16 acc2[2];
 #pragma unroll
         for (int jb = 0; jb < 2; jb++) {
@@ -419,10 +427,6 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, 
             for (int r = 0; r < 16; r++)
                 slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
         wave_sync();
-        const int n = g * 64 + c4 * 4;
-        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
-        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int row = it * 4 + (lane >> 4);
@@ -431,12 +435,15 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, 
             const float4 v = *sp_;
             float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
                         v.w * sc.w + bi.w + rv[it].w};
-            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
-            if (m < a.M) *reinterpret_cast<float4*>(a.F_C + (size_t)m * a.F_ldc + n) = o;
+            o.x = tF.act(o.x); o.y = tF.act(o.y); o.z = tF.act(o.z); o.w = tF.act(o.w);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), out_rs, voff(it, g), 0, 0);
             *sp_ = o;
         }
         wave_sync();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the reduce slice of this group (requested at the top) is in
+        // the reduce slice of this group (requested at the top) is in: younger than its pieces are exactly 2 scale / bias
+        // loads, 8 residual loads and 8 stores -- buffer instructions, never branched around; the stores may stay in flight
+        // (the next group's expand filters are OLDER than the slice: this wait covers them as well)
+        asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
         __syncthreads();
         asm volatile("" : "+v"(half), "+v"(l32));
 #pragma unroll 1
@@ -461,12 +468,13 @@ __device__ __forceinline__ void fused_chain128(const ConvGemmArgs& a, ACC& acc, 
     }
 #undef ODAM_MM2
     // the reduce's own epilogue, 128 channels in two passes of 64 through the slab
+    const TailAffine tG(a.G_scale, a.G_bias, 1, 128);
 #pragma unroll
     for (int h2 = 0; h2 < 2; h2++) {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const int n = h2 * 64 + j * 32 + l32;
-            const float sc = a.G_scale ? a.G_scale[n] : 1.0f, bi = a.G_bias ? a.G_bias[n] : 0.0f;
+                const float sc = tG.scale1(n), bi = tG.bias1(n);
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 float v = acc3[2 * h2 + j][r] * sc + bi;
@@ -498,6 +506,11 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
     static_assert(SLABS + 2 * GB == 160 * 1024, "slabs and two filter groups fill the LDS");
     const int half = lane >> 5, l32 = lane & 31;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // this layer's and the expand's scale / bias / ReLU: branch-free (TailAffine); this layer's are requested now
+    const TailAffine t1(a.scale, a.bias, a.relu, a.Cout), tF(a.F_scale, a.F_bias, a.F_relu, a.F_ldc);
+    float sc1[2][4], bi1[2][4];
+    cols64_affine(acc, t1, 0, lane, sc1[0], bi1[0]);
+    cols64_affine(acc, t1, 1, lane, sc1[1], bi1[1]);
     const unsigned long long pf = (unsigned long long)a.F_Wt3;
     const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
     const int swz = ((lane & 1) ^ ((lane >> 4) & 1)) * 16;
@@ -543,11 +556,7 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
     uint4 ah[KS], am[KS], al[KS];
 #pragma unroll
     for (int h2 = 0; h2 < 2; h2++) {                        // channels 64 h2 .. + 63 of the 3x3's tile
-        acc_cols64(acc, h2, lane, [&](int row, int c64, int n, float x) {
-            float v = x * (a.scale ? a.scale[n] : 1.0f) + (a.bias ? a.bias[n] : 0.0f);
-            if (a.relu) v = v > 0.f ? v : 0.f;
-            slab[slab_at(row, c64)] = v;
-        });
+        acc_cols64(acc, h2, lane, [&](int row, int c64, int j, float x) { slab[slab_at(row, c64)] = t1.act(x * sc1[h2][j] + bi1[h2][j]); });
         wave_sync();
 #pragma unroll
         for (int s_ = 0; s_ < 4; s_++) {
@@ -569,6 +578,8 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
         __syncthreads();
         if (g + 1 < NG) dma_group(g + 1);
         const char* wf = lds_c + SLABS + (g & 1) * GB;
+        const int n = g * 64 + c4 * 4;
+        const float4 sc = tF.scale4(n), bi = tF.bias4(n);      // requested here: their round trip runs under the matrix instructions
         floatx16 acc2[2];
 #pragma unroll
         for (int jb = 0; jb < 2; jb++) {
@@ -591,10 +602,6 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
             for (int r = 0; r < 16; r++)
                 slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
         wave_sync();
-        const int n = g * 64 + c4 * 4;
-        float4 sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
-        if (a.F_scale) sc = *reinterpret_cast<const float4*>(a.F_scale + n);
-        if (a.F_bias) bi = *reinterpret_cast<const float4*>(a.F_bias + n);
 #pragma unroll
         for (int it = 0; it < 8; it++) {
             const int row = it * 4 + (lane >> 4);
@@ -602,7 +609,7 @@ __device__ __forceinline__ void fused_second128(const ConvGemmArgs& a, ACC& acc,
             const float4 v = *reinterpret_cast<const float4*>(&slab[row * 64 + ((c4 ^ (row & 15)) << 2)]);
             float4 o = {v.x * sc.x + bi.x + rv[it].x, v.y * sc.y + bi.y + rv[it].y, v.z * sc.z + bi.z + rv[it].z,
                         v.w * sc.w + bi.w + rv[it].w};
-            if (a.F_relu) { o.x = o.x > 0.f ? o.x : 0.f; o.y = o.y > 0.f ? o.y : 0.f; o.z = o.z > 0.f ? o.z : 0.f; o.w = o.w > 0.f ? o.w : 0.f; }
+            o.x = tF.act(o.x); o.y = tF.act(o.y); o.z = tF.act(o.z); o.w = tF.act(o.w);
 #if CG_HACK & 4      // timing build without the tail's memory traffic: the value is consumed, nothing is stored, no residual row is requested
             asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
 #else
