@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
         }
     }
     if constexpr (FUSE >= 5) {
-        fused_bf16<BN, FUSE == 5 ? 0 : (32 << (FUSE - 5))>(a, acc, smem, lds_base, m0, wm, wn, wave, lane);
+        fused_bf16<BN, FUSE == 5 ? 0 : (32 << (FUSE - 5)), FUSE == 7 ? 2 : 3>(a, acc, smem, lds_base, m0, wm, wn, wave, lane);      // (128 chained outputs: no registers for a third residual group)
         return;
     }
     static_assert(X16 || (WM * WN * 32 * (BN / WN) * 4 <= big_lds_bytes<MODE, BN, NST, NTH>() && NST * STAGE <= big_lds_bytes<MODE, BN, NST, NTH>()),

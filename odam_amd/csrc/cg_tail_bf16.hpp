@@ -18,10 +18,10 @@ namespace odam_cg {
 //       into the reduce's accumulators (32 rows x PN), which after the last group are the next 3x3's input tile.
 // Same products in the same order as the separate launches (k ascending in steps of 16), same rounding points: bit-identical
 // to them.  vmcnt bookkeeping: the DMAs are inline assembly (the compiler does not count them); each group's top waits with
-// vmcnt(8) -- the DMAs of this group were issued one group ago and exactly 4 residual loads + 4 stores (buffer instructions
-// with an out-of-range offset for rows past M: issued by every wave, never branched around) are younger.  More compiler-visible
-// loads in between only make that wait stricter, never laxer.
-template <int P, int PN>
+// vmcnt(12) -- the DMAs of this group were issued one group ago and exactly 4 residual loads + 4 scale / bias loads + 4 stores
+// (buffer instructions with an out-of-range offset for rows past M: issued by every wave, never branched around) are younger.
+// More compiler-visible loads in between would only make that wait stricter, never laxer.
+template <int P, int PN, int RES_DEPTH = 3>
 __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc)[256 / (P == 64 ? 8 : (P == 128 ? 4 : 2)) / 32][2],
                                            float* smem, unsigned lds_base, int m0, int wm, int wn, int wave, int lane) {
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -49,13 +49,18 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
         const int m = m_base + it * 8 + (lane >> 3);
         row_off[it] = m < a.M ? (unsigned)((size_t)m * a.F_ldc * 2 + c8 * 16) : OOB_VOFF;
     }
-    u32x4 rv[2][4];
-    auto load_res = [&](int g) {
+    // residual rows are requested RD - 1 groups ahead of their use (a group's 4 KB per wave is 32 KB per CU in flight: at the
+    // ~2 us a loaded HBM read takes that alone is 16 GB/s per CU; the tail's registers -- the 3x3's accumulators are dead here --
+    // allow a second group where the chained reduce's accumulators leave room)
+    constexpr int RD = RES_DEPTH;
+    u32x4 rv[RD][4];
+    auto load_res = [&](int g) {      // g >= NG: an out-of-range request (zeros, no traffic): the instruction count per group stays
 #pragma unroll
         for (int it = 0; it < 4; it++)
-            rv[g & 1][it] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, row_off[it] == OOB_VOFF ? OOB_VOFF : row_off[it] + (unsigned)(g * 128), 0, 0);
+            rv[g % RD][it] = __builtin_amdgcn_raw_buffer_load_b128(res_rs, (g >= NG || row_off[it] == OOB_VOFF) ? OOB_VOFF : row_off[it] + (unsigned)(g * 128), 0, 0);
     };
-    load_res(0);
+#pragma unroll
+    for (int g = 0; g < RD - 1; g++) load_res(g);
     // (1) this layer's epilogue -> mid
     {
         // (the lane's channel of column block j is the same for every row tile: one branch-free fetch per block -- TailAffine)
@@ -132,10 +137,23 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
 #pragma unroll
     for (int g = 0; g < NG; g++) {      // unrolled: the residual buffers rv[g & 1] must be compile-time register names
         if (g == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // my pieces of group g's filters have landed (see the header)
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");     // my pieces of group g's filters have landed (see the header)
         __syncthreads();                                             // ... and everybody's; everybody is done with group g - 1's buffer
         if (g + 1 < NG) dma_group(g + 1);
-        load_res(g + 1 < NG ? g + 1 : g);                            // (the last group repeats its own: the instruction count stays)
+        load_res(g + RD - 1);
+        const int n = g * 64 + c8 * 8;
+        // scale / bias of the lane's 8 channels: two 16-byte loads each through descriptors that hold no records when the pointer is null
+        // (the load then returns zeros; a missing scale becomes 1 by a select) -- no branch around a load, so the group stays ONE basic block
+        // (round 6: `p ? p[n + c] : 1` per element was 16 scalar loads and 31 branches per group, which also fenced the scheduler in);
+        // requested here, ahead of the matrix instructions that hide their round trip
+        // (with 128 chained outputs the 16 registers are not there across the products: requested where they are used, as before)
+        constexpr bool AFFINE_EARLY = PN != 128;
+        u32x4 s0, s1, b0, b1;
+        auto load_affine = [&] {
+            s0 = __builtin_amdgcn_raw_buffer_load_b128(sc_rs, (unsigned)n * 4u, 0, 0); s1 = __builtin_amdgcn_raw_buffer_load_b128(sc_rs, (unsigned)n * 4u + 16u, 0, 0);
+            b0 = __builtin_amdgcn_raw_buffer_load_b128(bi_rs, (unsigned)n * 4u, 0, 0); b1 = __builtin_amdgcn_raw_buffer_load_b128(bi_rs, (unsigned)n * 4u + 16u, 0, 0);
+        };
+        if constexpr (AFFINE_EARLY) load_affine();
         const char* wf = lds + WB + (g & 1) * GB;
         floatx16 acc2[2];
 #pragma unroll
@@ -156,14 +174,9 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
             for (int r = 0; r < 16; r++)
                 slab[slab_at((r & 3) + 8 * (r >> 2) + 4 * half, jb * 32 + l32)] = acc2[jb][r];
         wave_sync();
-        const int n = g * 64 + c8 * 8;
-        // scale / bias of the lane's 8 channels: two 16-byte loads each through descriptors that hold no records when the pointer is null
-        // (the load then returns zeros; a missing scale becomes 1 by a select) -- no branch around a load, so the group stays ONE basic block
-        // (round 6: `p ? p[n + c] : 1` per element was 16 scalar loads and 31 branches per group, which also fenced the scheduler in)
         float sc[8], bi[8];
+        if constexpr (!AFFINE_EARLY) load_affine();
         {
-            const u32x4 s0 = __builtin_amdgcn_raw_buffer_load_b128(sc_rs, (unsigned)n * 4u, 0, 0), s1 = __builtin_amdgcn_raw_buffer_load_b128(sc_rs, (unsigned)n * 4u + 16u, 0, 0);
-            const u32x4 b0 = __builtin_amdgcn_raw_buffer_load_b128(bi_rs, (unsigned)n * 4u, 0, 0), b1 = __builtin_amdgcn_raw_buffer_load_b128(bi_rs, (unsigned)n * 4u + 16u, 0, 0);
             const unsigned sw[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
             for (int c = 0; c < 8; c++) {
@@ -177,7 +190,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
             const float4 v0 = *reinterpret_cast<const float4*>(&slab[row * 64 + (((2 * c8) ^ (row & 15)) << 2)]);
             const float4 v1 = *reinterpret_cast<const float4*>(&slab[row * 64 + (((2 * c8 + 1) ^ (row & 15)) << 2)]);
             const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            const u32x4 rr = rv[g & 1][it];
+            const u32x4 rr = rv[g % RD][it];
             const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
             unsigned ow[4];
 #pragma unroll
