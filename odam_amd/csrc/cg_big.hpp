@@ -696,11 +696,8 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             load_res(0, rv[0]);
             if (NU > 1) load_res(1, rv[1]);
             __syncthreads();      // every wave is past its last fragment read: the ring is free for the slabs
-            const unsigned relu_m = a.relu ? 0xffffffffu : 0u;
-            auto act = [&](float v) {      // relu ? (v > 0 ? v : 0) : v, without a branch
-                const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
-                return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
-            };
+            const int relu_fb = relu_floor_bits(a.relu);
+            auto act = [&](float v) { return relu_floor(v, relu_fb); };      // relu ? (v > 0 ? v : 0) : v, without a branch
 #pragma unroll
             for (int u = 0; u < NU; u++) {
                 const int mi = u / NH, h = u % NH;

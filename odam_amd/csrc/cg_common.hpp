@@ -84,6 +84,14 @@ __device__ __forceinline__ void lds_dma16(u32x4 rsrc, unsigned lds_byte, unsigne
                  : "memory");
 }
 
+// ReLU under a run-time flag as ONE integer maximum (v_max_i32): a float is > 0 exactly when its bits, read as int32, are, so
+// max(bits, 0) is relu(v) and max(bits, INT_MIN) is v; a positive NaN passes through either way (as in the reference's relu).
+// (`keep = v > 0 ? ~0 : ~relu_mask; bits & keep` was a compare into an SGPR pair, a select and an AND per element.)
+__device__ __forceinline__ int relu_floor_bits(int relu) { return relu ? 0 : (int)0x80000000; }
+__device__ __forceinline__ float relu_floor(float v, int floor_bits) {
+    return __builtin_bit_cast(float, __builtin_elementwise_max(__builtin_bit_cast(int, v), floor_bits));      // (llvm.smax: written as a select the integer compare stays beside a float select)
+}
+
 // ---- epilogue shared by the kernels below: scale/bias (FrozenBN or Linear bias), residual, ReLU ----------------
 // acc[i][j] is the wave's (i, j)-th 32x32 accumulator tile of its (BM / WM) x (BN / WN) sub-tile; `smem` (at least
 // WM * WN * 32 * (BN / WN) floats, free after the K loop) is used to turn the sub-tile for wide stores.
@@ -333,11 +341,8 @@ __device__ __forceinline__ void epilogue2(const ConvGemmArgs& a, floatx16 (&acc)
     load_res(0, rv[0]);
     if (TM > 1) load_res(1, rv[1]);
     __syncthreads();      // every wave is done with the staging buffers: they become the slabs
-    const unsigned relu_m = a.relu ? 0xffffffffu : 0u;
-    auto act = [&](float v) {      // relu ? (v > 0 ? v : 0) : v
-        const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
-        return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
-    };
+    const int relu_fb = relu_floor_bits(a.relu);
+    auto act = [&](float v) { return relu_floor(v, relu_fb); };      // relu ? (v > 0 ? v : 0) : v, without a branch
 #pragma unroll
     for (int i = 0; i < TM; i++) {
         __builtin_amdgcn_wave_barrier();
@@ -410,11 +415,12 @@ __device__ __forceinline__ void acc_cols64(floatx4 (&acc)[2][NJ], int h2, int la
 // plain buffer instructions the wait counts of a tail can count, and a group of the tail is ONE basic block.
 struct TailAffine {
     __amdgpu_buffer_rsrc_t sc_rs, bi_rs;
-    unsigned have_sc, relu_m;
+    unsigned have_sc;
+    int relu_fb;
     __device__ __forceinline__ TailAffine(const float* scale, const float* bias, int relu, int n_ch)
         : sc_rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(scale), 0, scale ? n_ch * 4 : 0, 0x00020000)),
           bi_rs(__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias), 0, bias ? n_ch * 4 : 0, 0x00020000)),
-          have_sc(scale ? 0xffffffffu : 0u), relu_m(relu ? 0xffffffffu : 0u) {}
+          have_sc(scale ? 0xffffffffu : 0u), relu_fb(relu_floor_bits(relu)) {}
     __device__ __forceinline__ float one_or(unsigned w) const { return __builtin_bit_cast(float, (w & have_sc) | (0x3f800000u & ~have_sc)); }
     __device__ __forceinline__ float scale1(int n) const { return one_or(__builtin_amdgcn_raw_buffer_load_b32(sc_rs, n * 4, 0, 0)); }
     __device__ __forceinline__ float bias1(int n) const { return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bi_rs, n * 4, 0, 0)); }
@@ -423,10 +429,7 @@ struct TailAffine {
         return float4{one_or(w.x), one_or(w.y), one_or(w.z), one_or(w.w)};
     }
     __device__ __forceinline__ float4 bias4(int n) const { return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(bi_rs, n * 4, 0, 0)); }
-    __device__ __forceinline__ float act(float v) const {      // relu ? (v > 0 ? v : 0) : v
-        const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
-        return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
-    }
+    __device__ __forceinline__ float act(float v) const { return relu_floor(v, relu_fb); }      // relu ? (v > 0 ? v : 0) : v
 };
 // the lane's scale / bias of column block j of channels 64 h2 .. + 63, for either accumulator layout (see acc_cols64)
 template <int TN>

@@ -4,6 +4,13 @@
 
 namespace odam_cg {
 
+// Timing builds of the tail (WRONG results; tests/native/tail_phases_bf16.sh): 1 no residual request and no store leaves the CU
+// (out-of-range offsets), 2 no expand / reduce products, 4 the tail returns at once (the launch is the 3x3's main loop alone),
+// 8 no expand-filter DMA.
+#ifndef CG_TAILHACK
+#define CG_TAILHACK 0
+#endif
+
 // ---- bf16 bottleneck on the tile (BASELINE config 4): 3x3 (P channels) + 1x1 expand (4 P) + residual [+ the next reduce] -----
 // After the K loop of the 3x3 the workgroup holds a 256-row x P-channel tile (P = 64 / 128 / 256) in accumulators.  In bf16 the
 // bottleneck's 1x1 layers are bound by bytes, not by the matrix pipe (layer3's expand as its own launch: 154 us for 56 GFLOP,
@@ -32,6 +39,13 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
     constexpr int GB = 128 * P + 128 * PN;             // bytes per weight buffer: 64 x P expand rows + PN x 64 reduce slice
     static_assert(WB + 2 * GB <= 160 * 1024, "fused bf16 bottleneck: LDS");
     static_assert(256 * PITCH <= 160 * 1024, "mid tile fits");
+    if (CG_TAILHACK & 4) {
+#pragma unroll
+        for (int i = 0; i < TM; i++)
+#pragma unroll
+            for (int j = 0; j < TN; j++) asm volatile("" :: "v"(acc[i][j]));
+        return;
+    }
     const int half = lane >> 5, l32 = lane & 31;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     char* lds = reinterpret_cast<char*>(smem);
@@ -47,7 +61,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
 #pragma unroll
     for (int it = 0; it < 4; it++) {
         const int m = m_base + it * 8 + (lane >> 3);
-        row_off[it] = m < a.M ? (unsigned)((size_t)m * a.F_ldc * 2 + c8 * 16) : OOB_VOFF;
+        row_off[it] = (m < a.M && !(CG_TAILHACK & 1)) ? (unsigned)((size_t)m * a.F_ldc * 2 + c8 * 16) : OOB_VOFF;
     }
     // residual rows are requested RD - 1 groups ahead of their use (a group's 4 KB per wave is 32 KB per CU in flight: at the
     // ~2 us a loaded HBM read takes that alone is 16 GB/s per CU; the tail's registers -- the 3x3's accumulators are dead here --
@@ -92,8 +106,8 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
     __syncthreads();     // mid has been read by everybody: the LDS is free for the weight buffers and the slabs
     // (3) weights of group g -> buffer g & 1
     const unsigned long long pf = (unsigned long long)a.F_Wt, pg = (unsigned long long)a.G_Wt;
-    const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
-    const u32x4 rsg = u32x4{(unsigned)pg, (unsigned)(pg >> 32) & 0xffffu, OOB_VOFF, 0x00020000u};
+    const u32x4 rsf = u32x4{(unsigned)pf, (unsigned)(pf >> 32) & 0xffffu, (CG_TAILHACK & 8) ? 0u : OOB_VOFF, 0x00020000u};
+    const u32x4 rsg = u32x4{(unsigned)pg, (unsigned)(pg >> 32) & 0xffffu, (CG_TAILHACK & 8) ? 0u : OOB_VOFF, 0x00020000u};
     auto dma_group = [&](int g) {
         const unsigned buf = lds_base + (unsigned)(WB + (g & 1) * GB);
         constexpr int RPC = 1024 / PITCH;              // filter rows per 1 KB piece
@@ -123,11 +137,9 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
     };
     const __amdgpu_buffer_rsrc_t sc_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F_scale), 0, a.F_scale ? 4 * P * 4 : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t bi_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.F_bias), 0, a.F_bias ? 4 * P * 4 : 0, 0x00020000);
-    const unsigned have_sc = a.F_scale ? 0xffffffffu : 0u, relu_m = a.F_relu ? 0xffffffffu : 0u;
-    auto act = [&](float v) {      // F_relu ? (v > 0 ? v : 0) : v, without a branch
-        const unsigned keep = (v > 0.f) ? 0xffffffffu : ~relu_m;
-        return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & keep);
-    };
+    const unsigned have_sc = a.F_scale ? 0xffffffffu : 0u;
+    const int relu_fb = relu_floor_bits(a.F_relu);
+    auto act = [&](float v) { return relu_floor(v, relu_fb); };      // F_relu ? (v > 0 ? v : 0) : v, without a branch
     floatx16 acc3[PN ? PN / 32 : 1];
 #pragma unroll
     for (int jc = 0; jc < (PN ? PN / 32 : 1); jc++)
@@ -162,7 +174,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
             for (int r = 0; r < 16; r++) acc2[jb][r] = 0.0f;
             const int nrow = jb * 32 + l32;
 #pragma unroll
-            for (int s_ = 0; s_ < P / 16; s_++) {
+            for (int s_ = 0; s_ < ((CG_TAILHACK & 2) ? 0 : P / 16); s_++) {
                 const uint4 b = *reinterpret_cast<const uint4*>(wf + nrow * PITCH + (swz(nrow, 2 * s_ + half) << 4));
                 ODAM_MMB(acc2[jb], af[s_], b);
             }
@@ -215,7 +227,7 @@ __device__ __forceinline__ void fused_bf16(const ConvGemmArgs& a, floatx16 (&acc
             for (int jc = 0; jc < PN / 32; jc++) {
                 const int nrow = jc * 32 + l32;
 #pragma unroll
-                for (int s_ = 0; s_ < 4; s_++) {
+                for (int s_ = 0; s_ < ((CG_TAILHACK & 2) ? 0 : 4); s_++) {
                     const uint4 b = *reinterpret_cast<const uint4*>(wg + nrow * 128 + (((2 * s_ + half) ^ ((nrow >> 1) & 7)) << 4));
                     ODAM_MMB(acc3[jc], xf[s_], b);
                 }
