@@ -48,6 +48,13 @@ constexpr int big_wm(int MODE, int BN, int NTH) {
     return NTH == 1024 ? (BN == 64 ? 16 : 4)      // bf16, 256 columns: sixteen waves of 64 x 64
          : MODE >= 3 ? (BN == 256 ? ((MODE == 4 && CG_X16_WM8) ? 8 : 4) : 8) : (BN == 256 ? 2 : (BN == 128 ? 4 : 8));
 }
+// bf16, sixteen waves on 256 x 256 (the plain 1x1 layers of config 4: reduce / expand / downsample / the transformer's wide
+// linears): activation tiles two PAIRS ahead in a ring of their own (see "deep A ring" in the main loop).  CG_DEEP_A = 0: off.
+#ifndef CG_DEEP_A
+#define CG_DEEP_A 1
+#endif
+
+constexpr bool big_deep_a(int MODE, int BN, int NST, int NTH) { return CG_DEEP_A != 0 && MODE == 0 && BN == 256 && NST == 4 && NTH == 1024; }
 // dynamic LDS of the ring kernel: the ring, or the epilogue's 32-row slab per wave if that is larger
 template <int MODE, int BN, int NST, int NTH>
 constexpr int big_lds_bytes() {
@@ -58,7 +65,9 @@ constexpr int big_lds_bytes() {
     const int slab = MODE == 4 ? (NTH / 64) * 16 * ((BN / wn > 128 ? 128 : BN / wn) + 4) * 4 : (NTH / 64) * 32 * (BN / wn) * 4;      // the 16x16x32 loop's epilogue: 16-row slabs, rows padded by 4
     const int s1 = (MODE == 0 && NTH == 512) ? (BN == 256 ? 2 : (BN == 128 ? 3 : 4)) * (384 * 64 + 3 * BN * 64) : 0;   // the 3x3 stride-1 window ring (bf16)
     const int m = ring > slab ? ring : slab;
-    return m > s1 ? m : s1;
+    const int deep = big_deep_a(MODE, BN, NST, NTH) ? (6 + 4) * 256 * 64 : 0;      // six activation + four filter slots (see the main loop)
+    const int m2 = m > s1 ? m : s1;
+    return m2 > deep ? m2 : deep;
 }
 
 template <int MODE, int BN, int NST, int NTH = 512, int FUSE = 0>     // FUSE: 1 = second layer on the tile (F_*), 2 = and a third (G_*)
@@ -310,6 +319,32 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
 #if CG_STAMP
     unsigned long long st_acc[4] = {0, 0, 0, 0}, st_prev = 0;
 #endif
+    // one k-tile (two k-steps of 16) of bf16 operands: Ab / Bb = this lane's fragment rows of the activation / filter slot
+    auto mma_ab = [&](const char* Ab, const char* Bb, auto&& issue_next) {
+        float4 af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[0]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[0]);
+        int part = 0;
+        issue_next(part++);
+#pragma unroll
+        for (; part < LPT; part++) issue_next(part);
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[1]);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[1]);
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+#pragma unroll
+            for (int i = 0; i < TM; i++) {
+#pragma unroll
+                for (int j = 0; j < TN; j++) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
+                                                                        __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
+                }
+            }
+    };
     auto mma_tile = [&](int st, auto&& issue_next) {
         const char* Ab = lds_c + st * STAGE + a_off;
         const char* Bb = lds_c + st * STAGE + b_off;
@@ -349,29 +384,7 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             }
             return;
         }
-        float4 af[2][TM], bf[2][TN];
-#pragma unroll
-        for (int i = 0; i < TM; i++) af[0][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[0]);
-#pragma unroll
-        for (int j = 0; j < TN; j++) bf[0][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[0]);
-        int part = 0;
-        issue_next(part++);
-#pragma unroll
-        for (; part < LPT; part++) issue_next(part);
-#pragma unroll
-        for (int i = 0; i < TM; i++) af[1][i] = *reinterpret_cast<const float4*>(Ab + i * 32 * ROWB + fq[1]);
-#pragma unroll
-        for (int j = 0; j < TN; j++) bf[1][j] = *reinterpret_cast<const float4*>(Bb + j * 32 * ROWB + fq[1]);
-#pragma unroll
-        for (int q = 0; q < 2; q++)
-#pragma unroll
-            for (int i = 0; i < TM; i++) {
-#pragma unroll
-                for (int j = 0; j < TN; j++) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[q][i]),
-                                                                        __builtin_bit_cast(bf16x8, bf[q][j]), acc[i][j], 0, 0, 0);
-                }
-            }
+        mma_ab(Ab, Bb, issue_next);
     };
 
     const int nk = a.Kpad / BKE;
@@ -998,6 +1011,60 @@ __global__ __launch_bounds__(NTH, (NTH == 1024 ? 4 : 2)) void conv_gemm_big_kern
             }
             s1_done = true;
         }
+    }
+    if constexpr (big_deep_a(MODE, BN, NST, NTH)) if (!s1_done) {
+        // Deep A ring (round 6).  The pair loop below keeps ONE pair of k-tiles in flight behind the pair being multiplied: 32 KB of
+        // activations per CU, requested 0.85 us of matrix work ahead of their use -- less than a loaded HBM read takes, so a 1x1 layer
+        // that streams its activations once (layer3's reduce: 512 KB per tile) ran at the LATENCY of a pair, 44 us per tile for 13.6 us
+        // of products, 3.4 TB/s.  The filters come from L2 and need no such distance.  So the two operands get rings of their own:
+        // six activation slots (three pairs) and four filter slots (two pairs) = 160 KB; iteration kp requests the filters of pair
+        // kp + 1 and then the activations of pair kp + 2.  The wait at its top is for filters (kp) -- requested in iteration kp - 1 and
+        // followed there by exactly the two activation pieces of pair kp + 1, which stay in flight (vmcnt(2)); everything older has
+        // landed with them.  A pair's second tile past the end of K is requested out of range (no traffic, the count stays); pairs past
+        // the end are not requested at all and the wait is then for everything, so nothing is in flight when the epilogue takes the LDS.
+        // Same products in the same order: bit-identical.  MEASURED (profiles/r6_experiments.txt 18): R101 bf16 forward -0.4 % at 32 frames,
+        // -0.8 % at 76 -- the distance was NOT what held these layers at 3.4 TB/s; nor is it the lockstep of the CUs on the same filter
+        // lines (every workgroup starting K at a different pair: -1.5 % / +0.7 %).  What is left is the loop's own ratio: sixteen waves of
+        // 64 x 64 read one LDS fragment per matrix instruction (1 KB per 32 cycles of the pipe per wave, 128 KB per k-tile and CU, plus
+        // 32 KB of DMA writes), so the LDS is as busy as the matrix pipe and neither reaches half.
+        static_assert(A_LD == 1 && B_LD == 1 && LPT == 2, "deep A ring: one activation and one filter piece per thread and tile");
+        constexpr int A_SL = BM * ROWB, B_SL = BN * ROWB, B_BASE = 6 * A_SL;
+        static_assert(B_BASE + 4 * B_SL <= big_lds_bytes<MODE, BN, NST, NTH>(), "deep A ring fits the dynamic LDS");
+        const int npair = (nk + 1) >> 1;
+        auto dma_a_pair = [&](int kp) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int kt = 2 * kp + h;
+                const TilePrep tp = tile_prep(kt < nk ? kt : 0);
+                const unsigned vo = (kt < nk && ((a_mask[0] >> tp.tap) & 1u)) ? a_voff[0] : OOB_VOFF;
+                lds_dma16(a_rs4, lds_base + (unsigned)((2 * (kp % 3) + h) * A_SL + wave_u * 16 * ROWB), vo, tp.soff_a);
+            }
+        };
+        auto dma_b_pair = [&](int kp) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int kt = 2 * kp + h;
+                const TilePrep tp = tile_prep(kt < nk ? kt : 0);
+                lds_dma16(w_rs4, lds_base + (unsigned)(B_BASE + (2 * (kp & 1) + h) * B_SL + wave_u * 16 * ROWB), kt < nk ? w_voff[0] : OOB_VOFF, tp.soff_b);
+            }
+        };
+        dma_b_pair(0);
+        dma_a_pair(0);
+        if (1 < npair) dma_a_pair(1);
+        for (int kp = 0; kp < npair; ++kp) {
+            if (kp + 1 < npair) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const char* Ab = lds_c + (2 * (kp % 3)) * A_SL + a_off;
+            const char* Bb = lds_c + B_BASE + (2 * (kp & 1)) * B_SL + (b_off - BM * ROWB);
+            mma_ab(Ab, Bb, [&](int part) {
+                if (part == 0) { if (kp + 1 < npair) dma_b_pair(kp + 1); }
+                else if (kp + 2 < npair) dma_a_pair(kp + 2);
+            });
+            if (2 * kp + 1 < nk) mma_ab(Ab + A_SL, Bb + B_SL, [](int) {});
+        }
+        s1_done = true;
     }
     if (BF16 && NST == 4 && !s1_done) {
         // bf16, tiles in PAIRS: k-tiles 2 kp and 2 kp + 1 are the two 64-byte halves of the same 128-byte lines, and their DMAs
