@@ -8,6 +8,7 @@ the host, exactly as the reference does (odam_config assoc.hungarian = 0, the de
 odam_assoc_hungarian restates scipy's shortest-augmenting-path solver with its tie order on one wavefront, launched behind the Sinkhorn
 loop; same matching on every fixture and on matrices full of ties -- tests/test_assoc_gpu.py -- but 0.01 ms per frame slower, because the
 host has to wait for the device either way)."""
+import contextlib
 import ctypes
 import math
 
@@ -343,8 +344,12 @@ class Associator:
         n_app = len(app_ids)
         ids = np.ascontiguousarray(app_ids, np.int32)
         rows = np.ascontiguousarray(app_rows14, np.float64)
-        with torch.cuda.device(dev), fitter._lock:
-            cur = torch.cuda.current_stream(dev)
+        # (per-frame host cost matters here -- the device is idle until the call below: the device context is entered only when another
+        # device is current, and the completion event is one object, recorded again every frame)
+        dev_t = torch.device(dev)
+        ctx = torch.cuda.device(dev_t) if torch.cuda.current_device() != (dev_t.index or 0) else contextlib.nullcontext()
+        with ctx, fitter._lock:
+            cur = torch.cuda.current_stream(dev_t)
             stream = cur.cuda_stream
             if fitter._last is not None and fitter._last[0] != stream:
                 cur.wait_event(fitter._last[1])
@@ -352,7 +357,9 @@ class Associator:
                                          rows.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(n_tracks), cam21.ctypes.data_as(ctypes.c_void_p),
                                          ctypes.c_double(cam_azi), ctypes.c_double(img_w), ctypes.c_double(img_h), _lib.ptr(self._pin[0]),
                                          ctypes.c_int(n_det), _lib.ptr(buf), _lib.ptr(self._pin[1]), ctypes.c_void_p(stream)), "odam_assoc_step")
-            ev = torch.cuda.Event()
+            ev = getattr(self, "_step_ev", None)
+            if ev is None:
+                ev = self._step_ev = torch.cuda.Event()
             ev.record(cur)
             fitter._last = (stream, ev)
         self._step = (n_tracks, n_det, fitter)

@@ -569,14 +569,14 @@ class OdamProcess:
         n_det = cur["det32T"].shape[1]
         # hungarian_matching (associator.py:19-35) on the float32 scores torch computes, without its Python loop: the assignment of
         # linear_sum_assignment(1 - scores), kept where the matched score exceeds the match threshold
-        scores = Z[:-1, :-1].exp().numpy()
+        score_mat = Z.exp().numpy()              # ONE exponential (elementwise: its [:-1, :-1] block is what Z[:-1, :-1].exp() computes)
+        scores = score_mat[:-1, :-1]
         r_, c_ = linear_sum_assignment(1 - scores)
         ok = scores[r_, c_] > self.match_threshold
         match = np.full(n_det, -1, np.int32)
         match[c_[ok]] = r_[ok]
         # _attach_to_tracks' tests (processor.py:228-231): a detection is dropped if the score of its pair -- for an unmatched one the
         # dustbin row, index -1 -- is below the score threshold (a NaN is not below anything: kept, as in the loop)
-        score_mat = Z.exp().numpy()
         keep = ~(score_mat[match, np.arange(n_det)] < self.score_threshold)
         picked = np.flatnonzero(keep)
         mk = match[picked]
