@@ -128,6 +128,15 @@ int odam_assoc_debug_read(odam_assoc* m, int which, float* out, long long n);
 int odam_assoc_hungarian(const float* Z, int n_tracks, int n_det, int ldz, double threshold, int log_domain, int* match_out, int* status,
                          void* stream);
 
+/* hungarian_matching (src/models/associator.py:19-35) and the score test of _attach_to_tracks (src/processor.py:228-231) on the HOST, no device
+ * work: score [host] = exp of the log assignment, (n_tracks + 1) x (n_det + 1) float32 with row stride lds (the last row / column are the
+ * dustbins); match_out [n_det] receives the track of every detection whose matched score exceeds match_threshold (scipy's
+ * linear_sum_assignment(1 - score[:-1, :-1]) restated sequentially with its tie order), -1 otherwise; keep_out [n_det] is 0 where the
+ * score of the detection's pair -- the dustbin row for an unmatched one -- is below score_threshold (both comparisons in float32, as numpy and
+ * torch compare a float32 array with a Python float).  4: NaN / -inf in the cost matrix, 5: infeasible (scipy raises ValueError for both). */
+int odam_assoc_attach(const float* score, int n_tracks, int n_det, int lds, double match_threshold, double score_threshold, int* match_out,
+                      unsigned char* keep_out);
+
 /* log_optimal_transport alone: scores [dev][m, n] with row stride lds, alpha = bin_score */
 int odam_assoc_sinkhorn(const float* scores, int lds, int m, int n, float alpha, int iters, float* Z_out, void* stream);
 

@@ -353,8 +353,8 @@ class Associator:
             stream = cur.cuda_stream
             if fitter._last is not None and fitter._last[0] != stream:
                 cur.wait_event(fitter._last[1])
-            _lib.check(L.odam_assoc_step(self._handle(), win._h, fitter._h, ctypes.c_int(n_app), ids.ctypes.data_as(ctypes.c_void_p),
-                                         rows.ctypes.data_as(ctypes.c_void_p), ctypes.c_int(n_tracks), cam21.ctypes.data_as(ctypes.c_void_p),
+            _lib.check(L.odam_assoc_step(self._handle(), win._h, fitter._h, ctypes.c_int(n_app), ctypes.c_void_p(ids.ctypes.data),
+                                         ctypes.c_void_p(rows.ctypes.data), ctypes.c_int(n_tracks), ctypes.c_void_p(cam21.ctypes.data),
                                          ctypes.c_double(cam_azi), ctypes.c_double(img_w), ctypes.c_double(img_h), _lib.ptr(self._pin[0]),
                                          ctypes.c_int(n_det), _lib.ptr(buf), _lib.ptr(self._pin[1]), ctypes.c_void_p(stream)), "odam_assoc_step")
             ev = getattr(self, "_step_ev", None)

@@ -1803,6 +1803,76 @@ __global__ __launch_bounds__(64) void hungarian_wave_kernel(const float* __restr
 }
 }  // namespace
 
+// ---- the same step on the HOST, with the tests that follow it (OdamProcess's fast path: one call between a frame's result and the next launch) ----
+// scipy.optimize.linear_sum_assignment(1 - scores) as hungarian_matching calls it (associator.py:19-35) -- the sequential form of the solver
+// restated above: rows in order, the scan over a "remaining" list that starts reversed and shrinks by swap-removal, among equal reduced costs a
+// free column wins and the LAST such column of the scan, binary64 duals in scipy's order of operations -- then `score > match_threshold` for
+// the matched pairs and `!(score[pair or dustbin row] < score_threshold)` of _attach_to_tracks (processor.py:228-231), both as numpy / torch
+// compare a float32 array with a Python float: in float32.  No device work.
+extern "C" int odam_assoc_attach(const float* score, int n_tracks, int n_det, int lds, double match_threshold, double score_threshold,
+                                 int* match_out, unsigned char* keep_out) {
+    if (!score || !match_out || !keep_out || n_tracks < 0 || n_det < 0 || lds < n_det + 1) return odam_fail(1, "odam_assoc_attach: bad argument");
+    for (int c = 0; c < n_det; c++) match_out[c] = -1;
+    const bool tr = n_det < n_tracks;                       // scipy transposes a tall matrix
+    const int nr = tr ? n_det : n_tracks, nc = tr ? n_tracks : n_det;
+    if (nr > 0) {
+        std::vector<double> cost((size_t)nr * nc), u(nr, 0.0), v(nc, 0.0), spc(nc);
+        std::vector<int> col4row(nr, -1), row4col(nc, -1), path(nc, -1), remaining(nc);
+        std::vector<unsigned char> SR(nr), SC(nc);
+        for (int r = 0; r < n_tracks; r++)
+            for (int c = 0; c < n_det; c++) {
+                const double x = (double)(1.0f - score[(size_t)r * lds + c]);      // numpy: float32 (1 - scores), widened by the solver
+                if (x != x || x == -__builtin_huge_val()) return odam_fail(4, "odam_assoc_attach: matrix contains invalid numeric entries");
+                cost[tr ? (size_t)c * nc + r : (size_t)r * nc + c] = x;
+            }
+        const double INF = __builtin_huge_val();
+        for (int cur = 0; cur < nr; cur++) {
+            double minVal = 0.0;
+            int num_remaining = nc, sink = -1, i = cur;
+            for (int it = 0; it < nc; it++) remaining[it] = nc - it - 1;
+            std::fill(SR.begin(), SR.end(), 0); std::fill(SC.begin(), SC.end(), 0); std::fill(spc.begin(), spc.end(), INF);
+            while (sink == -1) {
+                int index = -1;
+                double lowest = INF;
+                SR[i] = 1;
+                for (int it = 0; it < num_remaining; it++) {
+                    const int j = remaining[it];
+                    const double r = minVal + cost[(size_t)i * nc + j] - u[i] - v[j];
+                    if (r < spc[j]) { path[j] = i; spc[j] = r; }
+                    if (spc[j] < lowest || (spc[j] == lowest && row4col[j] == -1)) { lowest = spc[j]; index = it; }
+                }
+                minVal = lowest;
+                if (!(minVal < INF)) return odam_fail(5, "odam_assoc_attach: cost matrix is infeasible");
+                const int j = remaining[index];
+                if (row4col[j] == -1) sink = j; else i = row4col[j];
+                SC[j] = 1;
+                remaining[index] = remaining[--num_remaining];
+            }
+            u[cur] += minVal;
+            for (int r = 0; r < nr; r++) if (SR[r] && r != cur) u[r] += minVal - spc[col4row[r]];
+            for (int j = 0; j < nc; j++) if (SC[j]) v[j] -= minVal - spc[j];
+            int j = sink;
+            while (true) {
+                const int ii = path[j];
+                row4col[j] = ii;
+                const int t = col4row[ii]; col4row[ii] = j; j = t;
+                if (ii == cur) break;
+            }
+        }
+        const float mt = (float)match_threshold;
+        for (int r0 = 0; r0 < nr; r0++) {
+            const int r = tr ? col4row[r0] : r0, c = tr ? r0 : col4row[r0];
+            if (score[(size_t)r * lds + c] > mt) match_out[c] = r;
+        }
+    }
+    const float st = (float)score_threshold;
+    for (int c = 0; c < n_det; c++) {
+        const int r = match_out[c] < 0 ? n_tracks : match_out[c];      // index -1 reads the dustbin row, as in the reference
+        keep_out[c] = !(score[(size_t)r * lds + c] < st);
+    }
+    return 0;
+}
+
 extern "C" int odam_assoc_hungarian(const float* Z, int n_tracks, int n_det, int ldz, double threshold, int log_domain, int* match_out,
                                     int* status, void* stream) {
     if (!Z || !match_out || !status || n_tracks < 0 || n_det < 0 || ldz < n_det)

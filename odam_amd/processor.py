@@ -15,6 +15,7 @@ What is different underneath:
 The associator (src/models/associator.py) is the reference's own and stays caller-supplied; the track merge
 between the two fit passes is restated in odam_amd/merge.py (run_merge.py:79-130).
 """
+import ctypes
 import logging
 
 import numpy as np
@@ -565,19 +566,24 @@ class OdamProcess:
     def _attach_fast(self, Z, cur):
         """hungarian_matching + _attach_to_tracks (src/models/associator.py:19-35, src/processor.py:212-257) on the assignment of a
         fast frame: the same tests on the same float32 values; the rows go to the record list and to the mirror's next append"""
-        from scipy.optimize import linear_sum_assignment
+        from . import _lib
         n_det = cur["det32T"].shape[1]
-        # hungarian_matching (associator.py:19-35) on the float32 scores torch computes, without its Python loop: the assignment of
-        # linear_sum_assignment(1 - scores), kept where the matched score exceeds the match threshold
-        score_mat = Z.exp().numpy()              # ONE exponential (elementwise: its [:-1, :-1] block is what Z[:-1, :-1].exp() computes)
-        scores = score_mat[:-1, :-1]
-        r_, c_ = linear_sum_assignment(1 - scores)
-        ok = scores[r_, c_] > self.match_threshold
-        match = np.full(n_det, -1, np.int32)
-        match[c_[ok]] = r_[ok]
-        # _attach_to_tracks' tests (processor.py:228-231): a detection is dropped if the score of its pair -- for an unmatched one the
-        # dustbin row, index -1 -- is below the score threshold (a NaN is not below anything: kept, as in the loop)
-        keep = ~(score_mat[match, np.arange(n_det)] < self.score_threshold)
+        # hungarian_matching (associator.py:19-35) on the float32 scores torch computes -- linear_sum_assignment(1 - scores), kept where the
+        # matched score exceeds the match threshold -- and _attach_to_tracks' test (processor.py:228-231: a detection is dropped if the score
+        # of its pair, for an unmatched one the dustbin row, is below the score threshold; a NaN is not below anything: kept, as in the
+        # loop): ONE native host call on ONE exponential (odam_assoc_attach restates scipy's solver with its tie order;
+        # tests/test_assoc_host.py holds it to scipy on random, tie-ridden and fixture matrices)
+        score_mat = Z.exp()
+        att = getattr(self, "_att", None)
+        if att is None:      # result buffers and their addresses, once (numpy's .ctypes.data_as costs 3 us a call, np.empty + two of them 7)
+            m_, k_ = np.empty(32, np.int32), np.empty(32, np.uint8)
+            att = self._att = (m_, k_, ctypes.c_void_p(m_.ctypes.data), ctypes.c_void_p(k_.ctypes.data), _lib.lib().odam_assoc_attach)
+        rc = att[4](ctypes.c_void_p(score_mat.data_ptr()), Z.shape[0] - 1, n_det, Z.shape[1], ctypes.c_double(self.match_threshold),
+                    ctypes.c_double(self.score_threshold), att[2], att[3])
+        if rc in (4, 5):      # what scipy raises for the same matrices
+            raise ValueError("matrix contains invalid numeric entries" if rc == 4 else "cost matrix is infeasible")
+        _lib.check(rc, "odam_assoc_attach")
+        match, keep = att[0][:n_det], att[1][:n_det]
         picked = np.flatnonzero(keep)
         mk = match[picked]
         new = mk == -1

@@ -41,14 +41,40 @@ def run(mode):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / N * 1e3
     return dt, [t.copy() for t in proc.tracks]
+def _attach_numpy(self, Z, cur):
+    """the attach step as numpy + scipy computed it before odam_assoc_attach (A/B: ATTACH_AB=1 adds a 'batched-np' line per repetition)"""
+    from scipy.optimize import linear_sum_assignment
+    n_det = cur["det32T"].shape[1]
+    score_mat = Z.exp().numpy()
+    scores = score_mat[:-1, :-1]
+    r_, c_ = linear_sum_assignment(1 - scores)
+    ok = scores[r_, c_] > self.match_threshold
+    match = np.full(n_det, -1, np.int32)
+    match[c_[ok]] = r_[ok]
+    keep = ~(score_mat[match, np.arange(n_det)] < self.score_threshold)
+    picked = np.flatnonzero(keep)
+    mk = match[picked]
+    new = mk == -1
+    n_tracks = self._n_tracks
+    ids_a = mk.astype(np.int64)
+    ids_a[new] = n_tracks + np.arange(int(new.sum()))
+    n_tracks += int(new.sum())
+    ids_ = ids_a.tolist()
+    if ids_:
+        sel = cur["rows82"][picked]
+        self._pending.append((ids_, sel)); self._pending_app = (ids_, sel); self._n_tracks = n_tracks; self._win_meta_stale = True
+_native_attach = OdamProcess._attach_fast
 ref = None
-for rep in range(2):
-    for mode in ("host", "single", "batched"):
-        ms, tr = run(mode)
+modes = ("host", "single", "batched") + (("batched-np", "batched") if os.environ.get("ATTACH_AB") else ())
+for rep in range(2 if not os.environ.get("ATTACH_AB") else 3):
+    for mode in modes:
+        OdamProcess._attach_fast = _attach_numpy if mode == "batched-np" else _native_attach
+        ms, tr = run("batched" if mode == "batched-np" else mode)
         if ref is None:
             ref = tr
         same = len(tr) == len(ref) and all(a.shape == b.shape and np.array_equal(a, b) for a, b in zip(tr, ref))
         print(f"{mode:8s} {ms:.3f} ms per frame, {len(tr)} tracks, identical to the step-by-step path: {same}", flush=True)
+OdamProcess._attach_fast = _native_attach
 print("lost launches", net.lost_launches)
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable(); run("batched"); pr.disable()
