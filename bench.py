@@ -780,10 +780,25 @@ def config4_block(device, args, pmc):
     det(det.preprocess_u8(frames[:B]))
     torch.cuda.synchronize()
     n_launch, conv_ms, conv_flops = det.profile_read(H, W)
+    att_n, att_ms, att_flops = det.profile_read_attention(H, W)
     det.profile(H, W, False)
     det.close(); fitter.close()
     fps_det = n_frames / (t1 - t0)
-    return {"workload": "DETR-R101, %d frames 800x600 -> 800x1066, bf16 (fp32 accumulate / softmax / LayerNorm / heads), batches of %d on %d "
+    att_busy = (pmc.get("mfma_util_bf16_r101") or {}).get("odam_dk::attention_bf16_kernel")
+    attention = None
+    if att_ms > 0:
+        attention = {"achieved": att_flops / (att_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA / 1e12, "unit": "TFLOP/s",
+                     "frac": att_flops / (att_ms * 1e-3) / PEAK_BF16_MFMA,
+                     "matrix_pipe_busy_pmc": att_busy,
+                     "kernel": "attention_bf16_kernel (bf16 operands, fp32 softmax; V read transposed from a row-major LDS image, one v_cvt_pk_bf16_f32 "
+                               "per pair of probabilities)",
+                     "launches_per_forward": att_n, "ms_per_forward": att_ms, "batch": B,
+                     "bound_note": "vector issue, not the matrix pipe: per 64-key tile a wave issues 8 matrix instructions (256 cycles of pipe) beside "
+                                   "~150 vector instructions of softmax at d_head = 32 (DESIGN 7.3): <= ~0.3 of the pipe at best",
+                     "measured": "QK^T + PV flops of the attention launches of one forward / their durations (HIP events, one forward alone on one "
+                                 "stream); matrix_pipe_busy_pmc from profiles/pmc_summary.json (SQ_VALU_MFMA_BUSY_CYCLES, not measured in this run)"}
+    return {"attention_kernel": attention,
+            "workload": "DETR-R101, %d frames 800x600 -> 800x1066, bf16 (fp32 accumulate / softmax / LayerNorm / heads), batches of %d on %d "
                         "streams + 2 passes of 200-step SQ fit over %d objects (fp32)" % (n_frames, B, args.config4_streams, len(scene["tracks"])),
             "dtype": "bf16", "frames_per_s_detect": fps_det, "fit_ms_two_passes": 1e3 * (t2 - t1),
             "frames": n_frames, "extrapolated": False,
