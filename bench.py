@@ -883,7 +883,7 @@ def cpu_baseline(scene, tracks, N):
     sq_ag = len(t_on) / sum(t_on)
     e2e = N / (N / det_fps + 2 * len(tracks) / sq_ag)
     e2e_port = N / (N / det_fps + 2 * len(tracks) / sq_ops)
-    return {"value": e2e, "unit": "frames/s", "cores": ncpu, "threads_used": best, "kind": "port",
+    return {"value": e2e, "unit": "frames/s", "cores": best, "threads_used": best, "host_logical_cores": ncpu, "kind": "port",      # cores = the threads the reported figure used (detector leg; the SQ leg runs on 1)
             "sample": f"detector oracle (torch CPU fp32, host transform + forward + post-processing): 5 frames at each of "
                       f"{sorted(sweep)} threads, median of the single-frame rates per thread count, the best reported ({best} threads: "
                       f"{det_fps:.3f} frames/s, min {min(per[best]):.3f} max {max(per[best]):.3f}) on a host with "
